@@ -1,0 +1,285 @@
+"""Generate golden input/output vectors by running the *reference itself* on CPU.
+
+Run in the build container only:   python tests/golden/make_golden.py
+(needs /root/reference; see _refload.py).  Outputs: tests/golden/*.npz — data only
+(inputs + expected outputs); no reference source is stored.
+
+Fixture families:
+  scan_*.npz      selective_scan_ref fwd + autograd bwd on the reference's own test
+                  distribution (kernels/selective_scan/test_selective_scan.py:593-654)
+  csm.npz         CrossScan / CrossMerge fwd+bwd           (model/vmamba.py:27-73)
+  dwconv.npz      depthwise conv3x3 + bias + SiLU fwd+bwd  (model/vmamba.py:859-868,1543-1545)
+  ss2d.npz        one SS2D + one VSSBlock, d_model 16, 16x16, fwd + all grads
+  stft.npz        wav2spectro / spectro2wav                (utils/stft.py:22-115)
+  model_tiny.npz  DualStreamInteractiveMambaUNet dims=4, n_fft=128 fwd + grads + LSD
+  metric.npz      LSD / SNR / LSD-HF / LSD-LF on fixed pairs (model/metric.py)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _refload import load_reference, patch_ss2d_to_cpu  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def _np(t):
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype == torch.bfloat16 or t.dtype == torch.float16:
+        t = t.float()
+    return t.cpu().numpy()
+
+
+def save(name, **arrs):
+    arrs = {k: v for k, v in arrs.items() if v is not None}
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrs)} arrays")
+
+
+# --------------------------------------------------------------------------------------
+def gen_scan(ns):
+    """(B, KD, G, N, L) cases x flag combos; seed 0; reference distribution."""
+    cases = [
+        # tag,        B, KD, G, N,  L,   itype
+        ("b2d24g2n1l64", 2, 24, 2, 1, 64, torch.float32),
+        ("b2d24g4n1l65", 2, 24, 4, 1, 65, torch.float32),
+        ("b1d8g4n1l4113", 1, 8, 4, 1, 4113, torch.float32),
+        ("b2d16g4n8l300", 2, 16, 4, 8, 300, torch.float32),
+        ("b1d8g4n32l520", 1, 8, 4, 32, 520, torch.float32),
+        ("b2d8g1n1l1", 2, 8, 1, 1, 1, torch.float32),
+        ("b1d4g4n1l1023", 1, 4, 4, 1, 1023, torch.float32),
+        ("b2d24g2n1l256bf16", 2, 24, 2, 1, 256, torch.bfloat16),
+        ("b2d24g2n1l256fp16", 2, 24, 2, 1, 256, torch.float16),
+    ]
+    for tag, Bn, KD, G, N, L, itype in cases:
+        combos = [(True, True, True)]
+        if itype == torch.float32 and L <= 300 and N == 1:
+            combos = [(d, b, s) for d in (False, True) for b in (False, True) for s in (False, True)]
+        elif itype == torch.float32 and L <= 300:
+            combos = [(True, True, True), (False, False, False)]
+        out = {}
+        for has_D, has_bias, softplus in combos:
+            torch.random.manual_seed(0)
+            A = (-0.5 * torch.rand(KD, N)).requires_grad_()
+            Bm = torch.randn(Bn, G, N, L).to(itype).requires_grad_()
+            Cm = torch.randn(Bn, G, N, L).to(itype).requires_grad_()
+            D = torch.randn(KD).requires_grad_() if has_D else None
+            bias = (0.5 * torch.rand(KD)).requires_grad_() if has_bias else None
+            u = torch.randn(Bn, KD, L).to(itype).requires_grad_()
+            delta = (0.5 * torch.rand(Bn, KD, L)).to(itype).requires_grad_()
+            y, last = ns.selective_scan_ref(u, delta, A, Bm, Cm, D, None, bias, softplus,
+                                            return_last_state=True)
+            g = torch.randn(y.shape).to(itype)
+            y.backward(g)
+            key = f"D{int(has_D)}b{int(has_bias)}s{int(softplus)}"
+            if not out:
+                out.update(u=_np(u), delta=_np(delta), A=_np(A), B=_np(Bm), C=_np(Cm), dout=_np(g))
+                out["meta"] = np.array([Bn, KD, G, N, L, {torch.float32: 0, torch.float16: 1,
+                                                          torch.bfloat16: 2}[itype]])
+            # inputs are identical across combos only if RNG draws match; store per combo
+            out[f"{key}_u"] = _np(u)
+            out[f"{key}_delta"] = _np(delta)
+            out[f"{key}_dout"] = _np(g)
+            if has_D:
+                out[f"{key}_D"] = _np(D)
+                out[f"{key}_dD"] = _np(D.grad)
+            if has_bias:
+                out[f"{key}_bias"] = _np(bias)
+                out[f"{key}_dbias"] = _np(bias.grad)
+            out[f"{key}_out"] = _np(y)
+            out[f"{key}_last"] = _np(last)
+            out[f"{key}_du"] = _np(u.grad)
+            out[f"{key}_ddelta"] = _np(delta.grad)
+            out[f"{key}_dA"] = _np(A.grad)
+            out[f"{key}_dB"] = _np(Bm.grad)
+            out[f"{key}_dC"] = _np(Cm.grad)
+        # drop redundant top-level copies of combo-varying inputs
+        for k in ("u", "delta", "dout"):
+            out.pop(k)
+        save(f"scan_{tag}.npz", **out)
+
+
+def gen_csm(ns):
+    out = {}
+    for tag, shape in (("a", (2, 3, 5, 7)), ("b", (1, 2, 64, 64)), ("c", (2, 4, 16, 48))):
+        torch.manual_seed(1)
+        x = torch.randn(*shape, requires_grad=True)
+        xs = ns.vmamba.CrossScan.apply(x)
+        g = torch.randn_like(xs)
+        xs.backward(g)
+        Bn, C, H, W = shape
+        ys = torch.randn(Bn, 4, C, H, W, requires_grad=True)
+        y = ns.vmamba.CrossMerge.apply(ys)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        out.update({f"{tag}_x": _np(x), f"{tag}_xs": _np(xs), f"{tag}_gxs": _np(g),
+                    f"{tag}_dx": _np(x.grad), f"{tag}_ys": _np(ys), f"{tag}_y": _np(y),
+                    f"{tag}_gy": _np(gy), f"{tag}_dys": _np(ys.grad)})
+    save("csm.npz", **out)
+
+
+def gen_dwconv(ns):
+    out = {}
+    for tag, shape in (("a", (2, 4, 9, 11)), ("b", (1, 32, 16, 16)), ("c", (2, 2, 40, 24))):
+        torch.manual_seed(2)
+        Bn, C, H, W = shape
+        conv = torch.nn.Conv2d(C, C, 3, padding=1, groups=C, bias=True)
+        x = torch.randn(*shape, requires_grad=True)
+        y = F.silu(conv(x))
+        g = torch.randn_like(y)
+        y.backward(g)
+        out.update({f"{tag}_x": _np(x), f"{tag}_w": _np(conv.weight), f"{tag}_b": _np(conv.bias),
+                    f"{tag}_y": _np(y), f"{tag}_g": _np(g), f"{tag}_dx": _np(x.grad),
+                    f"{tag}_dw": _np(conv.weight.grad), f"{tag}_db": _np(conv.bias.grad)})
+    save("dwconv.npz", **out)
+
+
+def _module_fixture(prefix, module, x, out):
+    module.zero_grad()
+    x = x.clone().requires_grad_()
+    y = module(x)
+    torch.manual_seed(99)
+    g = torch.randn_like(y)
+    y.backward(g)
+    out[f"{prefix}_x"] = _np(x)
+    out[f"{prefix}_y"] = _np(y)
+    out[f"{prefix}_g"] = _np(g)
+    out[f"{prefix}_dx"] = _np(x.grad)
+    for k, v in module.state_dict().items():
+        out[f"{prefix}_sd::{k}"] = _np(v)
+    for k, p in module.named_parameters():
+        if p.grad is not None:
+            out[f"{prefix}_grad::{k}"] = _np(p.grad)
+
+
+def gen_ss2d(ns):
+    out = {}
+    torch.manual_seed(3)
+    for tag, d_model, d_state, H, W in (("ss2d16", 16, 1, 16, 16), ("ss2d8n4", 8, 4, 8, 12),
+                                        ("ss2d1", 1, 1, 32, 32)):
+        m = ns.vmamba.SS2D(d_model=d_model, d_state=d_state, ssm_ratio=2.0, dt_rank="auto",
+                           act_layer=torch.nn.SiLU, d_conv=3, conv_bias=True, dropout=0.0,
+                           initialize="v0", forward_type="v5", channel_first=False)
+        patch_ss2d_to_cpu(ns, m)
+        # make Ds / A_logs / biases non-trivial so parity is meaningful
+        with torch.no_grad():
+            m.Ds.add_(0.1 * torch.randn_like(m.Ds))
+            m.A_logs.add_(0.3 * torch.randn_like(m.A_logs))
+            m.out_norm.weight.add_(0.1 * torch.randn_like(m.out_norm.weight))
+            m.out_norm.bias.add_(0.1 * torch.randn_like(m.out_norm.bias))
+        x = torch.randn(2, H, W, d_model)
+        _module_fixture(tag, m, x, out)
+    blk = ns.vmamba.VSSBlock(hidden_dim=16, drop_path=0.0, norm_layer=torch.nn.LayerNorm,
+                             channel_first=False, ssm_d_state=1, ssm_ratio=2.0,
+                             ssm_dt_rank="auto", ssm_act_layer=torch.nn.SiLU, ssm_conv=3,
+                             ssm_conv_bias=True, ssm_drop_rate=0.0, ssm_init="v0",
+                             forward_type="v5", mlp_ratio=4.0, mlp_act_layer=torch.nn.GELU,
+                             mlp_drop_rate=0.0, gmlp=False)
+    patch_ss2d_to_cpu(ns, blk)
+    x = torch.randn(2, 16, 16, 16)
+    _module_fixture("vssblock16", blk, x, out)
+    save("ss2d.npz", **out)
+
+
+def gen_stft(ns):
+    out = {}
+    torch.manual_seed(4)
+    # (tag, T, n_fft, hop, win)
+    for tag, T, n_fft, hop, win in (("s", 2400, 1024, 240, 1024), ("t", 2016, 128, 32, 128),
+                                    ("w", 4800, 2048, 240, 1024), ("r", 1000, 256, 80, 256)):
+        wav = 0.1 * torch.randn(2, 1, T)
+        mag, ph = ns.stft.wav2spectro(wav, n_fft, hop, win, "log2")
+        out.update({f"{tag}_wav": _np(wav), f"{tag}_mag": _np(mag), f"{tag}_phase": _np(ph),
+                    f"{tag}_cfg": np.array([n_fft, hop, win])})
+        # inverse with gradients wrt mag/phase (H3 needs backward)
+        m2 = (mag + 0.05 * torch.randn_like(mag)).requires_grad_()
+        p2 = (ph + 0.05 * torch.randn_like(ph)).requires_grad_()
+        rec = ns.stft.spectro2wav(m2, p2, n_fft, hop, win, "log2")
+        g = torch.randn_like(rec)
+        rec.backward(g)
+        out.update({f"{tag}_imag": _np(m2), f"{tag}_iphase": _np(p2), f"{tag}_rec": _np(rec),
+                    f"{tag}_grec": _np(g), f"{tag}_dmag": _np(m2.grad), f"{tag}_dphase": _np(p2.grad)})
+    # full-size clip: store checksums + 4 frames only
+    wav = 0.1 * torch.randn(1, 1, 122640)
+    mag, ph = ns.stft.wav2spectro(wav, 1024, 240, 1024, "log2")
+    rec = ns.stft.spectro2wav(mag, ph, 1024, 240, 1024, "log2")
+    fr = [0, 1, 255, 511]
+    out.update(big_wav=_np(wav), big_mag_frames=_np(mag[..., fr]), big_phase_frames=_np(ph[..., fr]),
+               big_frames=np.array(fr), big_mag_sum=np.array(mag.double().sum().item()),
+               big_mag_abs=np.array(mag.double().abs().sum().item()),
+               big_cos_sum=np.array(torch.cos(ph.double()).sum().item()),
+               big_rec_err=np.array((rec - wav).abs().max().item()),
+               big_shape=np.array(mag.shape))
+    save("stft.npz", **out)
+
+
+def gen_model(ns):
+    out = {}
+    torch.manual_seed(123)
+    kw = dict(in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=4, ssm_d_state=1, ssm_ratio=2.0,
+              ssm_dt_rank="auto", ssm_act_layer="silu", ssm_conv=3, ssm_conv_bias=True,
+              ssm_drop_rate=0.0, ssm_init="v0", forward_type="v5", mlp_ratio=4.0,
+              mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False, drop_path_rate=0.1,
+              patch_norm=True, norm_layer="LN", patchembed_version="v2", downsample_version="v1",
+              upsample_version="v1", output_version="v3", concat_skip=True, interact="dual",
+              n_fft=128, hop_length=32, win_length=128, spectro_scale="log2",
+              low_freq_replacement=True)
+    m = ns.model.DualStreamInteractiveMambaUNet(**kw)
+    patch_ss2d_to_cpu(ns, m)
+    # de-symmetrise the two streams (deepcopy init makes them identical) and make the
+    # zero-init / one-init tensors non-trivial so every op is exercised
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.add_(0.02 * torch.randn(p.shape, generator=g))
+    m.eval()  # DropPath off (stochastic)
+    T = 32 * 63
+    wave = 0.1 * torch.randn(2, 1, T, generator=g)
+    target = 0.1 * torch.randn(2, 1, T, generator=g)
+    hf = torch.full((2,), int(65 * 16000 / 48000), dtype=torch.int64)
+    y = m(wave, hf)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update(wave=_np(wave), target=_np(target), hf=_np(hf), y=_np(y), gy=_np(gy),
+               lsd=np.array(ns.metric.lsd(y.detach().squeeze(1), target.squeeze(1))),
+               snr=np.array(ns.metric.snr(y.detach().squeeze(1), target.squeeze(1))))
+    n_unused = 0
+    for k, v in m.state_dict().items():
+        out[f"sd::{k}"] = _np(v)
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            n_unused += 1
+        else:
+            out[f"grad::{k}"] = _np(p.grad)
+    out["n_unused"] = np.array(n_unused)
+    print(f"  tiny model: {sum(p.numel() for p in m.parameters())} params, "
+          f"{n_unused} tensors without grad")
+    save("model_tiny.npz", **out)
+
+
+def gen_metric(ns):
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    a = 0.1 * torch.randn(3, 8192, generator=g)
+    b = a + 0.02 * torch.randn(3, 8192, generator=g)
+    hf = torch.tensor([171, 300, 512])
+    out.update(a=_np(a), b=_np(b), hf=_np(hf),
+               lsd=np.array(ns.metric.lsd(a, b)), snr=np.array(ns.metric.snr(a, b)),
+               lsd_hf=np.array(ns.metric.lsd_hf(a, b, hf)), lsd_lf=np.array(ns.metric.lsd_lf(a, b, hf)))
+    save("metric.npz", **out)
+
+
+if __name__ == "__main__":
+    ns = load_reference()
+    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric"]
+    for w in which:
+        print(f"[{w}]")
+        globals()[f"gen_{w}"](ns)
