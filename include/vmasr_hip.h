@@ -1,0 +1,138 @@
+/*
+ * vmasr_hip.h — C ABI of libvmasr_hip.so, the MI355X (gfx950) implementation of the
+ * VM-ASR data-parallel hot path.  Plain pointers and sizes only: no torch types.
+ *
+ * Every entry point replaces one reference interface (file:line under the reference):
+ *
+ *   vmasr_sscan_fwd      selective_scan_cuda_core.fwd  kernels/selective_scan/csrc/selective_scan/cus/selective_scan.cpp:157-239
+ *                        (kernel cus/selective_scan_fwd_kernel.cuh:61-172; params selective_scan.h:26-62)
+ *   vmasr_sscan_bwd      selective_scan_cuda_core.bwd  cus/selective_scan.cpp:241-349
+ *                        (kernel cus/selective_scan_bwd_kernel.cuh:66-273; params selective_scan.h:64-90)
+ *   vmasr_cross_scan     CrossScanTriton.forward / CrossMergeTriton.backward   model/csm_triton.py:311-337 (kernel :7-79), model/vmamba.py:27-47
+ *   vmasr_cross_merge    CrossMergeTriton.forward / CrossScanTriton.backward   model/csm_triton.py:340-366 (kernel :82-154), model/vmamba.py:50-73
+ *   vmasr_dwconv_silu_*  SS2D.conv2d + act (depthwise 3x3, pad 1)               model/vmamba.py:859-868,1543-1545
+ *   vmasr_stft           wav2spectro                                            utils/stft.py:22-68
+ *   vmasr_istft(_bwd)    spectro2wav (+ its autograd)                           utils/stft.py:71-115
+ *
+ * All functions are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ * default stream), never synchronise the host, allocate nothing, and return 0 on
+ * success, a negative VMASR_E* code for a contract violation (nothing launched), or a
+ * positive hipError_t.  vmasr_last_error() gives a thread-local message.
+ *
+ * Device pointers must belong to the current HIP device of the calling thread.
+ */
+#ifndef VMASR_HIP_H
+#define VMASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMASR_ABI_VERSION 1
+
+typedef void *vmasr_stream_t; /* hipStream_t */
+
+enum { VMASR_F32 = 0, VMASR_F16 = 1, VMASR_BF16 = 2 };
+
+enum {
+    VMASR_OK = 0,
+    VMASR_EINVAL = -1,   /* shape / dtype / stride contract violated            */
+    VMASR_EALIGN = -2,   /* pointer or stride alignment not supported           */
+    VMASR_ENOSPACE = -3  /* workspace too small                                 */
+};
+
+int vmasr_abi_version(void);
+const char *vmasr_last_error(void);
+
+/* Sequence positions per saved scan state.  The reference saves one (prod a, h) pair
+ * per 2048-step chunk (cus/selective_scan.cpp:217-220); this library saves one per
+ * VMASR_SSCAN_CHUNK steps so that the backward can restart every wave-tile
+ * independently.  x has shape (batch, dim, n_chunks, 2*dstate) fp32 with
+ * n_chunks = ceil(seqlen / vmasr_sscan_chunk()). */
+#define VMASR_SSCAN_CHUNK 256
+int vmasr_sscan_chunk(void);
+
+/* POD mirror of SSMParamsBase (selective_scan.h:26-62).  Strides are in ELEMENTS.
+ * u, delta, B, C, out share `dtype`; A, D, delta_bias, x are fp32.  Last-dim (seqlen)
+ * stride is 1 for u, delta, B, C, out.  D_ptr / delta_bias_ptr may be NULL. */
+typedef struct vmasr_sscan_params {
+    int32_t batch, dim, seqlen, dstate, n_groups, n_chunks;
+    int32_t dtype;          /* VMASR_F32 / F16 / BF16 */
+    int32_t delta_softplus; /* bool */
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_group_stride, B_dstate_stride;
+    int64_t C_batch_stride, C_group_stride, C_dstate_stride;
+    int64_t u_batch_stride, u_d_stride;
+    int64_t delta_batch_stride, delta_d_stride;
+    int64_t out_batch_stride, out_d_stride;
+    const void *A_ptr, *B_ptr, *C_ptr, *D_ptr, *u_ptr, *delta_ptr, *delta_bias_ptr;
+    void *out_ptr; /* (batch, dim, seqlen) dtype                       */
+    void *x_ptr;   /* (batch, dim, n_chunks, 2*dstate) fp32 contiguous */
+} vmasr_sscan_params;
+
+/* POD mirror of SSMParamsBwd (selective_scan.h:64-90).  du, ddelta have `dtype`;
+ * dA, dB, dC, dD, ddelta_bias are fp32 and MUST BE ZERO-INITIALISED by the caller
+ * (they are accumulated, as in the reference: cus/selective_scan.cpp:319-327).
+ * dB, dC are (batch, n_groups, dstate, seqlen) fp32 contiguous.  `ws_ptr` is a scratch
+ * buffer of at least vmasr_sscan_bwd_workspace() bytes (may be NULL if that is 0). */
+typedef struct vmasr_sscan_bwd_params {
+    vmasr_sscan_params f; /* forward tensors; f.out_ptr unused; f.x_ptr = saved states */
+    int64_t dout_batch_stride, dout_d_stride;
+    int64_t du_batch_stride, du_d_stride;
+    int64_t ddelta_batch_stride, ddelta_d_stride;
+    int64_t dA_d_stride, dA_dstate_stride;
+    const void *dout_ptr;
+    void *du_ptr, *ddelta_ptr;
+    void *dA_ptr, *dB_ptr, *dC_ptr, *dD_ptr, *ddelta_bias_ptr;
+    void *ws_ptr;
+    size_t ws_bytes;
+} vmasr_sscan_bwd_params;
+
+int vmasr_sscan_fwd(const vmasr_sscan_params *p, vmasr_stream_t stream);
+size_t vmasr_sscan_bwd_workspace(const vmasr_sscan_bwd_params *p);
+int vmasr_sscan_bwd(const vmasr_sscan_bwd_params *p, vmasr_stream_t stream);
+
+/* Tuning knobs (process-wide; -1 = automatic).  rows: rows of one group handled per
+ * wave (1/2/4); split: 0 = one wave walks a whole row, 1 = tile-parallel 3-phase scan. */
+void vmasr_sscan_tune(int rows, int split);
+
+/* x (B,C,H,W) contiguous -> xs (B,4,C,H*W) contiguous; same dtype. */
+int vmasr_cross_scan(const void *x, void *xs, int32_t B, int32_t C, int32_t H, int32_t W,
+                     int32_t dtype, vmasr_stream_t stream);
+/* ys (B,4,C,H*W) contiguous -> y (B,C,H*W) contiguous; same dtype, fp32 accumulation. */
+int vmasr_cross_merge(const void *ys, void *y, int32_t B, int32_t C, int32_t H, int32_t W,
+                      int32_t dtype, vmasr_stream_t stream);
+
+/* y = silu(dwconv3x3(x, w) + bias); x,y (B,C,H,W) contiguous `dtype`; w (C,3,3), bias (C)
+ * fp32 (bias may be NULL). */
+int vmasr_dwconv_silu_fwd(const void *x, const float *w, const float *bias, void *y, int32_t B,
+                          int32_t C, int32_t H, int32_t W, int32_t dtype, vmasr_stream_t stream);
+/* dx (B,C,H,W) `dtype`; dw (C,3,3), db (C) fp32, ZERO-INITIALISED by the caller.
+ * ws: scratch of B*C*H*W floats (holds gy * silu'(pre)). */
+int vmasr_dwconv_silu_bwd(const void *x, const float *w, const float *bias, const void *gy,
+                          void *dx, float *dw, float *db, float *ws, int32_t B, int32_t C,
+                          int32_t H, int32_t W, int32_t dtype, vmasr_stream_t stream);
+
+/* wav (B,T) fp32 -> out0,out1 (B, n_fft/2+1, 1+T/hop) fp32.  center=True (reflect),
+ * periodic hann(win) centred in n_fft, onesided.  logmag!=0: out0 = log2(|S|+1e-8),
+ * out1 = angle(S); else out0 = Re S, out1 = Im S.  n_fft a power of two in [64, 4096]. */
+int vmasr_stft(const float *wav, float *out0, float *out1, int32_t B, int32_t T, int32_t n_fft,
+               int32_t hop, int32_t win, int32_t normalized, int32_t logmag,
+               vmasr_stream_t stream);
+/* mag,phase (B,F,M) fp32 -> wav (B, hop*(M-1)) fp32; n_fft = 2F-2, normalized=True,
+ * center=True.  ws: scratch of vmasr_istft_workspace() bytes. */
+size_t vmasr_istft_workspace(int32_t B, int32_t F, int32_t M, int32_t hop);
+int vmasr_istft(const float *mag, const float *phase, float *wav, int32_t B, int32_t F, int32_t M,
+                int32_t hop, int32_t win, void *ws, size_t ws_bytes, vmasr_stream_t stream);
+/* gradient of vmasr_istft wrt (mag, phase) given g = dL/dwav (B, hop*(M-1)). */
+int vmasr_istft_bwd(const float *mag, const float *phase, const float *g, float *dmag,
+                    float *dphase, int32_t B, int32_t F, int32_t M, int32_t hop, int32_t win,
+                    vmasr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMASR_HIP_H */

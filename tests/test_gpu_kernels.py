@@ -1,0 +1,320 @@
+"""GPU parity tests (pytest -m gpu): every HIP entry point, called through the C ABI
+(vm_asr_amd.* -> ctypes -> libvmasr_hip.so), against
+  (1) the committed reference-generated goldens (tests/golden/*.npz),
+  (2) the CPU oracle (oracle/) on seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances: fp32 1e-4 (north_star), bf16/fp16 the reference's own kernel-test tolerances
+(kernels/selective_scan/test_selective_scan.py:585-587)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def _t(a, dtype=torch.float32):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def _close(got, want, rtol, atol, what=""):
+    got = got.detach().float().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    excess = np.abs(got - want) - (atol + rtol * np.abs(want))
+    assert excess.max() <= 0, f"{what}: max|diff|={np.abs(got - want).max():.3e} (tol rtol={rtol}, atol={atol})"
+
+
+def _scaled(want, tol=1e-4):
+    return tol * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.fixture(autouse=True)
+def _reset_tune():
+    from vm_asr_amd import selective_scan as ss
+    ss.tune(-1, -1)
+    yield
+    ss.tune(-1, -1)
+
+
+# ------------------------------------------------------------------------------------------
+# selective scan vs goldens (reference output on the reference's own test distribution)
+# ------------------------------------------------------------------------------------------
+SCAN_FILES = sorted(glob.glob(os.path.join(GOLDEN, "scan_*.npz")))
+TUNES = [(-1, -1), (1, 0), (1, 1), (2, 1), (4, 0)]
+
+
+@pytest.mark.parametrize("tune", TUNES, ids=[f"r{r}s{s}" for r, s in TUNES])
+@pytest.mark.parametrize("path", SCAN_FILES, ids=[os.path.basename(p)[5:-4] for p in SCAN_FILES])
+def test_scan_golden(path, tune):
+    from vm_asr_amd import selective_scan as ss
+    z = np.load(path)
+    itype = int(z["meta"][5])
+    dt = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[itype]
+    rtol, atol = {0: (1e-4, 1e-4), 1: (3e-3, 5e-3), 2: (3e-2, 5e-2)}[itype]
+    ss.tune(*tune)
+    keys = sorted({k.split("_")[0] for k in z.files if k[0] == "D" and "_" in k})
+    for key in keys:
+        D = _t(z[f"{key}_D"]) if f"{key}_D" in z.files else None
+        bias = _t(z[f"{key}_bias"]) if f"{key}_bias" in z.files else None
+        sp = key.endswith("s1")
+        u, delta, dout = _t(z[f"{key}_u"], dt), _t(z[f"{key}_delta"], dt), _t(z[f"{key}_dout"], dt)
+        A, Bm, Cm = _t(z["A"]), _t(z["B"], dt), _t(z["C"], dt)
+        out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, sp, 1)
+        _close(out, z[f"{key}_out"], rtol, atol, f"{key} out")
+        # last saved state == reference last_state
+        N = A.shape[1]
+        last = x[:, :, -1].view(x.shape[0], x.shape[1], N, 2)[..., 1]
+        _close(last, z[f"{key}_last"], 1e-4, 1e-4, f"{key} last_state")
+        du, dd, dA, dB, dC, dD, db = ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, sp, 1)
+        g = 1 if itype == 0 else 2
+        _close(du, z[f"{key}_du"], rtol * g, atol * g if itype else _scaled(z[f"{key}_du"]), f"{key} du")
+        _close(dd, z[f"{key}_ddelta"], rtol * 5 if itype else rtol, atol * 10 if itype else _scaled(z[f"{key}_ddelta"]), f"{key} ddelta")
+        _close(dA, z[f"{key}_dA"], 1e-3 if itype else 1e-4, _scaled(z[f"{key}_dA"], 5e-3 if itype else 1e-4), f"{key} dA")
+        _close(dB, z[f"{key}_dB"], rtol, atol if itype else _scaled(z[f"{key}_dB"]), f"{key} dB")
+        _close(dC, z[f"{key}_dC"], rtol, atol if itype else _scaled(z[f"{key}_dC"]), f"{key} dC")
+        if D is not None:
+            _close(dD, z[f"{key}_dD"], 1e-3 if itype else 1e-4, _scaled(z[f"{key}_dD"], 5e-3 if itype else 1e-4), f"{key} dD")
+        if bias is not None:
+            _close(db, z[f"{key}_dbias"], 1e-3 if itype else 1e-4, _scaled(z[f"{key}_dbias"], 5e-3 if itype else 1e-4), f"{key} dbias")
+
+
+# ------------------------------------------------------------------------------------------
+# selective scan vs the CPU oracle on the §8 call shapes (scaled down in L where needed)
+# ------------------------------------------------------------------------------------------
+def _scan_inputs(Bn, KD, G, N, L, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    A = -0.5 * torch.rand(KD, N, generator=g)
+    Bm = torch.randn(Bn, G, N, L, generator=g)
+    Cm = torch.randn(Bn, G, N, L, generator=g)
+    D = torch.randn(KD, generator=g)
+    bias = 0.5 * torch.rand(KD, generator=g)
+    u = torch.randn(Bn, KD, L, generator=g)
+    delta = 0.5 * torch.rand(Bn, KD, L, generator=g)
+    dout = torch.randn(Bn, KD, L, generator=g)
+    return u, delta, A, Bm, Cm, D, bias, dout
+
+
+ORACLE_SHAPES = [  # (B, KD, G, N, L)
+    (2, 8, 4, 1, 16384), (1, 64, 4, 1, 4096), (2, 128, 4, 1, 2048), (1, 256, 4, 1, 4096),
+    (2, 512, 4, 1, 1024), (2, 1024, 4, 1, 256), (1, 8, 4, 32, 1024), (1, 16, 4, 1, 777),
+]
+
+
+@pytest.mark.parametrize("shape", ORACLE_SHAPES, ids=["x".join(map(str, s)) for s in ORACLE_SHAPES])
+def test_scan_vs_oracle(shape):
+    from vm_asr_amd import selective_scan as ss
+    Bn, KD, G, N, L = shape
+    cpu = _scan_inputs(*shape)
+    u, delta, A, Bm, Cm, D, bias, dout = [t.to(DEV) for t in cpu]
+    want = oracle.sscan_fwd(*[t.numpy() for t in cpu[:7]], True)
+    wdu, wdd, wdA, wdB, wdC, wdD, wdb = oracle.sscan_bwd(*[t.numpy() for t in cpu[:7]], cpu[7].numpy(), True)
+    for tune in ((-1, -1), (1, 0), (1, 1)):
+        ss.tune(*tune)
+        out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
+        # 1e-4 of the tensor scale: |out| reaches ~150 on this distribution and the fp32
+        # sequential oracle itself sits 1e-4 (absolute) away from a float64 evaluation
+        _close(out, want, 1e-4, _scaled(want), f"out tune={tune}")
+        du, dd, dA, dB, dC, dD, db = ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
+        for name, got, w in (("du", du, wdu), ("ddelta", dd, wdd), ("dA", dA, wdA), ("dB", dB, wdB),
+                             ("dC", dC, wdC), ("dD", dD, wdD), ("dbias", db, wdb)):
+            _close(got, w, 1e-4, _scaled(w), f"{name} tune={tune}")
+
+
+def test_scan_strided_inputs():
+    """Non-contiguous batch/dim strides and unaligned bases are part of the operator contract
+    (cus/selective_scan.cpp:80-95)."""
+    from vm_asr_amd import selective_scan as ss
+    Bn, KD, G, N, L = 2, 8, 4, 1, 515
+    cpu = _scan_inputs(Bn, KD, G, N, L, seed=3)
+    u, delta, A, Bm, Cm, D, bias, dout = [t.to(DEV) for t in cpu]
+    big_u = torch.zeros(Bn, KD * 2, L + 5, device=DEV)
+    big_u[:, ::2, 3:3 + L] = u
+    u_s = big_u[:, ::2, 3:3 + L]
+    assert not u_s.is_contiguous() and u_s.stride(-1) == 1
+    want = oracle.sscan_fwd(*[t.numpy() for t in cpu[:7]], True)
+    out, x = ss.fwd(u_s, delta, A, Bm, Cm, D, bias, True, 1)
+    _close(out, want, 1e-4, _scaled(want), "strided out")
+    du = ss.bwd(u_s, delta, A, Bm, Cm, D, bias, dout, x, True, 1)[0]
+    wdu = oracle.sscan_bwd(*[t.numpy() for t in cpu[:7]], cpu[7].numpy(), True)[0]
+    _close(du, wdu, 1e-4, _scaled(wdu), "strided du")
+
+
+def test_scan_autograd_function_and_full_size_properties():
+    """BASELINE full-size call shapes (B=4): modes agree with each other, linearity in u of
+    (out - D*u) and gradient consistency (<dout, J v> == <J^T dout, v>)."""
+    from vm_asr_amd import selective_scan as ss
+    for KD, L in ((8, 262144), (128, 16384), (1024, 256)):
+        Bn, G, N = 4, 4, 1
+        u, delta, A, Bm, Cm, D, bias, dout = [t.to(DEV) for t in _scan_inputs(Bn, KD, G, N, L, seed=1)]
+        outs = []
+        for tune in ((1, 0), (1, 1), (2, 1), (-1, -1)):
+            ss.tune(*tune)
+            outs.append(ss.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)[0])
+        sc = 1e-4 * max(1.0, outs[0].abs().max().item())
+        for o in outs[1:]:
+            assert torch.allclose(o, outs[0], rtol=1e-4, atol=sc)
+        ss.tune(-1, -1)
+        # linearity in u:  f(2u) - D*2u == 2 (f(u) - D*u)
+        o2 = ss.fwd(2 * u, delta, A, Bm, Cm, D, bias, True, 1)[0]
+        assert torch.allclose(o2, 2 * outs[-1], rtol=1e-4, atol=2 * sc)
+        # adjoint identity on the u-path
+        uu = u.clone().requires_grad_()
+        out = ss.SelectiveScanCore.apply(uu, delta, A, Bm, Cm, D, bias, True)
+        out.backward(dout)
+        v = torch.randn_like(u)
+        jv = ss.fwd(v, delta, A, Bm, Cm, D, bias, True, 1)[0]  # linear in u
+        lhs = (dout.double() * jv.double()).sum()
+        rhs = (uu.grad.double() * v.double()).sum()
+        assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (KD, L, lhs.item(), rhs.item())
+
+
+def test_scan_bf16_io():
+    from vm_asr_amd import selective_scan as ss
+    Bn, KD, G, N, L = 2, 32, 4, 1, 2048
+    cpu = _scan_inputs(Bn, KD, G, N, L, seed=2)
+    q = [t.to(torch.bfloat16) if i in (0, 1, 3, 4, 7) else t for i, t in enumerate(cpu)]
+    want = oracle.sscan_fwd(*[t.float().numpy() for t in q[:7]], True)
+    dev = [t.to(DEV) for t in q]
+    out, x = ss.fwd(*dev[:7], True, 1)
+    assert out.dtype == torch.bfloat16
+    _close(out, want, 3e-2, 5e-2, "bf16 out")
+    du, dd, dA, dB, dC, dD, db = ss.bwd(*dev[:7], dev[7], x, True, 1)
+    w = oracle.sscan_bwd(*[t.float().numpy() for t in q[:7]], q[7].float().numpy(), True)
+    assert du.dtype == torch.bfloat16 and dB.dtype == torch.bfloat16 and dA.dtype == torch.float32
+    _close(du, w[0], 6e-2, 1e-1, "bf16 du")
+    _close(dA, w[2], 1e-2, _scaled(w[2], 1e-2), "bf16 dA")
+
+
+# ------------------------------------------------------------------------------------------
+# cross scan / merge: bit-exact data movement
+# ------------------------------------------------------------------------------------------
+def test_cross_scan_merge_golden_and_oracle():
+    from vm_asr_amd import csm
+    z = np.load(os.path.join(GOLDEN, "csm.npz"))
+    for t in "abc":
+        x = _t(z[f"{t}_x"]).requires_grad_()
+        xs = csm.CrossScan.apply(x)
+        assert np.array_equal(xs.detach().cpu().numpy(), z[f"{t}_xs"])
+        xs.backward(_t(z[f"{t}_gxs"]))
+        _close(x.grad, z[f"{t}_dx"], 1e-6, 1e-6, "scan bwd")
+        ys = _t(z[f"{t}_ys"]).requires_grad_()
+        y = csm.CrossMerge.apply(ys)
+        _close(y, z[f"{t}_y"], 1e-6, 1e-6, "merge")
+        y.backward(_t(z[f"{t}_gy"]))
+        assert np.array_equal(ys.grad.cpu().numpy(), z[f"{t}_dys"])
+    # the six SS2D shapes of the 48 kHz config (B=1) + ragged, vs oracle, bit-exact
+    for C, H, W in ((2, 512, 512), (16, 256, 256), (32, 128, 128), (64, 64, 64), (128, 32, 32), (256, 16, 16),
+                    (3, 65, 130), (1, 1, 7)):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(1, C, H, W, generator=g)
+        assert np.array_equal(csm.cross_scan(x.to(DEV)).cpu().numpy(), oracle.cross_scan(x.numpy()))
+        ys = torch.randn(1, 4, C, H, W, generator=g)
+        got = csm.cross_merge(ys.to(DEV), H, W).cpu().numpy()
+        assert np.array_equal(got, oracle.cross_merge(ys.numpy())), (C, H, W)
+    # bf16 payload moves as raw bits
+    xb = torch.randn(2, 5, 33, 17).to(torch.bfloat16)
+    want = oracle.cross_scan(xb.float().numpy())
+    assert np.array_equal(csm.cross_scan(xb.to(DEV)).float().cpu().numpy(), want)
+
+
+def test_cross_scan_merge_roundtrip_full_size():
+    """merge(scan(x)) == 4x at the largest call shape (B=4, 512x512), a size-independent check."""
+    from vm_asr_amd import csm
+    x = torch.randn(4, 2, 512, 512, device=DEV)
+    y = csm.cross_merge(csm.cross_scan(x), 512, 512).view_as(x)
+    assert torch.equal(y, 4 * x)
+
+
+# ------------------------------------------------------------------------------------------
+# depthwise conv + SiLU
+# ------------------------------------------------------------------------------------------
+def test_dwconv_silu_golden_and_oracle():
+    from vm_asr_amd import dwconv
+    z = np.load(os.path.join(GOLDEN, "dwconv.npz"))
+    for t in "abc":
+        x = _t(z[f"{t}_x"]).requires_grad_()
+        w = _t(z[f"{t}_w"]).requires_grad_()
+        b = _t(z[f"{t}_b"]).requires_grad_()
+        y = dwconv.dwconv3x3_silu(x, w, b)
+        _close(y, z[f"{t}_y"], 1e-4, 1e-5, "y")
+        y.backward(_t(z[f"{t}_g"]))
+        _close(x.grad, z[f"{t}_dx"], 1e-4, 1e-5, "dx")
+        _close(w.grad, z[f"{t}_dw"], 1e-4, _scaled(z[f"{t}_dw"]), "dw")
+        _close(b.grad, z[f"{t}_db"], 1e-4, _scaled(z[f"{t}_db"]), "db")
+    for C, H, W in ((2, 512, 512), (32, 128, 128), (256, 16, 16), (3, 7, 130)):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(2, C, H, W, generator=g)
+        w = 0.3 * torch.randn(C, 1, 3, 3, generator=g)
+        b = 0.1 * torch.randn(C, generator=g)
+        gy = torch.randn(2, C, H, W, generator=g)
+        xd, wd, bd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        y = dwconv.dwconv3x3_silu(xd, wd, bd)
+        _close(y, oracle.dwconv_silu_fwd(x.numpy(), w.numpy(), b.numpy()), 1e-4, 1e-5, f"y {C}")
+        y.backward(gy.to(DEV))
+        dx, dw, db = oracle.dwconv_silu_bwd(x.numpy(), w.numpy(), b.numpy(), gy.numpy())
+        _close(xd.grad, dx, 1e-4, 1e-5, f"dx {C}")
+        _close(wd.grad, dw.reshape(C, 1, 3, 3), 1e-4, _scaled(dw), f"dw {C}")
+        _close(bd.grad, db, 1e-4, _scaled(db), f"db {C}")
+
+
+# ------------------------------------------------------------------------------------------
+# STFT / iSTFT
+# ------------------------------------------------------------------------------------------
+def _phase_close(a, b, mag, tol, what):
+    a = a.detach().cpu().numpy().astype(np.float64)
+    d = np.angle(np.exp(1j * (a - b.astype(np.float64))))
+    ok = mag > -12  # ignore bins with |S| < 2^-12: the angle of ~0 is noise in the reference too
+    assert np.abs(d[ok]).max() < tol, f"{what}: {np.abs(d[ok]).max():.3e}"
+
+
+def test_stft_istft_golden():
+    from vm_asr_amd import stft
+    z = np.load(os.path.join(GOLDEN, "stft.npz"))
+    for t in "stwr":
+        n_fft, hop, win = (int(v) for v in z[f"{t}_cfg"])
+        mag, ph = stft.wav2spectro(_t(z[f"{t}_wav"]), n_fft, hop, win, "log2")
+        assert tuple(mag.shape) == z[f"{t}_mag"].shape
+        _close(mag, z[f"{t}_mag"], 1e-4, 2e-4, f"{t} mag")
+        _phase_close(ph, z[f"{t}_phase"], z[f"{t}_mag"], 2e-3, f"{t} phase")
+        m2, p2 = _t(z[f"{t}_imag"]).requires_grad_(), _t(z[f"{t}_iphase"]).requires_grad_()
+        rec = stft.spectro2wav(m2, p2, n_fft, hop, win, "log2")
+        _close(rec, z[f"{t}_rec"], 1e-4, 1e-5, f"{t} rec")
+        rec.backward(_t(z[f"{t}_grec"]))
+        _close(m2.grad, z[f"{t}_dmag"], 1e-4, _scaled(z[f"{t}_dmag"], 1e-5), f"{t} dmag")
+        _close(p2.grad, z[f"{t}_dphase"], 1e-4, _scaled(z[f"{t}_dphase"], 1e-5), f"{t} dphase")
+    wav = _t(z["big_wav"])
+    mag, ph = stft.wav2spectro(wav, 1024, 240, 1024, "log2")
+    assert tuple(mag.shape) == tuple(z["big_shape"])
+    fr = z["big_frames"]
+    _close(mag[..., fr], z["big_mag_frames"], 1e-4, 2e-4, "big frames")
+    assert abs(mag.double().sum().item() - float(z["big_mag_sum"])) < 1e-4 * float(z["big_mag_abs"])
+    rec = stft.spectro2wav(mag, ph, 1024, 240, 1024, "log2")
+    assert (rec - wav).abs().max().item() < 1e-4  # STFT -> iSTFT round trip at the full clip size
+
+
+def test_stft_vs_oracle_batch4_full_clip():
+    from vm_asr_amd import stft
+    g = torch.Generator().manual_seed(11)
+    wav = 0.1 * torch.randn(4, 1, 122640, generator=g)
+    mag, ph = stft.wav2spectro(wav.to(DEV), 1024, 240, 1024, "log2")
+    om, op = oracle.stft(wav.numpy(), 1024, 240, 1024)
+    # typical |S| is 0.06 here; an fp32 FFT is good to ~1e-7 of that, so the log2 of bins below
+    # 2^-10 is dominated by rounding (in torch.stft as well): compare those in the linear domain
+    _close(torch.exp2(mag), np.exp2(om.astype(np.float64)), 1e-4, 1e-6, "|S|")
+    big = om > -10
+    d = np.abs(mag.cpu().numpy().astype(np.float64) - om)[big]
+    assert d.max() < 5e-4, f"log2|S| on bins above 2^-10: {d.max():.3e}"
+    _phase_close(ph, op, om, 2e-3, "phase")
+    re, im = stft.stft_complex(wav.to(DEV)[:, 0], 2048, 512, 2048)  # LSD's STFT (model/metric.py:5-12)
+    ore, oim = oracle.stft(wav.numpy()[:, 0], 2048, 512, 2048, normalized=False, logmag=False)
+    _close(re, ore, 1e-4, 1e-4, "re")
+    _close(im, oim, 1e-4, 1e-4, "im")

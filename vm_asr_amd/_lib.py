@@ -1,0 +1,101 @@
+"""ctypes loader for libvmasr_hip.so (C ABI: include/vmasr_hip.h).
+
+The library is built in-tree by `make -C vm_asr_amd/csrc` (see __graft_entry__.build).
+Missing library == hard error; there is deliberately no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvmasr_hip.so")
+
+c_i32, c_i64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+
+F32, F16, BF16 = 0, 1, 2
+
+
+class SScanParams(ctypes.Structure):
+    """POD mirror of vmasr_sscan_params (include/vmasr_hip.h)."""
+    _fields_ = (
+        [(n, c_i32) for n in ("batch", "dim", "seqlen", "dstate", "n_groups", "n_chunks", "dtype",
+                              "delta_softplus")]
+        + [(n, c_i64) for n in ("A_d_stride", "A_dstate_stride",
+                                "B_batch_stride", "B_group_stride", "B_dstate_stride",
+                                "C_batch_stride", "C_group_stride", "C_dstate_stride",
+                                "u_batch_stride", "u_d_stride", "delta_batch_stride", "delta_d_stride",
+                                "out_batch_stride", "out_d_stride")]
+        + [(n, c_vp) for n in ("A_ptr", "B_ptr", "C_ptr", "D_ptr", "u_ptr", "delta_ptr",
+                               "delta_bias_ptr", "out_ptr", "x_ptr")]
+    )
+
+
+class SScanBwdParams(ctypes.Structure):
+    """POD mirror of vmasr_sscan_bwd_params."""
+    _fields_ = (
+        [("f", SScanParams)]
+        + [(n, c_i64) for n in ("dout_batch_stride", "dout_d_stride", "du_batch_stride", "du_d_stride",
+                                "ddelta_batch_stride", "ddelta_d_stride", "dA_d_stride", "dA_dstate_stride")]
+        + [(n, c_vp) for n in ("dout_ptr", "du_ptr", "ddelta_ptr", "dA_ptr", "dB_ptr", "dC_ptr", "dD_ptr",
+                               "ddelta_bias_ptr", "ws_ptr")]
+        + [("ws_bytes", c_sz)]
+    )
+
+
+# name -> (restype, argtypes); every symbol declared in include/vmasr_hip.h
+SYMBOLS = {
+    "vmasr_abi_version": (ctypes.c_int, []),
+    "vmasr_last_error": (ctypes.c_char_p, []),
+    "vmasr_sscan_chunk": (ctypes.c_int, []),
+    "vmasr_sscan_fwd": (ctypes.c_int, [ctypes.POINTER(SScanParams), c_vp]),
+    "vmasr_sscan_bwd_workspace": (c_sz, [ctypes.POINTER(SScanBwdParams)]),
+    "vmasr_sscan_bwd": (ctypes.c_int, [ctypes.POINTER(SScanBwdParams), c_vp]),
+    "vmasr_sscan_tune": (None, [ctypes.c_int, ctypes.c_int]),
+    "vmasr_cross_scan": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_cross_merge": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_dwconv_silu_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_dwconv_silu_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                             c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_stft": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_istft_workspace": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "vmasr_istft": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "vmasr_istft_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libvmasr_hip.so (once) and type its entry points."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C vm_asr_amd/csrc` "
+                "(or __graft_entry__.build()). vm_asr_amd has no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = res, args
+        if l.vmasr_abi_version() != 1:
+            raise RuntimeError("libvmasr_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().vmasr_last_error().decode() or "unknown error"
+        raise RuntimeError(f"{what} failed ({code}): {msg}")
+
+
+def torch_dtype_code(dt):
+    import torch
+    try:
+        return {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}[dt]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {dt}: expected float32 / float16 / bfloat16")
+
+
+def current_stream(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

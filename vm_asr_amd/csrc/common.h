@@ -1,0 +1,110 @@
+// common.h — shared device/host helpers for libvmasr_hip (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "vmasr_hip.h"
+
+#define VMASR_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace vmasr {
+
+// ---- host-side error plumbing -------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define VMASR_REQUIRE(cond, code, ...)      \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::vmasr::set_error(__VA_ARGS__); \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ---- element types -------------------------------------------------------------------
+using f16_t = _Float16;
+using bf16_t = __bf16;
+
+template <typename T> struct VecOf4;
+template <> struct VecOf4<float> { using type = float4; };
+template <> struct VecOf4<f16_t> { using type = uint2; };
+template <> struct VecOf4<bf16_t> { using type = uint2; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+constexpr int kWave = 64;
+
+// 4 consecutive elements starting at p[t] (t may run past `len`; out-of-range -> fill).
+// VEC: p + t is 4-element aligned and the caller guarantees 16-B (fp32) / 8-B (16-bit)
+// alignment of the row base, so a full quad is one dwordx4 / dwordx2 load.
+template <typename T, bool VEC>
+__device__ __forceinline__ void load4(const T *__restrict__ p, int t, int len, float (&v)[4],
+                                      float fill = 0.f) {
+    if (VEC && t + 3 < len) {
+        if constexpr (sizeof(T) == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(p + t);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            union { uint2 raw; T e[4]; } q;
+            q.raw = *reinterpret_cast<const uint2 *>(p + t);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = to_f32(q.e[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (t + i < len) ? to_f32(p[t + i]) : fill;
+    }
+}
+
+template <typename T, bool VEC>
+__device__ __forceinline__ void store4(T *__restrict__ p, int t, int len, const float (&v)[4]) {
+    if (VEC && t + 3 < len) {
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4 *>(p + t) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            union { uint2 raw; T e[4]; } q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q.e[i] = from_f32<T>(v[i]);
+            *reinterpret_cast<uint2 *>(p + t) = q.raw;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t + i < len) p[t + i] = from_f32<T>(v[i]);
+    }
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// wave64 all-reduce sum (result valid in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// XCD-aware block remap (blocks b and b+8 share an XCD under round-robin dispatch): give
+// each XCD a contiguous run of logical blocks so neighbours that share operand tiles hit
+// the same L2.  Pure speed: any placement is correct.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    return (nblocks % 8 == 0) ? (bid % 8) * (nblocks / 8) + bid / 8 : bid;
+}
+
+inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace vmasr

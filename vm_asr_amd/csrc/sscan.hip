@@ -1,0 +1,724 @@
+// sscan.hip — SS2D selective scan, forward and backward, for gfx950 (wave64).
+//
+// Replaces selective_scan_cuda_core.{fwd,bwd} of the reference
+// (kernels/selective_scan/csrc/selective_scan/cus/selective_scan.cpp:157-349, kernels
+// cus/selective_scan_fwd_kernel.cuh:61-172 and cus/selective_scan_bwd_kernel.cuh:66-273).
+// Same mathematics, different machine mapping:
+//
+//   * unit of work = one WAVE-TILE: 64 lanes x 4 consecutive steps = 256 steps of R rows
+//     that share one (batch, group) and therefore one B/C tile (loaded once per wave);
+//   * the recurrence h_t = a_t h_{t-1} + b_t is a scan over the monoid (a,b): 4 steps are
+//     composed per lane, the 64 lane aggregates are scanned across the wave with
+//     cross-lane shuffles, and the running state is a wave-uniform register (N==1) or an
+//     LDS slot (general N);  there is no block-wide barrier in the forward;
+//   * the sequence axis is parallelised two ways, chosen per call shape:
+//       mode 0  one wave walks a whole row tile by tile (rows*batch fills the chip);
+//       mode 1  tile-parallel 3-phase scan: per-tile aggregates -> scan of aggregates
+//               (this produces the saved states x) -> per-tile apply;
+//   * x holds the state at the END of every 256-step tile, so the backward restarts the
+//     forward recurrence of every tile independently; only the reverse (adjoint) scan
+//     carries across tiles, handled with the same two modes;
+//   * dB/dC (summed over the rows of a group) are reduced across the waves of a workgroup
+//     in LDS and leave as 256-B contiguous float atomics (or plain stores when one
+//     workgroup owns the whole group).
+//
+// HBM roofline: algorithmic bytes are (3 KD + 2 K N) L s forward and (5 KD + 4 K N) L s
+// backward per clip.
+#include "common.h"
+
+namespace vmasr {
+namespace {
+
+constexpr int kItems = 4;
+constexpr int kTile = kWave * kItems;  // 256 == VMASR_SSCAN_CHUNK
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kMaxDState = 256;
+static_assert(kTile == VMASR_SSCAN_CHUNK, "tile must equal the saved-state chunk");
+
+struct Pair {
+    float a, b;  // h -> a*h + b
+};
+
+// apply `first`, then `second`
+__device__ __forceinline__ Pair then(Pair first, Pair second) {
+    return {second.a * first.a, fmaf(second.a, first.b, second.b)};
+}
+
+// forward inclusive scan across the wave: lane i <- p_0 then p_1 ... then p_i
+__device__ __forceinline__ Pair wave_scan_fwd(Pair v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Pair o{__shfl_up(v.a, off), __shfl_up(v.b, off)};
+        if (lane >= off) v = then(o, v);
+    }
+    return v;
+}
+
+// reverse inclusive scan: lane i <- p_63 then ... then p_i   (g_i = b_i + a_i * g_{i+1})
+__device__ __forceinline__ Pair wave_scan_rev(Pair v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Pair o{__shfl_down(v.a, off), __shfl_down(v.b, off)};
+        if (lane + off < kWave) v = then(o, v);
+    }
+    return v;
+}
+
+__device__ __forceinline__ float softplus_f(float x) {
+    // threshold 20 as in the reference (cus/selective_scan_fwd_kernel.cuh:115-118)
+    return x <= 20.f ? log1pf(__expf(x)) : x;
+}
+
+struct TaskMap {
+    int b, d0, g, tile0, tile1;
+    bool valid;
+};
+
+// tasks: row-block fastest (the waves of a workgroup share B/C lines), then segment, then batch.
+template <int R>
+__device__ __forceinline__ TaskMap map_task(const vmasr_sscan_params &p, int task, int tiles_per_task,
+                                            int nseg, int ntiles) {
+    TaskMap m;
+    const int nrb = p.dim / R;
+    const int rb = task % nrb;
+    const int rest = task / nrb;
+    const int seg = rest % nseg;
+    m.b = rest / nseg;
+    m.valid = m.b < p.batch;
+    m.d0 = rb * R;
+    m.g = m.d0 / (p.dim / p.n_groups);
+    m.tile0 = seg * tiles_per_task;
+    m.tile1 = min(ntiles, m.tile0 + tiles_per_task);
+    return m;
+}
+
+// =====================================================================================
+// forward
+//   MODE 0: carry-in zero at tile 0, sequential over [tile0,tile1), writes x per tile
+//   MODE 1: carry-in from x[tile0-1] (already scanned by the carry kernel), no x write
+//   MODE 2: aggregates only: writes the tile-local pair (prod a, h_end | h_in = 0) to x
+// DYN: general d_state (runtime loop over states, running state in LDS, R must be 1);
+// otherwise d_state == 1 and the running state lives in registers.
+// =====================================================================================
+template <typename T, int R, bool DYN, bool VEC, int MODE>
+__global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params p,
+                                                        const int tiles_per_task, const int nseg) {
+    static_assert(!DYN || R == 1, "general-N path handles one row per wave");
+    __shared__ float s_h[DYN ? 4 * kMaxDState : 1];
+    __shared__ float s_p[DYN ? 4 * kMaxDState : 1];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = (p.seqlen + kTile - 1) / kTile;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const TaskMap m = map_task<R>(p, bid * 4 + wave, tiles_per_task, nseg, ntiles);
+    if (!m.valid) return;
+    const int L = p.seqlen, N = DYN ? p.dstate : 1;
+
+    const T *__restrict__ Bg = static_cast<const T *>(p.B_ptr) + m.b * p.B_batch_stride + m.g * p.B_group_stride;
+    const T *__restrict__ Cg = static_cast<const T *>(p.C_ptr) + m.b * p.C_batch_stride + m.g * p.C_group_stride;
+    const float *__restrict__ Ap = static_cast<const float *>(p.A_ptr);
+    float *__restrict__ xp = static_cast<float *>(p.x_ptr);
+
+    const T *u_row[R], *dl_row[R];
+    T *out_row[R];
+    float Dv[R], bias[R], h_in[R], p_in[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int d = m.d0 + r;
+        u_row[r] = static_cast<const T *>(p.u_ptr) + m.b * p.u_batch_stride + d * p.u_d_stride;
+        dl_row[r] = static_cast<const T *>(p.delta_ptr) + m.b * p.delta_batch_stride + d * p.delta_d_stride;
+        out_row[r] = static_cast<T *>(p.out_ptr) + m.b * p.out_batch_stride + d * p.out_d_stride;
+        Dv[r] = p.D_ptr ? static_cast<const float *>(p.D_ptr)[d] : 0.f;
+        bias[r] = p.delta_bias_ptr ? static_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
+        h_in[r] = 0.f;
+        p_in[r] = 1.f;
+    }
+    // running state at entry of the first tile
+    const size_t xrow0 = ((size_t)m.b * p.dim + m.d0) * p.n_chunks;  // in chunks
+    if constexpr (DYN) {
+        for (int n = lane; n < N; n += kWave) {
+            float h = 0.f, pr = 1.f;
+            if (MODE == 1 && m.tile0 > 0) {
+                h = xp[((xrow0 + m.tile0 - 1) * N + n) * 2 + 1];
+                pr = xp[((xrow0 + m.tile0 - 1) * N + n) * 2 + 0];
+            }
+            s_h[wave * kMaxDState + n] = h;
+            s_p[wave * kMaxDState + n] = pr;
+        }
+    } else if (MODE == 1 && m.tile0 > 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const size_t xi = ((xrow0 + (size_t)r * p.n_chunks) + m.tile0 - 1) * 2;
+            p_in[r] = xp[xi];
+            h_in[r] = xp[xi + 1];
+        }
+    }
+
+    for (int tile = m.tile0; tile < m.tile1; ++tile) {
+        const int t0 = tile * kTile + lane * kItems;
+        float uv[R][kItems], dl[R][kItems], outv[R][kItems];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            load4<T, VEC>(u_row[r], t0, L, uv[r]);
+            load4<T, VEC>(dl_row[r], t0, L, dl[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) {
+                float v = dl[r][i] + bias[r];
+                dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
+                outv[r][i] = Dv[r] * uv[r][i];
+            }
+
+        for (int n = 0; n < N; ++n) {
+            float Bv[kItems], Cv[kItems];
+            load4<T, VEC>(Bg + n * p.B_dstate_stride, t0, L, Bv);
+            if (MODE != 2) load4<T, VEC>(Cg + n * p.C_dstate_stride, t0, L, Cv);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float An = Ap[(m.d0 + r) * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
+                float a[kItems], bb[kItems];
+#pragma unroll
+                for (int i = 0; i < kItems; ++i) {
+                    const bool in = t0 + i < L;
+                    a[i] = in ? __builtin_amdgcn_exp2f(dl[r][i] * An) : 1.f;
+                    bb[i] = in ? dl[r][i] * uv[r][i] * Bv[i] : 0.f;
+                }
+                // lane aggregate, then wave scan of aggregates
+                Pair agg{a[0], bb[0]};
+#pragma unroll
+                for (int i = 1; i < kItems; ++i) agg = then(agg, Pair{a[i], bb[i]});
+                const Pair inc = wave_scan_fwd(agg, lane);
+                const float tot_a = readlane_f(inc.a, kWave - 1), tot_b = readlane_f(inc.b, kWave - 1);
+                if constexpr (MODE == 2) {
+                    if (lane == 0) {
+                        const size_t xi = (((xrow0 + (size_t)r * p.n_chunks) + tile) * N + n) * 2;
+                        xp[xi] = tot_a;
+                        xp[xi + 1] = tot_b;
+                    }
+                } else {
+                    float hin, pin;
+                    if constexpr (DYN) {
+                        hin = s_h[wave * kMaxDState + n];
+                        pin = s_p[wave * kMaxDState + n];
+                    } else {
+                        hin = h_in[r];
+                        pin = p_in[r];
+                    }
+                    float ea = __shfl_up(inc.a, 1), eb = __shfl_up(inc.b, 1);
+                    if (lane == 0) { ea = 1.f; eb = 0.f; }
+                    float h = fmaf(ea, hin, eb);
+#pragma unroll
+                    for (int i = 0; i < kItems; ++i) {
+                        h = fmaf(a[i], h, bb[i]);
+                        outv[r][i] = fmaf(h, Cv[i], outv[r][i]);
+                    }
+                    const float hout = fmaf(tot_a, hin, tot_b), pout = tot_a * pin;
+                    if constexpr (DYN) {
+                        if (lane == 0) {
+                            s_h[wave * kMaxDState + n] = hout;
+                            s_p[wave * kMaxDState + n] = pout;
+                        }
+                    } else {
+                        h_in[r] = hout;
+                        p_in[r] = pout;
+                    }
+                    if (MODE == 0 && lane == 0) {
+                        const size_t xi = (((xrow0 + (size_t)r * p.n_chunks) + tile) * N + n) * 2;
+                        xp[xi] = pout;
+                        xp[xi + 1] = hout;
+                    }
+                }
+            }
+        }
+        if constexpr (MODE != 2) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) store4<T, VEC>(out_row[r], t0, L, outv[r]);
+        }
+    }
+}
+
+// In-place inclusive scan of the per-tile aggregates of one (batch,row,state) sequence:
+// x[c] <- x[0] then ... then x[c].  One wave per sequence; lanes own contiguous runs.
+// REVERSE: exclusive scan from the right over (alpha, beta) pairs, used by the backward:
+// ws[c] <- g entering tile c from tile c+1 (beta slot), alpha slot unused afterwards.
+template <bool REVERSE>
+__global__ __launch_bounds__(256) void sscan_carry_kernel(float *__restrict__ x, const int nseq,
+                                                          const int n_chunks, const int N) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);  // (b*dim + d)*N + n
+    if (seq >= nseq) return;
+    const int row = seq / N, n = seq % N;
+    float *base = x + ((size_t)row * n_chunks * N + n) * 2;
+    const size_t cstride = (size_t)N * 2;
+    const int per = (n_chunks + kWave - 1) / kWave;
+    if constexpr (!REVERSE) {
+        const int c0 = lane * per, c1 = min(n_chunks, c0 + per);
+        Pair agg{1.f, 0.f};
+        for (int c = c0; c < c1; ++c) agg = then(agg, Pair{base[c * cstride], base[c * cstride + 1]});
+        const Pair inc = wave_scan_fwd(agg, lane);
+        Pair run{__shfl_up(inc.a, 1), __shfl_up(inc.b, 1)};
+        if (lane == 0) run = Pair{1.f, 0.f};
+        for (int c = c0; c < c1; ++c) {
+            run = then(run, Pair{base[c * cstride], base[c * cstride + 1]});
+            base[c * cstride] = run.a;
+            base[c * cstride + 1] = run.b;
+        }
+    } else {
+        // lanes own runs from the right end: lane 0 owns the LAST run
+        const int c1 = n_chunks - lane * per, c0 = max(0, c1 - per);
+        Pair agg{1.f, 0.f};  // composition "later tile first": g_out = b + a*g_in
+        for (int c = c1 - 1; c >= c0; --c) agg = then(agg, Pair{base[c * cstride], base[c * cstride + 1]});
+        // scan across lanes in lane order (lane 0 = rightmost run = applied first)
+        const Pair inc = wave_scan_fwd(c1 > 0 ? agg : Pair{1.f, 0.f}, lane);
+        Pair run{__shfl_up(inc.a, 1), __shfl_up(inc.b, 1)};
+        if (lane == 0) run = Pair{1.f, 0.f};
+        for (int c = c1 - 1; c >= c0; --c) {
+            const Pair mine{base[c * cstride], base[c * cstride + 1]};
+            base[c * cstride + 1] = run.b;  // g entering tile c from the right (g_in = 0 at the end)
+            run = then(run, mine);
+        }
+    }
+}
+
+// =====================================================================================
+// backward
+//   MODE 0: one workgroup walks [tile0,tile1) from the right, adjoint state in registers
+//   MODE 1: adjoint carry-in per tile read from ws (scanned by the reverse carry kernel)
+//   MODE 2: per-tile reverse aggregates (prod alpha, beta-chain) written to ws
+// Workgroup = W waves (blockDim.x/64) that own W consecutive row-blocks of ONE group and
+// walk the same tiles in lockstep; dB/dC are reduced over the W*R rows in LDS.
+// =====================================================================================
+struct BwdGeom {
+    int tiles_per_task, nseg, W, wg_per_group;  // wg_per_group = (rows_per_group / R) / W
+};
+
+template <typename T, int R, bool DYN, bool VEC, int MODE>
+__global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_params q, const BwdGeom geo) {
+    static_assert(!DYN || R == 1, "general-N path handles one row per wave");
+    const vmasr_sscan_params &p = q.f;
+    __shared__ float s_g[DYN ? 4 * kMaxDState : 1];   // adjoint carry per state (general N)
+    __shared__ float s_an[DYN ? 4 * kMaxDState : 1];  // a of the first step of the tile to the right
+    __shared__ __attribute__((aligned(16))) float s_red[2][4][kTile];  // dB / dC partials per wave
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int W = geo.W;
+    const int L = p.seqlen, N = DYN ? p.dstate : 1;
+    const int ntiles = (L + kTile - 1) / kTile;
+    const int rpg = p.dim / p.n_groups;
+    // block -> (wg-in-group fastest, group, segment, batch)
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int wgi = bid % geo.wg_per_group; bid /= geo.wg_per_group;
+    const int g = bid % p.n_groups; bid /= p.n_groups;
+    const int seg = bid % geo.nseg;
+    const int b = bid / geo.nseg;
+    const int d0 = g * rpg + (wgi * W + wave) * R;
+    const int tile0 = seg * geo.tiles_per_task, tile1 = min(ntiles, tile0 + geo.tiles_per_task);
+
+    const T *__restrict__ Bg = static_cast<const T *>(p.B_ptr) + b * p.B_batch_stride + g * p.B_group_stride;
+    const T *__restrict__ Cg = static_cast<const T *>(p.C_ptr) + b * p.C_batch_stride + g * p.C_group_stride;
+    const float *__restrict__ Ap = static_cast<const float *>(p.A_ptr);
+    const float *__restrict__ xp = static_cast<const float *>(p.x_ptr);
+    float *__restrict__ ws = static_cast<float *>(q.ws_ptr);
+    float *__restrict__ dBg = static_cast<float *>(q.dB_ptr) + ((size_t)b * p.n_groups + g) * N * L;
+    float *__restrict__ dCg = static_cast<float *>(q.dC_ptr) + ((size_t)b * p.n_groups + g) * N * L;
+
+    const T *u_row[R], *dl_row[R], *do_row[R];
+    T *du_row[R], *dd_row[R];
+    float Dv[R], bias[R], g_in[R], a_nx[R], accA[R], accD[R], accBias[R];
+    const size_t xrow0 = ((size_t)b * p.dim + d0) * p.n_chunks;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int d = d0 + r;
+        u_row[r] = static_cast<const T *>(p.u_ptr) + b * p.u_batch_stride + d * p.u_d_stride;
+        dl_row[r] = static_cast<const T *>(p.delta_ptr) + b * p.delta_batch_stride + d * p.delta_d_stride;
+        do_row[r] = static_cast<const T *>(q.dout_ptr) + b * q.dout_batch_stride + d * q.dout_d_stride;
+        du_row[r] = static_cast<T *>(q.du_ptr) + b * q.du_batch_stride + d * q.du_d_stride;
+        dd_row[r] = static_cast<T *>(q.ddelta_ptr) + b * q.ddelta_batch_stride + d * q.ddelta_d_stride;
+        Dv[r] = p.D_ptr ? static_cast<const float *>(p.D_ptr)[d] : 0.f;
+        bias[r] = p.delta_bias_ptr ? static_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
+        g_in[r] = 0.f; a_nx[r] = 1.f; accA[r] = 0.f; accD[r] = 0.f; accBias[r] = 0.f;
+    }
+    // state entering from the right of the last tile of this task
+    {
+        const int tn = tile1 * kTile;  // first step of the tile to the right
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float dnx = 0.f;
+            if (tn < L) {
+                const float v = to_f32(dl_row[r][tn]) + bias[r];
+                dnx = p.delta_softplus ? softplus_f(v) : v;
+            }
+            if constexpr (DYN) {
+                for (int n = lane; n < N; n += kWave) {
+                    const float An = Ap[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
+                    s_an[wave * kMaxDState + n] = tn < L ? __builtin_amdgcn_exp2f(dnx * An) : 1.f;
+                    s_g[wave * kMaxDState + n] =
+                        (MODE == 1 && tn < L) ? ws[(((xrow0 + tile1 - 1) * N) + n) * 2 + 1] : 0.f;
+                }
+            } else {
+                const float An = Ap[(d0 + r) * p.A_d_stride] * kLog2e;
+                a_nx[r] = tn < L ? __builtin_amdgcn_exp2f(dnx * An) : 1.f;
+                if (MODE == 1 && tn < L) g_in[r] = ws[((xrow0 + (size_t)r * p.n_chunks) + tile1 - 1) * 2 + 1];
+            }
+        }
+    }
+
+    for (int tile = tile1 - 1; tile >= tile0; --tile) {
+        const int t0 = tile * kTile + lane * kItems;
+        float uv[R][kItems], dl[R][kItems], dov[R][kItems], duv[R][kItems], ddv[R][kItems];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            load4<T, VEC>(dl_row[r], t0, L, dl[r]);
+            load4<T, VEC>(do_row[r], t0, L, dov[r]);
+            if (MODE != 2) load4<T, VEC>(u_row[r], t0, L, uv[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) {
+                const float v = dl[r][i] + bias[r];
+                dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
+                if (MODE != 2) {
+                    duv[r][i] = Dv[r] * dov[r][i];
+                    ddv[r][i] = 0.f;
+                    accD[r] = fmaf(dov[r][i], uv[r][i], accD[r]);
+                }
+            }
+
+        for (int n = 0; n < N; ++n) {
+            float Bv[kItems], Cv[kItems], dBv[kItems], dCv[kItems];
+            load4<T, VEC>(Cg + n * p.C_dstate_stride, t0, L, Cv);
+            if (MODE != 2) load4<T, VEC>(Bg + n * p.B_dstate_stride, t0, L, Bv);
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) { dBv[i] = 0.f; dCv[i] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float Araw = Ap[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride];
+                const float An = Araw * kLog2e;
+                float a[kItems], al[kItems], be[kItems];
+#pragma unroll
+                for (int i = 0; i < kItems; ++i) a[i] = (t0 + i < L) ? __builtin_amdgcn_exp2f(dl[r][i] * An) : 1.f;
+                float anx, gin;
+                if constexpr (DYN) { anx = s_an[wave * kMaxDState + n]; gin = s_g[wave * kMaxDState + n]; }
+                else { anx = a_nx[r]; gin = g_in[r]; }
+                // alpha_i = a_{t+1}: next item, next lane's first item, or the tile to the right
+                float a_up = __shfl_down(a[0], 1);
+                if (lane == kWave - 1) a_up = anx;
+#pragma unroll
+                for (int i = 0; i < kItems; ++i) {
+                    al[i] = (i + 1 < kItems) ? a[i + 1] : a_up;
+                    be[i] = dov[r][i] * Cv[i];
+                }
+                // lane aggregate from the right: g_first = qb + qa * g_after_lane
+                Pair ragg{al[kItems - 1], be[kItems - 1]};
+#pragma unroll
+                for (int i = kItems - 2; i >= 0; --i) ragg = then(ragg, Pair{al[i], be[i]});
+                const Pair rinc = wave_scan_rev(ragg, lane);
+                const float rt_a = readlane_f(rinc.a, 0), rt_b = readlane_f(rinc.b, 0);
+                const float a_first = readlane_f(a[0], 0);
+                if constexpr (MODE == 2) {
+                    if (lane == 0) {
+                        const size_t wi = (((xrow0 + (size_t)r * p.n_chunks) + tile) * N + n) * 2;
+                        ws[wi] = rt_a;
+                        ws[wi + 1] = rt_b;
+                    }
+                    continue;
+                }
+                // forward recurrence of this tile restarted from the saved state
+                float hin = 0.f;
+                if (tile > 0) hin = xp[(((xrow0 + (size_t)r * p.n_chunks) + tile - 1) * N + n) * 2 + 1];
+                float bb[kItems];
+#pragma unroll
+                for (int i = 0; i < kItems; ++i) bb[i] = (t0 + i < L) ? dl[r][i] * uv[r][i] * Bv[i] : 0.f;
+                Pair agg{a[0], bb[0]};
+#pragma unroll
+                for (int i = 1; i < kItems; ++i) agg = then(agg, Pair{a[i], bb[i]});
+                const Pair inc = wave_scan_fwd(agg, lane);
+                float ea = __shfl_up(inc.a, 1), eb = __shfl_up(inc.b, 1);
+                if (lane == 0) { ea = 1.f; eb = 0.f; }
+                float h = fmaf(ea, hin, eb);
+                float hv[kItems];
+#pragma unroll
+                for (int i = 0; i < kItems; ++i) { h = fmaf(a[i], h, bb[i]); hv[i] = h; }
+                // adjoint recurrence inside the lane
+                float ra = __shfl_down(rinc.a, 1), rb = __shfl_down(rinc.b, 1);
+                if (lane == kWave - 1) { ra = 1.f; rb = 0.f; }
+                float gcur = fmaf(ra, gin, rb);  // g of the first step of the next lane
+#pragma unroll
+                for (int i = kItems - 1; i >= 0; --i) {
+                    gcur = fmaf(al[i], gcur, be[i]);
+                    const float gB = gcur * Bv[i];
+                    const float ax = hv[i] - bb[i];  // a_t h_{t-1}
+                    duv[r][i] = fmaf(gB, dl[r][i], duv[r][i]);
+                    ddv[r][i] += fmaf(gB, uv[r][i], gcur * Araw * ax);
+                    accA[r] = fmaf(gcur * dl[r][i], ax, accA[r]);
+                    dBv[i] = fmaf(gcur * dl[r][i], uv[r][i], dBv[i]);
+                    dCv[i] = fmaf(dov[r][i], hv[i], dCv[i]);
+                }
+                const float gout = fmaf(rt_a, gin, rt_b);
+                if constexpr (DYN) {
+                    // one (row, state) per iteration: flush dA now
+                    const float s = wave_sum(accA[r]);
+                    accA[r] = 0.f;
+                    if (lane == 0) {
+                        atomicAdd(static_cast<float *>(q.dA_ptr) + (d0 + r) * q.dA_d_stride + n * q.dA_dstate_stride, s);
+                        s_g[wave * kMaxDState + n] = gout;
+                        s_an[wave * kMaxDState + n] = a_first;
+                    }
+                } else {
+                    g_in[r] = gout;
+                    a_nx[r] = a_first;
+                }
+            }
+            if constexpr (MODE != 2) {
+                // reduce dB/dC over the W waves (rows) of the workgroup, then leave as 256-B runs
+                const int tbase = tile * kTile;
+                if (W == 1) {
+#pragma unroll
+                    for (int i = 0; i < kItems; ++i) {
+                        const int t = t0 + i;
+                        if (t < L) {
+                            if (geo.wg_per_group == 1) { dBg[(size_t)n * L + t] = dBv[i]; dCg[(size_t)n * L + t] = dCv[i]; }
+                            else { atomicAdd(dBg + (size_t)n * L + t, dBv[i]); atomicAdd(dCg + (size_t)n * L + t, dCv[i]); }
+                        }
+                    }
+                } else {
+                    *reinterpret_cast<float4 *>(&s_red[0][wave][lane * kItems]) = make_float4(dBv[0], dBv[1], dBv[2], dBv[3]);
+                    *reinterpret_cast<float4 *>(&s_red[1][wave][lane * kItems]) = make_float4(dCv[0], dCv[1], dCv[2], dCv[3]);
+                    __syncthreads();
+                    for (int e = threadIdx.x; e < 2 * kTile; e += blockDim.x) {
+                        const int which = e / kTile, idx = e % kTile;
+                        float s = 0.f;
+                        for (int w = 0; w < W; ++w) s += s_red[which][w][idx];
+                        const int t = tbase + idx;
+                        if (t < L) {
+                            float *dst = (which ? dCg : dBg) + (size_t)n * L + t;
+                            if (geo.wg_per_group == 1) *dst = s; else atomicAdd(dst, s);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if constexpr (MODE != 2) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (p.delta_softplus) {
+                    float raw[kItems];
+                    load4<T, VEC>(dl_row[r], t0, L, raw);
+#pragma unroll
+                    for (int i = 0; i < kItems; ++i) {
+                        const float v = raw[i] + bias[r];
+                        if (v <= 20.f) ddv[r][i] = ddv[r][i] / (1.f + __expf(-v));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kItems; ++i) accBias[r] += (t0 + i < L) ? ddv[r][i] : 0.f;
+                store4<T, VEC>(du_row[r], t0, L, duv[r]);
+                store4<T, VEC>(dd_row[r], t0, L, ddv[r]);
+            }
+        }
+    }
+    if constexpr (MODE != 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int d = d0 + r;
+            const float sA = DYN ? 0.f : wave_sum(accA[r]);
+            const float sD = wave_sum(accD[r]), sB = wave_sum(accBias[r]);
+            if (lane == 0) {
+                if (!DYN) atomicAdd(static_cast<float *>(q.dA_ptr) + d * q.dA_d_stride, sA);
+                if (q.dD_ptr) atomicAdd(static_cast<float *>(q.dD_ptr) + d, sD);
+                if (q.ddelta_bias_ptr) atomicAdd(static_cast<float *>(q.ddelta_bias_ptr) + d, sB);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+int g_tune_rows = -1, g_tune_split = -1;
+
+int validate(const vmasr_sscan_params &p) {
+    VMASR_REQUIRE(p.batch > 0 && p.dim > 0 && p.seqlen > 0 && p.dstate > 0 && p.n_groups > 0, VMASR_EINVAL,
+                  "sscan: non-positive size");
+    VMASR_REQUIRE(p.dim % p.n_groups == 0, VMASR_EINVAL, "sscan: dims should be dividable by n_groups");
+    VMASR_REQUIRE(p.dstate <= kMaxDState, VMASR_EINVAL, "sscan: only supports state dimension <= 256");
+    VMASR_REQUIRE(p.dtype == VMASR_F32 || p.dtype == VMASR_F16 || p.dtype == VMASR_BF16, VMASR_EINVAL,
+                  "sscan: dtype must be fp32/fp16/bf16");
+    VMASR_REQUIRE(p.n_chunks == (p.seqlen + kTile - 1) / kTile, VMASR_EINVAL,
+                  "sscan: n_chunks must be ceil(seqlen/%d)", kTile);
+    VMASR_REQUIRE(p.u_ptr && p.delta_ptr && p.A_ptr && p.B_ptr && p.C_ptr, VMASR_EINVAL, "sscan: null tensor");
+    VMASR_REQUIRE(p.x_ptr || p.n_chunks == 1, VMASR_EINVAL, "sscan: x is required when n_chunks > 1");
+    return 0;
+}
+
+bool vec_ok(const vmasr_sscan_params &p, int esz, std::initializer_list<const void *> ptrs,
+            std::initializer_list<int64_t> strides) {
+    const size_t bytes = esz == 4 ? 16 : 8;
+    for (const void *q : ptrs)
+        if (q && !aligned_to(q, bytes)) return false;
+    for (int64_t s : strides)
+        if (s % 4 != 0) return false;
+    (void)p;
+    return true;
+}
+
+struct Plan {
+    int R, split, tiles_per_task, nseg;
+};
+
+Plan make_plan(const vmasr_sscan_params &p, bool dyn) {
+    Plan pl;
+    const int rpg = p.dim / p.n_groups;
+    const int ntiles = (p.seqlen + kTile - 1) / kTile;
+    int R = 1;
+    if (!dyn) {
+        // share B/C loads between rows while keeping enough waves in flight
+        const long waves1 = (long)p.batch * p.dim * (long)ntiles;  // upper bound on wave-tiles
+        if (rpg % 4 == 0 && waves1 / 4 >= 16384) R = 4;
+        else if (rpg % 2 == 0 && waves1 / 2 >= 8192) R = 2;
+        if (rpg == 2) R = 2;
+        if (g_tune_rows > 0 && rpg % g_tune_rows == 0 && (g_tune_rows == 1 || g_tune_rows == 2 || g_tune_rows == 4))
+            R = g_tune_rows;
+    }
+    pl.R = R;
+    const long rows_tasks = (long)p.batch * (p.dim / R);
+    int split = (ntiles > 1 && rows_tasks < 2048) ? 1 : 0;
+    if (g_tune_split >= 0) split = (ntiles > 1) ? g_tune_split : 0;
+    pl.split = split;
+    pl.tiles_per_task = split ? 1 : ntiles;
+    pl.nseg = split ? ntiles : 1;
+    return pl;
+}
+
+template <typename T, int R, bool DYN, bool VEC>
+int launch_fwd(const vmasr_sscan_params &p, const Plan &pl, hipStream_t st) {
+    const int ntiles = (p.seqlen + kTile - 1) / kTile;
+    const long ntasks = (long)p.batch * (p.dim / R) * pl.nseg;
+    const int nblocks = (int)((ntasks + 3) / 4);
+    if (!pl.split) {
+        hipLaunchKernelGGL((sscan_fwd_kernel<T, R, DYN, VEC, 0>), dim3(nblocks), dim3(256), 0, st, p,
+                           pl.tiles_per_task, pl.nseg);
+        return check_launch("sscan_fwd");
+    }
+    hipLaunchKernelGGL((sscan_fwd_kernel<T, R, DYN, VEC, 2>), dim3(nblocks), dim3(256), 0, st, p,
+                       pl.tiles_per_task, pl.nseg);
+    const int nseq = p.batch * p.dim * p.dstate;
+    hipLaunchKernelGGL((sscan_carry_kernel<false>), dim3((nseq + 3) / 4), dim3(256), 0, st,
+                       static_cast<float *>(p.x_ptr), nseq, ntiles, p.dstate);
+    hipLaunchKernelGGL((sscan_fwd_kernel<T, R, DYN, VEC, 1>), dim3(nblocks), dim3(256), 0, st, p,
+                       pl.tiles_per_task, pl.nseg);
+    return check_launch("sscan_fwd(split)");
+}
+
+template <typename T, int R, bool DYN, bool VEC>
+int launch_bwd(const vmasr_sscan_bwd_params &q, const Plan &pl, hipStream_t st) {
+    const vmasr_sscan_params &p = q.f;
+    const int ntiles = (p.seqlen + kTile - 1) / kTile;
+    const int rbg = (p.dim / p.n_groups) / R;  // row-blocks per group
+    int W = 4;
+    while (rbg % W) W >>= 1;
+    BwdGeom geo{pl.tiles_per_task, pl.nseg, W, rbg / W};
+    const long nblocks = (long)p.batch * pl.nseg * p.n_groups * geo.wg_per_group;
+    if (!pl.split) {
+        hipLaunchKernelGGL((sscan_bwd_kernel<T, R, DYN, VEC, 0>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
+        return check_launch("sscan_bwd");
+    }
+    hipLaunchKernelGGL((sscan_bwd_kernel<T, R, DYN, VEC, 2>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
+    const int nseq = p.batch * p.dim * p.dstate;
+    hipLaunchKernelGGL((sscan_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st,
+                       static_cast<float *>(q.ws_ptr), nseq, ntiles, p.dstate);
+    hipLaunchKernelGGL((sscan_bwd_kernel<T, R, DYN, VEC, 1>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
+    return check_launch("sscan_bwd(split)");
+}
+
+#define VMASR_DISPATCH_R(FN, T, DYN, VEC, ...)                         \
+    do {                                                               \
+        if (DYN || pl.R == 1) return FN<T, 1, DYN, VEC>(__VA_ARGS__);  \
+        if constexpr (!DYN) {                                          \
+            if (pl.R == 2) return FN<T, 2, false, VEC>(__VA_ARGS__);   \
+            return FN<T, 4, false, VEC>(__VA_ARGS__);                  \
+        }                                                              \
+    } while (0)
+
+template <typename T>
+int dispatch_fwd(const vmasr_sscan_params &p, const Plan &pl, bool dyn, bool vec, hipStream_t st) {
+    if (dyn) { if (vec) VMASR_DISPATCH_R(launch_fwd, T, true, true, p, pl, st); else VMASR_DISPATCH_R(launch_fwd, T, true, false, p, pl, st); }
+    else { if (vec) VMASR_DISPATCH_R(launch_fwd, T, false, true, p, pl, st); else VMASR_DISPATCH_R(launch_fwd, T, false, false, p, pl, st); }
+    return VMASR_EINVAL;
+}
+template <typename T>
+int dispatch_bwd(const vmasr_sscan_bwd_params &q, const Plan &pl, bool dyn, bool vec, hipStream_t st) {
+    if (dyn) { if (vec) VMASR_DISPATCH_R(launch_bwd, T, true, true, q, pl, st); else VMASR_DISPATCH_R(launch_bwd, T, true, false, q, pl, st); }
+    else { if (vec) VMASR_DISPATCH_R(launch_bwd, T, false, true, q, pl, st); else VMASR_DISPATCH_R(launch_bwd, T, false, false, q, pl, st); }
+    return VMASR_EINVAL;
+}
+
+}  // namespace
+}  // namespace vmasr
+
+using namespace vmasr;
+
+VMASR_EXPORT int vmasr_sscan_chunk(void) { return kTile; }
+
+VMASR_EXPORT void vmasr_sscan_tune(int rows, int split) {
+    g_tune_rows = rows;
+    g_tune_split = split;
+}
+
+VMASR_EXPORT int vmasr_sscan_fwd(const vmasr_sscan_params *pp, vmasr_stream_t stream) {
+    VMASR_REQUIRE(pp, VMASR_EINVAL, "sscan_fwd: null params");
+    const vmasr_sscan_params &p = *pp;
+    if (int e = validate(p)) return e;
+    VMASR_REQUIRE(p.out_ptr, VMASR_EINVAL, "sscan_fwd: null out");
+    const bool dyn = p.dstate != 1;
+    const int esz = p.dtype == VMASR_F32 ? 4 : 2;
+    const bool vec = vec_ok(p, esz, {p.u_ptr, p.delta_ptr, p.B_ptr, p.C_ptr, p.out_ptr},
+                            {p.u_batch_stride, p.u_d_stride, p.delta_batch_stride, p.delta_d_stride,
+                             p.out_batch_stride, p.out_d_stride, p.B_batch_stride, p.B_group_stride,
+                             p.B_dstate_stride, p.C_batch_stride, p.C_group_stride, p.C_dstate_stride});
+    const Plan pl = make_plan(p, dyn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (p.dtype) {
+        case VMASR_F32: return dispatch_fwd<float>(p, pl, dyn, vec, st);
+        case VMASR_F16: return dispatch_fwd<f16_t>(p, pl, dyn, vec, st);
+        default: return dispatch_fwd<bf16_t>(p, pl, dyn, vec, st);
+    }
+}
+
+VMASR_EXPORT size_t vmasr_sscan_bwd_workspace(const vmasr_sscan_bwd_params *q) {
+    if (!q) return 0;
+    const vmasr_sscan_params &p = q->f;
+    if (p.batch <= 0 || p.dim <= 0 || p.seqlen <= 0 || p.dstate <= 0) return 0;
+    const size_t ntiles = (p.seqlen + kTile - 1) / kTile;
+    return ntiles > 1 ? (size_t)p.batch * p.dim * ntiles * p.dstate * 2 * sizeof(float) : 0;
+}
+
+VMASR_EXPORT int vmasr_sscan_bwd(const vmasr_sscan_bwd_params *qq, vmasr_stream_t stream) {
+    VMASR_REQUIRE(qq, VMASR_EINVAL, "sscan_bwd: null params");
+    const vmasr_sscan_bwd_params &q = *qq;
+    const vmasr_sscan_params &p = q.f;
+    if (int e = validate(p)) return e;
+    VMASR_REQUIRE(q.dout_ptr && q.du_ptr && q.ddelta_ptr && q.dA_ptr && q.dB_ptr && q.dC_ptr, VMASR_EINVAL,
+                  "sscan_bwd: null tensor");
+    const bool dyn = p.dstate != 1;
+    const int esz = p.dtype == VMASR_F32 ? 4 : 2;
+    const bool vec = vec_ok(p, esz, {p.u_ptr, p.delta_ptr, p.B_ptr, p.C_ptr, q.dout_ptr, q.du_ptr, q.ddelta_ptr},
+                            {p.u_batch_stride, p.u_d_stride, p.delta_batch_stride, p.delta_d_stride,
+                             q.dout_batch_stride, q.dout_d_stride, q.du_batch_stride, q.du_d_stride,
+                             q.ddelta_batch_stride, q.ddelta_d_stride, p.B_batch_stride, p.B_group_stride,
+                             p.B_dstate_stride, p.C_batch_stride, p.C_group_stride, p.C_dstate_stride});
+    const Plan pl = make_plan(p, dyn);
+    if (pl.split)
+        VMASR_REQUIRE(q.ws_ptr && q.ws_bytes >= vmasr_sscan_bwd_workspace(qq), VMASR_ENOSPACE,
+                      "sscan_bwd: workspace too small (%zu < %zu)", q.ws_bytes, vmasr_sscan_bwd_workspace(qq));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (p.dtype) {
+        case VMASR_F32: return dispatch_bwd<float>(q, pl, dyn, vec, st);
+        case VMASR_F16: return dispatch_bwd<f16_t>(q, pl, dyn, vec, st);
+        default: return dispatch_bwd<bf16_t>(q, pl, dyn, vec, st);
+    }
+}
