@@ -132,6 +132,38 @@ int vmasr_istft_bwd(const float *mag, const float *phase, const float *g, float 
                     float *dphase, int32_t B, int32_t F, int32_t M, int32_t hop, int32_t win,
                     vmasr_stream_t stream);
 
+/* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
+ * When enabled, every kernel launch of this library is bracketed by two hipEvents
+ * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
+ * recorded events and returns, per kernel id, the launch count, the summed event time
+ * (ms) and the summed ALGORITHMIC bytes of those launches (SURVEY.md §8d definition).
+ * Used by bench.py for the `roofline` object; off by default (no events, no overhead). */
+enum {
+    VMASR_K_SSCAN_FWD = 0,      /* single-pass forward scan (mode 0)                    */
+    VMASR_K_SSCAN_FWD_AGG,      /* split: per-tile aggregates                           */
+    VMASR_K_SSCAN_FWD_CARRY,    /* split: scan of aggregates                            */
+    VMASR_K_SSCAN_FWD_APPLY,    /* split: per-tile apply                                */
+    VMASR_K_SSCAN_BWD,
+    VMASR_K_SSCAN_BWD_AGG,
+    VMASR_K_SSCAN_BWD_CARRY,
+    VMASR_K_SSCAN_BWD_APPLY,
+    VMASR_K_CROSS_SCAN,
+    VMASR_K_CROSS_MERGE,
+    VMASR_K_DWCONV_FWD,
+    VMASR_K_DWCONV_BWD_A,
+    VMASR_K_DWCONV_BWD_B,
+    VMASR_K_STFT,
+    VMASR_K_ISTFT_FRAMES,
+    VMASR_K_ISTFT_OLA,
+    VMASR_K_ISTFT_BWD,
+    VMASR_K_COUNT
+};
+void vmasr_prof_enable(int on);
+void vmasr_prof_reset(void);
+const char *vmasr_prof_name(int kernel_id);
+/* returns 0, or a hipError_t; blocks the host until the recorded events have completed */
+int vmasr_prof_collect(int kernel_id, int64_t *launches, double *total_ms, double *alg_bytes);
+
 #ifdef __cplusplus
 }
 #endif

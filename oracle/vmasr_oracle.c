@@ -367,6 +367,16 @@ VMASR_API void vmasr_oracle_stft(const float *wav, int Bn, int T, int n_fft, int
                     im[n] = 0.0;
                 }
                 fft_inplace(re, im, n_fft, 0);
+                /* a real-input FFT (what torch.stft runs) returns EXACTLY zero imaginary parts for
+                 * the DC and Nyquist bins; angle() is then 0 or +pi, never -pi.  The network
+                 * consumes the phase as is (it is not 2*pi-periodic), so the branch matters. */
+                im[0] = 0.0; im[n_fft / 2] = 0.0;
+                /* Frame 0 is centred on sample 0: reflect padding and the symmetric window make it
+                 * an even sequence about n_fft/2, so its spectrum is exactly real.  A floating
+                 * point FFT leaves +-1e-9 there and angle() flips between +pi and -pi with the
+                 * FFT library's rounding (the reference's own CPU and GPU runs disagree).  The
+                 * exact value is taken: imaginary part +0. */
+                if (m == 0) for (int f = 0; f < F; ++f) im[f] = 0.0;
                 for (int f = 0; f < F; ++f) {
                     const float r = (float)(re[f] * scale), i = (float)(im[f] * scale);
                     const size_t o = ((size_t)b * F + f) * M + m;

@@ -11,7 +11,7 @@ Fixture families:
   dwconv.npz      depthwise conv3x3 + bias + SiLU fwd+bwd  (model/vmamba.py:859-868,1543-1545)
   ss2d.npz        one SS2D + one VSSBlock, d_model 16, 16x16, fwd + all grads
   stft.npz        wav2spectro / spectro2wav                (utils/stft.py:22-115)
-  model_tiny.npz  DualStreamInteractiveMambaUNet dims=4, n_fft=128 fwd + grads + LSD
+  model_tiny.npz  DualStreamInteractiveMambaUNet dims=8, n_fft=128 fwd + grads + LSD
   metric.npz      LSD / SNR / LSD-HF / LSD-LF on fixed pairs (model/metric.py)
 """
 import os
@@ -224,7 +224,9 @@ def gen_stft(ns):
 def gen_model(ns):
     out = {}
     torch.manual_seed(123)
-    kw = dict(in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=4, ssm_d_state=1, ssm_ratio=2.0,
+    # dims >= 8: with dims=4 the second output PatchExpanding ends in LayerNorm(1), which outputs its
+    # bias and cuts every gradient upstream (a degenerate model)
+    kw = dict(in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=8, ssm_d_state=1, ssm_ratio=2.0,
               ssm_dt_rank="auto", ssm_act_layer="silu", ssm_conv=3, ssm_conv_bias=True,
               ssm_drop_rate=0.0, ssm_init="v0", forward_type="v5", mlp_ratio=4.0,
               mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False, drop_path_rate=0.1,
@@ -245,6 +247,11 @@ def gen_model(ns):
     wave = 0.1 * torch.randn(2, 1, T, generator=g)
     target = 0.1 * torch.randn(2, 1, T, generator=g)
     hf = torch.full((2,), int(65 * 16000 / 48000), dtype=torch.int64)
+    # the spectrogram the reference fed to the network: frame 0 of a reflect-padded STFT is exactly
+    # real, so its phase is +-pi by FFT rounding noise; parity tests of the network inject THIS
+    # spectrogram and test the STFT separately (angles compared on the circle)
+    mag_in, phase_in = m._mag_phase(wave)
+    out.update(mag_in=_np(mag_in), phase_in=_np(phase_in))
     y = m(wave, hf)
     gy = torch.randn(y.shape, generator=g)
     y.backward(gy)
@@ -257,8 +264,13 @@ def gen_model(ns):
     for k, p in m.named_parameters():
         if p.grad is None:
             n_unused += 1
-        else:
+        elif p.numel() <= 2048:
             out[f"grad::{k}"] = _np(p.grad)
+        else:  # large tensors: 256 evenly spaced elements + the L2 norm keep the fixture small
+            flat = p.grad.flatten()
+            idx = torch.linspace(0, flat.numel() - 1, 256).long()
+            out[f"gradsample::{k}"] = _np(flat[idx])
+            out[f"gradnorm::{k}"] = np.array(flat.double().norm().item())
     out["n_unused"] = np.array(n_unused)
     print(f"  tiny model: {sum(p.numel() for p in m.parameters())} params, "
           f"{n_unused} tensors without grad")

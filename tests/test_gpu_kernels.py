@@ -270,10 +270,16 @@ def test_dwconv_silu_golden_and_oracle():
 # STFT / iSTFT
 # ------------------------------------------------------------------------------------------
 def _phase_close(a, b, mag, tol, what):
+    """See tests/test_oracle.py::_phase_close: frame 0 on the circle, other frames on the same branch."""
     a = a.detach().cpu().numpy().astype(np.float64)
-    d = np.angle(np.exp(1j * (a - b.astype(np.float64))))
-    ok = mag > -12  # ignore bins with |S| < 2^-12: the angle of ~0 is noise in the reference too
-    assert np.abs(d[ok]).max() < tol, f"{what}: {np.abs(d[ok]).max():.3e}"
+    b = b.astype(np.float64)
+    ok = mag > -12
+    d = np.abs(a - b)
+    d[..., 0] = np.abs(np.angle(np.exp(1j * (a[..., 0] - b[..., 0]))))
+    wrapped = ok & (d > tol) & (np.abs(np.abs(a) - np.pi) < 1e-3) & (np.abs(np.abs(b) - np.pi) < 1e-3)
+    assert wrapped.sum() <= max(2, ok.sum() // 100000), (what, int(wrapped.sum()))
+    bad = ok & (d > tol) & ~wrapped
+    assert not bad.any(), (what, int(bad.sum()), float(d[bad].max()))
 
 
 def test_stft_istft_golden():

@@ -50,6 +50,11 @@ SYMBOLS = {
     "vmasr_sscan_bwd_workspace": (c_sz, [ctypes.POINTER(SScanBwdParams)]),
     "vmasr_sscan_bwd": (ctypes.c_int, [ctypes.POINTER(SScanBwdParams), c_vp]),
     "vmasr_sscan_tune": (None, [ctypes.c_int, ctypes.c_int]),
+    "vmasr_prof_enable": (None, [ctypes.c_int]),
+    "vmasr_prof_reset": (None, []),
+    "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "vmasr_prof_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "vmasr_cross_scan": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_cross_merge": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_dwconv_silu_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -72,6 +77,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C vm_asr_amd/csrc` "
                 "(or __graft_entry__.build()). vm_asr_amd has no CPU fallback.")
+        # torch bundles its own libamdhip64 (soname libamdhip64.so.7); importing it first makes the
+        # loader bind this library to that same runtime instead of a second copy from /opt/rocm
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so is stale
@@ -99,3 +107,27 @@ def torch_dtype_code(dt):
 def current_stream(device):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+K_COUNT = 17
+
+
+def prof_enable(on=True):
+    lib().vmasr_prof_enable(int(bool(on)))
+
+
+def prof_reset():
+    lib().vmasr_prof_reset()
+
+
+def prof_collect():
+    """-> {kernel name: dict(launches, ms, alg_bytes)} for kernels launched since the last reset
+    (waits for their events)."""
+    l = lib()
+    out = {}
+    for k in range(K_COUNT):
+        n, ms, by = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        check(l.vmasr_prof_collect(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), "prof_collect")
+        if n.value:
+            out[l.vmasr_prof_name(k).decode()] = dict(launches=n.value, ms=ms.value, alg_bytes=by.value)
+    return out

@@ -1,17 +1,99 @@
-// api.hip — ABI version + thread-local error message for libvmasr_hip.
+// api.hip — ABI version, thread-local error message and the optional HIP-event profiler.
 #include "common.h"
+
+#include <mutex>
+#include <vector>
 
 namespace vmasr {
 namespace {
 thread_local char g_err[512] = "";
+
+struct Rec {
+    int kid;
+    hipEvent_t e0, e1;
+    double bytes;
+};
+std::mutex g_mu;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+thread_local Rec g_open{-1, nullptr, nullptr, 0.0};
+
+hipEvent_t take_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
 }
+
+const char *kNames[VMASR_K_COUNT] = {
+    "sscan_fwd", "sscan_fwd_agg", "sscan_fwd_carry", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_agg",
+    "sscan_bwd_carry", "sscan_bwd_apply", "cross_scan", "cross_merge", "dwconv_silu_fwd", "dwconv_silu_bwd_a",
+    "dwconv_silu_bwd_b", "stft", "istft_frames", "istft_ola", "istft_bwd"};
+}  // namespace
+
+bool g_prof_on = false;
+
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+void prof_begin(int kid, hipStream_t st, double bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_open = Rec{kid, take_event(), take_event(), bytes};
+    (void)hipEventRecord(g_open.e0, st);
+}
+
+void prof_end(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_open.kid < 0) return;
+    (void)hipEventRecord(g_open.e1, st);
+    g_recs.push_back(g_open);
+    g_open.kid = -1;
+}
 }  // namespace vmasr
 
+using namespace vmasr;
+
 VMASR_EXPORT int vmasr_abi_version(void) { return VMASR_ABI_VERSION; }
-VMASR_EXPORT const char *vmasr_last_error(void) { return vmasr::g_err; }
+VMASR_EXPORT const char *vmasr_last_error(void) { return g_err; }
+
+VMASR_EXPORT void vmasr_prof_enable(int on) { g_prof_on = on != 0; }
+
+VMASR_EXPORT void vmasr_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Rec &r : g_recs) {
+        g_pool.push_back(r.e0);
+        g_pool.push_back(r.e1);
+    }
+    g_recs.clear();
+}
+
+VMASR_EXPORT const char *vmasr_prof_name(int kid) { return (kid >= 0 && kid < VMASR_K_COUNT) ? kNames[kid] : ""; }
+
+VMASR_EXPORT int vmasr_prof_collect(int kid, int64_t *launches, double *total_ms, double *alg_bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int64_t n = 0;
+    double ms = 0.0, by = 0.0;
+    for (Rec &r : g_recs) {
+        if (r.kid != kid) continue;
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e != hipSuccess) return (int)e;
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, r.e0, r.e1);
+        if (e != hipSuccess) return (int)e;
+        ++n;
+        ms += t;
+        by += r.bytes;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (alg_bytes) *alg_bytes = by;
+    return 0;
+}

@@ -22,6 +22,19 @@ void set_error(const char *fmt, ...);
         }                                   \
     } while (0)
 
+// ---- optional per-launch HIP-event timing (api.hip) ----------------------------------
+extern bool g_prof_on;
+void prof_begin(int kernel_id, hipStream_t st, double alg_bytes);
+void prof_end(hipStream_t st);
+
+// launch `kernel` and, when profiling is on, bracket it with events on its own stream
+#define VMASR_LAUNCH(kid, bytes, kernel, grid, block, smem, st, ...)            \
+    do {                                                                        \
+        if (::vmasr::g_prof_on) ::vmasr::prof_begin((kid), (st), (double)(bytes)); \
+        hipLaunchKernelGGL(kernel, grid, block, smem, st, __VA_ARGS__);         \
+        if (::vmasr::g_prof_on) ::vmasr::prof_end((st));                        \
+    } while (0)
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

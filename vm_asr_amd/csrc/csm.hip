@@ -107,10 +107,11 @@ VMASR_EXPORT int vmasr_cross_scan(const void *x, void *xs, int32_t B, int32_t C,
     if (int e = check_shape(x, xs, B, C, H, W, dtype, "cross_scan")) return e;
     const dim3 grid(((W + kT - 1) / kT) * ((H + kT - 1) / kT), C, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const double bytes = 5.0 * B * C * H * W * (dtype == VMASR_F32 ? 4 : 2);  // 1 read + 4 writes
     if (dtype == VMASR_F32)
-        hipLaunchKernelGGL(cross_scan_kernel<float>, grid, dim3(256), 0, st, (const float *)x, (float *)xs, C, H, W);
+        VMASR_LAUNCH(VMASR_K_CROSS_SCAN, bytes, cross_scan_kernel<float>, grid, dim3(256), 0, st, (const float *)x, (float *)xs, C, H, W);
     else  // 16-bit payloads are moved as raw bits
-        hipLaunchKernelGGL(cross_scan_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t *)x, (uint16_t *)xs, C, H, W);
+        VMASR_LAUNCH(VMASR_K_CROSS_SCAN, bytes, cross_scan_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t *)x, (uint16_t *)xs, C, H, W);
     return check_launch("cross_scan");
 }
 
@@ -119,15 +120,16 @@ VMASR_EXPORT int vmasr_cross_merge(const void *ys, void *y, int32_t B, int32_t C
     if (int e = check_shape(ys, y, B, C, H, W, dtype, "cross_merge")) return e;
     const dim3 grid(((W + kT - 1) / kT) * ((H + kT - 1) / kT), C, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const double bytes = 5.0 * B * C * H * W * (dtype == VMASR_F32 ? 4 : 2);  // 4 reads + 1 write
     switch (dtype) {
         case VMASR_F32:
-            hipLaunchKernelGGL(cross_merge_kernel<float>, grid, dim3(256), 0, st, (const float *)ys, (float *)y, C, H, W);
+            VMASR_LAUNCH(VMASR_K_CROSS_MERGE, bytes, cross_merge_kernel<float>, grid, dim3(256), 0, st, (const float *)ys, (float *)y, C, H, W);
             break;
         case VMASR_F16:
-            hipLaunchKernelGGL(cross_merge_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t *)ys, (f16_t *)y, C, H, W);
+            VMASR_LAUNCH(VMASR_K_CROSS_MERGE, bytes, cross_merge_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t *)ys, (f16_t *)y, C, H, W);
             break;
         default:
-            hipLaunchKernelGGL(cross_merge_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)ys, (bf16_t *)y, C, H, W);
+            VMASR_LAUNCH(VMASR_K_CROSS_MERGE, bytes, cross_merge_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)ys, (bf16_t *)y, C, H, W);
     }
     return check_launch("cross_merge");
 }

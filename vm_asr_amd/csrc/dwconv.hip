@@ -142,10 +142,11 @@ VMASR_EXPORT int vmasr_dwconv_silu_fwd(const void *x, const float *w, const floa
     VMASR_REQUIRE(x && w && y, VMASR_EINVAL, "dwconv_silu_fwd: null tensor");
     const dim3 grid((H * W + kChunk - 1) / kChunk, C, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const double bytes = 2.0 * B * C * H * W * (dtype == VMASR_F32 ? 4 : 2);  // read x, write y
     switch (dtype) {
-        case VMASR_F32: hipLaunchKernelGGL(dwconv_silu_fwd_kernel<float>, grid, dim3(256), 0, st, (const float *)x, w, bias, (float *)y, C, H, W); break;
-        case VMASR_F16: hipLaunchKernelGGL(dwconv_silu_fwd_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t *)x, w, bias, (f16_t *)y, C, H, W); break;
-        default: hipLaunchKernelGGL(dwconv_silu_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, w, bias, (bf16_t *)y, C, H, W);
+        case VMASR_F32: VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<float>, grid, dim3(256), 0, st, (const float *)x, w, bias, (float *)y, C, H, W); break;
+        case VMASR_F16: VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t *)x, w, bias, (f16_t *)y, C, H, W); break;
+        default: VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, w, bias, (bf16_t *)y, C, H, W);
     }
     return check_launch("dwconv_silu_fwd");
 }
@@ -157,18 +158,20 @@ VMASR_EXPORT int vmasr_dwconv_silu_bwd(const void *x, const float *w, const floa
     VMASR_REQUIRE(x && w && gy && dx && dw && ws, VMASR_EINVAL, "dwconv_silu_bwd: null tensor");
     const dim3 grid((H * W + kChunk - 1) / kChunk, C, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const double n = (double)B * C * H * W, es = dtype == VMASR_F32 ? 4 : 2;
+    const double bytes_a = n * (2 * es + 4), bytes_b = n * (4 + es);  // a: read x, gy, write gp;  b: read gp, write dx
     switch (dtype) {
         case VMASR_F32:
-            hipLaunchKernelGGL(dwconv_silu_bwd_a_kernel<float>, grid, dim3(256), 0, st, (const float *)x, w, bias, (const float *)gy, ws, dw, db, C, H, W);
-            hipLaunchKernelGGL(dwconv_silu_bwd_b_kernel<float>, grid, dim3(256), 0, st, ws, w, (float *)dx, C, H, W);
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<float>, grid, dim3(256), 0, st, (const float *)x, w, bias, (const float *)gy, ws, dw, db, C, H, W);
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<float>, grid, dim3(256), 0, st, ws, w, (float *)dx, C, H, W);
             break;
         case VMASR_F16:
-            hipLaunchKernelGGL(dwconv_silu_bwd_a_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t *)x, w, bias, (const f16_t *)gy, ws, dw, db, C, H, W);
-            hipLaunchKernelGGL(dwconv_silu_bwd_b_kernel<f16_t>, grid, dim3(256), 0, st, ws, w, (f16_t *)dx, C, H, W);
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t *)x, w, bias, (const f16_t *)gy, ws, dw, db, C, H, W);
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<f16_t>, grid, dim3(256), 0, st, ws, w, (f16_t *)dx, C, H, W);
             break;
         default:
-            hipLaunchKernelGGL(dwconv_silu_bwd_a_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, w, bias, (const bf16_t *)gy, ws, dw, db, C, H, W);
-            hipLaunchKernelGGL(dwconv_silu_bwd_b_kernel<bf16_t>, grid, dim3(256), 0, st, ws, w, (bf16_t *)dx, C, H, W);
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, w, bias, (const bf16_t *)gy, ws, dw, db, C, H, W);
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<bf16_t>, grid, dim3(256), 0, st, ws, w, (bf16_t *)dx, C, H, W);
     }
     return check_launch("dwconv_silu_bwd");
 }

@@ -599,18 +599,22 @@ int launch_fwd(const vmasr_sscan_params &p, const Plan &pl, hipStream_t st) {
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
     const long ntasks = (long)p.batch * (p.dim / R) * pl.nseg;
     const int nblocks = (int)((ntasks + 3) / 4);
+    // algorithmic bytes: read u, delta, B, C; write out
+    const double es = sizeof(T), KD = p.dim, KN = (double)p.n_groups * p.dstate, BL = (double)p.batch * p.seqlen;
+    const double full = (3 * KD + 2 * KN) * BL * es, agg = (2 * KD + KN) * BL * es;
+    const double xb = (double)p.batch * p.dim * ntiles * p.dstate * 2 * 4 * 2;
     if (!pl.split) {
-        hipLaunchKernelGGL((sscan_fwd_kernel<T, R, DYN, VEC, 0>), dim3(nblocks), dim3(256), 0, st, p,
-                           pl.tiles_per_task, pl.nseg);
+        VMASR_LAUNCH(VMASR_K_SSCAN_FWD, full, (sscan_fwd_kernel<T, R, DYN, VEC, 0>), dim3(nblocks), dim3(256), 0, st, p,
+                     pl.tiles_per_task, pl.nseg);
         return check_launch("sscan_fwd");
     }
-    hipLaunchKernelGGL((sscan_fwd_kernel<T, R, DYN, VEC, 2>), dim3(nblocks), dim3(256), 0, st, p,
-                       pl.tiles_per_task, pl.nseg);
+    VMASR_LAUNCH(VMASR_K_SSCAN_FWD_AGG, agg, (sscan_fwd_kernel<T, R, DYN, VEC, 2>), dim3(nblocks), dim3(256), 0, st, p,
+                 pl.tiles_per_task, pl.nseg);
     const int nseq = p.batch * p.dim * p.dstate;
-    hipLaunchKernelGGL((sscan_carry_kernel<false>), dim3((nseq + 3) / 4), dim3(256), 0, st,
-                       static_cast<float *>(p.x_ptr), nseq, ntiles, p.dstate);
-    hipLaunchKernelGGL((sscan_fwd_kernel<T, R, DYN, VEC, 1>), dim3(nblocks), dim3(256), 0, st, p,
-                       pl.tiles_per_task, pl.nseg);
+    VMASR_LAUNCH(VMASR_K_SSCAN_FWD_CARRY, xb, (sscan_carry_kernel<false>), dim3((nseq + 3) / 4), dim3(256), 0, st,
+                 static_cast<float *>(p.x_ptr), nseq, ntiles, p.dstate);
+    VMASR_LAUNCH(VMASR_K_SSCAN_FWD_APPLY, full, (sscan_fwd_kernel<T, R, DYN, VEC, 1>), dim3(nblocks), dim3(256), 0, st, p,
+                 pl.tiles_per_task, pl.nseg);
     return check_launch("sscan_fwd(split)");
 }
 
@@ -623,15 +627,19 @@ int launch_bwd(const vmasr_sscan_bwd_params &q, const Plan &pl, hipStream_t st) 
     while (rbg % W) W >>= 1;
     BwdGeom geo{pl.tiles_per_task, pl.nseg, W, rbg / W};
     const long nblocks = (long)p.batch * pl.nseg * p.n_groups * geo.wg_per_group;
+    // algorithmic bytes: read u, delta, dout, B, C; write du, ddelta, dB, dC (dB/dC fp32)
+    const double es = sizeof(T), KD = p.dim, KN = (double)p.n_groups * p.dstate, BL = (double)p.batch * p.seqlen;
+    const double full = (5 * KD * es + 2 * KN * es + 2 * KN * 4) * BL, agg = (2 * KD + KN) * BL * es;
+    const double xb = (double)p.batch * p.dim * ntiles * p.dstate * 2 * 4 * 2;
     if (!pl.split) {
-        hipLaunchKernelGGL((sscan_bwd_kernel<T, R, DYN, VEC, 0>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
+        VMASR_LAUNCH(VMASR_K_SSCAN_BWD, full, (sscan_bwd_kernel<T, R, DYN, VEC, 0>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
         return check_launch("sscan_bwd");
     }
-    hipLaunchKernelGGL((sscan_bwd_kernel<T, R, DYN, VEC, 2>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
+    VMASR_LAUNCH(VMASR_K_SSCAN_BWD_AGG, agg, (sscan_bwd_kernel<T, R, DYN, VEC, 2>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
     const int nseq = p.batch * p.dim * p.dstate;
-    hipLaunchKernelGGL((sscan_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st,
-                       static_cast<float *>(q.ws_ptr), nseq, ntiles, p.dstate);
-    hipLaunchKernelGGL((sscan_bwd_kernel<T, R, DYN, VEC, 1>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
+    VMASR_LAUNCH(VMASR_K_SSCAN_BWD_CARRY, xb, (sscan_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st,
+                 static_cast<float *>(q.ws_ptr), nseq, ntiles, p.dstate);
+    VMASR_LAUNCH(VMASR_K_SSCAN_BWD_APPLY, full, (sscan_bwd_kernel<T, R, DYN, VEC, 1>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
     return check_launch("sscan_bwd(split)");
 }
 

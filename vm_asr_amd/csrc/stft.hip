@@ -145,7 +145,11 @@ __global__ __launch_bounds__(256) void stft_like_kernel(const float *__restrict_
                 const int m = which ? mb : ma;
                 float r0, r1;
                 if constexpr (KIND == 0) {
-                    const float re = normalized ? X.x * nrm : X.x, im = normalized ? X.y * nrm : X.y;
+                    const float re = normalized ? X.x * nrm : X.x;
+                    // frame 0 is an even sequence (reflect padding + symmetric window): its spectrum is
+                    // exactly real; take +0 instead of the FFT's rounding noise so that angle() does not
+                    // flip between +pi and -pi (see oracle/vmasr_oracle.c)
+                    const float im = (m == 0) ? 0.f : (normalized ? X.y * nrm : X.y);
                     if (logmag) {
                         r0 = log2f(sqrtf(re * re + im * im) + 1e-8f);
                         r1 = atan2f(im, re);
@@ -286,7 +290,8 @@ VMASR_EXPORT int vmasr_stft(const float *wav, float *out0, float *out1, int32_t 
     const int M = 1 + T / hop;
     const size_t sm = smem_bytes(n_fft, true);
     if (int e = allow_smem(stft_like_kernel<0>, sm, "stft")) return e;
-    hipLaunchKernelGGL(stft_like_kernel<0>, dim3((M + kFR - 1) / kFR, B), dim3(256), sm,
+    const double bytes = (double)B * (T * 4.0 + 2.0 * (n_fft / 2 + 1) * M * 4.0);  // read wave, write 2 planes
+    VMASR_LAUNCH(VMASR_K_STFT, bytes, stft_like_kernel<0>, dim3((M + kFR - 1) / kFR, B), dim3(256), sm,
                        static_cast<hipStream_t>(stream), wav, nullptr, nullptr, out0, out1, T, n_fft, hop, win, M,
                        normalized, logmag);
     return check_launch("stft");
@@ -308,9 +313,10 @@ VMASR_EXPORT int vmasr_istft(const float *mag, const float *phase, float *wav, i
     const int T = hop * (M - 1);
     const size_t sm = smem_bytes(n, false);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(istft_frames_kernel, dim3((M + kFR - 1) / kFR, B), dim3(256), sm, st, mag, phase,
+    const double fbytes = (double)B * M * n * 4.0;
+    VMASR_LAUNCH(VMASR_K_ISTFT_FRAMES, 2.0 * B * F * M * 4.0 + fbytes, istft_frames_kernel, dim3((M + kFR - 1) / kFR, B), dim3(256), sm, st, mag, phase,
                        static_cast<float *>(ws), n, win, M);
-    hipLaunchKernelGGL(istft_ola_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, static_cast<const float *>(ws),
+    VMASR_LAUNCH(VMASR_K_ISTFT_OLA, fbytes + (double)B * T * 4.0, istft_ola_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, static_cast<const float *>(ws),
                        wav, n, hop, win, M, T);
     return check_launch("istft");
 }
@@ -324,7 +330,8 @@ VMASR_EXPORT int vmasr_istft_bwd(const float *mag, const float *phase, const flo
     const int T = hop * (M - 1);
     const size_t sm = smem_bytes(n, true);
     if (int e = allow_smem(stft_like_kernel<2>, sm, "istft_bwd")) return e;
-    hipLaunchKernelGGL(stft_like_kernel<2>, dim3((M + kFR - 1) / kFR, B), dim3(256), sm,
+    const double bytes = (double)B * (T * 4.0 + 4.0 * F * M * 4.0);  // read g, mag, phase; write dmag, dphase
+    VMASR_LAUNCH(VMASR_K_ISTFT_BWD, bytes, stft_like_kernel<2>, dim3((M + kFR - 1) / kFR, B), dim3(256), sm,
                        static_cast<hipStream_t>(stream), g, mag, phase, dmag, dphase, T, n, hop, win, M, 1, 0);
     return check_launch("istft_bwd");
 }

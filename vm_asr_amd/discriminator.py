@@ -1,0 +1,100 @@
+"""Multi-period discriminator (PyTorch / MIOpen convs): the adversary of the MPD configs.
+
+Re-statement of model/discriminator.py:21-147 (HiFi-GAN style, periods 2,3,5,7,11, hidden 32
+-> 41.09 M parameters).  The reference's inverted ternary (`weight_norm if use_spectral_norm
+else spectral_norm`, :37) means the default `use_spectral_norm=False` yields SPECTRAL norm;
+that is reproduced so state_dicts (parametrizations.weight.original + power-iteration
+buffers) stay compatible.  MSD (:174-337) is not enabled by any yaml and is not built.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.parametrizations import spectral_norm, weight_norm
+
+__all__ = ["PeriodDiscriminator", "MultiPeriodDiscriminator"]
+
+
+def _conv_kx1_cl(x, weight, bias, stride, pad):
+    """Conv2d with a (k,1) kernel, stride (s,1), zero padding (pad,0) on CHANNEL-LAST input
+    x (B, P, T, Cin) -> (B, P, T_out, Cout), evaluated as unfold + GEMM.  MIOpen runs these
+    (5,1)/(3,1) bf16 convolutions with its `naive_conv_*` fallback (40+ ms per call on MI355X);
+    as GEMMs (K = Cin*k up to 5120) they run on the MFMA pipes through hipBLASLt."""
+    k = weight.shape[2]
+    if pad:
+        x = F.pad(x, (0, 0, pad, pad))
+    cols = x.unfold(2, k, stride)                      # (B, P, T_out, Cin, k) view
+    Bn, P, To, Cin, _ = cols.shape
+    w = weight[:, :, :, 0].reshape(weight.shape[0], Cin * k).to(x.dtype)   # (Cout, Cin*k), (c,k) order
+    y = F.linear(cols.reshape(Bn, P, To, Cin * k), w, None if bias is None else bias.to(x.dtype))
+    return y
+
+
+class PeriodDiscriminator(nn.Module):
+    def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False, hidden=32):
+        super().__init__()
+        self.period = period
+        norm = weight_norm if use_spectral_norm else spectral_norm  # sic
+        pad = (kernel_size - 1) // 2
+        chans = [1, hidden, hidden * 4, hidden * 16, hidden * 32]
+        layers = [norm(nn.Conv2d(chans[i], chans[i + 1], (kernel_size, 1), (stride, 1), padding=(pad, 0)))
+                  for i in range(4)]
+        layers.append(norm(nn.Conv2d(hidden * 32, hidden * 32, (kernel_size, 1), 1, padding=(2, 0))))
+        self.layers = nn.ModuleList(layers)
+        self.conv_post = norm(nn.Conv2d(hidden * 32, 1, (3, 1), 1, padding=(1, 0)))
+
+    def forward(self, x):
+        """Feature maps are returned channel-last (B, period, T', C): the losses that consume them
+        (L1 feature matching, LSGAN means) are layout-agnostic; the flattened score matches the
+        reference's element set."""
+        fmap = []
+        b, c, t = x.shape
+        if t % self.period != 0:
+            n_pad = self.period - (t % self.period)
+            x = F.pad(x, (0, n_pad), "reflect")
+            t = t + n_pad
+        if not x.is_cuda:  # host/CPU runs (tests, cpu_baseline) keep the plain convolutions
+            x = x.view(b, c, t // self.period, self.period)
+            for layer in self.layers:
+                x = F.gelu(layer(x))
+                fmap.append(x)
+            x = self.conv_post(x)
+            fmap.append(x)
+            return torch.flatten(x, 1, -1), fmap
+        x = x.view(b, c, t // self.period, self.period).permute(0, 3, 2, 1)  # (B, P, T', C=1)
+        for layer in self.layers:
+            x = F.gelu(_conv_kx1_cl(x, layer.weight, layer.bias, layer.stride[0], layer.padding[0]))
+            fmap.append(x)
+        x = _conv_kx1_cl(x, self.conv_post.weight, self.conv_post.bias, 1, self.conv_post.padding[0])
+        fmap.append(x)
+        return torch.flatten(x, 1, -1), fmap
+
+
+class MultiPeriodDiscriminator(nn.Module):
+    def __init__(self, hidden=32, periods=(2, 3, 5, 7, 11)):
+        super().__init__()
+        self.discriminators = nn.ModuleList([PeriodDiscriminator(p, hidden=hidden) for p in periods])
+
+    def forward_single(self, x):
+        """scores and feature maps of ONE signal batch (used for the generator pass, where the
+        real-signal features of the discriminator pass are reused instead of recomputed)."""
+        ys, fmaps = [], []
+        for disc in self.discriminators:
+            y, f = disc(x)
+            ys.append(y)
+            fmaps.append(f)
+        return ys, fmaps
+
+    def forward(self, y, y_hat):
+        y_real, y_gen, fmap_real, fmap_gen = [], [], [], []
+        for disc in self.discriminators:
+            r, fr = disc(y)
+            y_real.append(r)
+            fmap_real.append(fr)
+            if y_hat is not None:
+                g, fg = disc(y_hat)
+                y_gen.append(g)
+                fmap_gen.append(fg)
+            else:
+                y_gen.append(0)
+                fmap_gen.append(0)
+        return y_real, y_gen, fmap_real, fmap_gen

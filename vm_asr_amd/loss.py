@@ -1,0 +1,104 @@
+"""Training losses (PyTorch; consumers of the generator output, outside the HIP hot path).
+
+Re-statement of model/loss.py: multi-resolution STFT loss (:17-184; resolutions fft
+1024/2048/512, hop 120/240/50, win 600/1200/240 :142-144) and the HiFi-GAN style
+LSGAN / WGAN(-GP) / feature-matching losses (:188-260).  These need d/dx of an STFT, so
+they use torch.stft (hipFFT) rather than the forward-only HIP front-end.
+"""
+import torch
+import torch.nn.functional as F
+
+__all__ = ["mae_loss", "mse_loss", "stft_magnitude", "STFTLoss", "MultiResolutionSTFTLoss", "HiFiGANLoss"]
+
+
+def mae_loss(output, target):
+    return F.l1_loss(output, target)
+
+
+def mse_loss(output, target):
+    return F.mse_loss(output, target)
+
+
+def stft_magnitude(x, fft_size, hop_size, win_length, window, emphasize_high_freq=False):
+    """(B,T) -> (B, frames, fft_size//2+1); sqrt(clamp(re^2+im^2, 1e-7))."""
+    s = torch.stft(x.float(), fft_size, hop_size, win_length, window=window, return_complex=True)
+    mag = torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=1e-7)).transpose(2, 1)
+    if emphasize_high_freq:
+        # sic: the reference scales along dim 1 of the (B, frames, bins) tensor (model/loss.py:40-43)
+        mag = mag * torch.linspace(1.0, 2.0, mag.size(1), device=x.device).view(1, -1, 1)
+    return mag
+
+
+class STFTLoss(torch.nn.Module):
+    def __init__(self, fft_size=1024, shift_size=120, win_length=600, window="hann_window", emphasize_high_freq=False):
+        super().__init__()
+        self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
+        self.emphasize_high_freq = emphasize_high_freq
+        self.register_buffer("window", getattr(torch, window)(win_length))
+
+    def forward(self, x, y):
+        w = self.window.to(x.device)
+        x_mag = stft_magnitude(x, self.fft_size, self.shift_size, self.win_length, w, self.emphasize_high_freq)
+        y_mag = stft_magnitude(y, self.fft_size, self.shift_size, self.win_length, w, self.emphasize_high_freq)
+        sc = torch.norm(y_mag - x_mag, p="fro") / torch.norm(y_mag, p="fro")
+        mag = F.l1_loss(torch.log(y_mag), torch.log(x_mag))
+        return sc, mag
+
+
+class MultiResolutionSTFTLoss(torch.nn.Module):
+    def __init__(self, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240),
+                 window="hann_window", factor_sc=0.1, factor_mag=0.1, emphasize_high_freq=False):
+        super().__init__()
+        assert len(fft_sizes) == len(hop_sizes) == len(win_lengths)
+        self.stft_losses = torch.nn.ModuleList(
+            [STFTLoss(fs, ss, wl, window, emphasize_high_freq) for fs, ss, wl in zip(fft_sizes, hop_sizes, win_lengths)])
+        self.factor_sc, self.factor_mag = factor_sc, factor_mag
+
+    def forward(self, x, y):
+        sc_loss, mag_loss = 0.0, 0.0
+        for f in self.stft_losses:
+            sc, mag = f(x, y)
+            sc_loss = sc_loss + sc
+            mag_loss = mag_loss + mag
+        n = len(self.stft_losses)
+        return self.factor_sc * sc_loss / n, self.factor_mag * mag_loss / n
+
+
+class HiFiGANLoss:
+    def __init__(self, gan_loss_type, gp_weight=10):
+        self.gan_loss_type, self.gp_weight = gan_loss_type, gp_weight
+
+    def discriminator_loss(self, real_data, generated_data):
+        loss = 0
+        for dr, dg in zip(real_data, generated_data):
+            if self.gan_loss_type == "lsgan":
+                loss = loss + torch.mean((dr - 1) ** 2) + torch.mean(dg ** 2)
+            elif self.gan_loss_type in ("wgan", "wgan-gp"):
+                loss = loss - torch.mean(dr) + torch.mean(dg)
+        return loss
+
+    def generator_loss(self, disc_outputs):
+        loss = 0
+        for dg in disc_outputs:
+            if self.gan_loss_type == "lsgan":
+                loss = loss + torch.mean((1 - dg) ** 2)
+            elif self.gan_loss_type in ("wgan", "wgan-gp"):
+                loss = loss - torch.mean(dg)
+        return loss
+
+    def feature_loss(self, fmap_r, fmap_g):
+        loss, n = 0, 0
+        for dr, dg in zip(fmap_r, fmap_g):
+            for rl, gl in zip(dr, dg):
+                n += 1
+                loss = loss + torch.mean(torch.abs(rl - gl))
+        return loss / n
+
+    def gradient_penalty(self, real_data, generated_data, discriminator):
+        alpha = torch.rand(real_data.size(0), 1, 1, device=real_data.device)
+        inter = (alpha * real_data + (1 - alpha) * generated_data).requires_grad_(True)
+        d_inter, _, _, _ = discriminator(inter, None)
+        grads = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=[torch.ones_like(o) for o in d_inter],
+                                    create_graph=True, retain_graph=True, only_inputs=True)[0]
+        grads = grads.view(grads.size(0), -1)
+        return ((grads.norm(2, dim=1) - 1) ** 2).mean() * self.gp_weight

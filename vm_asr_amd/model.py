@@ -1,0 +1,294 @@
+"""DualStreamInteractiveMambaUNet on the HIP operators (generator of VM-ASR).
+
+Re-statement of the reference generator (model/model.py:119-1003 `MambaUNet`,
+:1006-1552 `DualStreamInteractiveMambaUNet`) with IDENTICAL `state_dict` keys and
+shapes, so reference checkpoints load with strict=True, and the same constructor
+keywords, so `model/__init__.py:get_model`'s call (:12-54) works unchanged.
+
+Data flow (48 kHz: wave (B,1,122640) -> spectrogram 513x512):
+    wav2spectro -> split DC bin -> patch-embed (x2 streams) -> 4 encoder stages <-> 4 decoder
+    stages (skip concat + 1x1 conv) -> output layer v3 (3 more VSS blocks at 1/4, 1/2, full
+    resolution) -> residual on magnitude -> re-attach DC -> spectro2wav.
+
+Reference behaviours that change numerics and are reproduced on purpose:
+  * with concat_skip the PHASE stream runs through the MAGNITUDE decoders
+    (model/model.py:1186-1187); `layers_decoder_phase` exists in the state_dict but never
+    receives a gradient;
+  * interaction is sequential: mag += phase, then phase += (new) mag (:1175-1176);
+  * low-frequency replacement copies the whole model output (its slice indexes the channel
+    axis, :447-451), i.e. it is the identity whenever highcut >= 1 — so the second STFT
+    the reference spends there is not recomputed here; the highcut == 0 corner (output
+    replaced by the input spectrogram) is kept.
+
+Only the configuration family reachable from configs/*.yaml is built: 4-entry dims,
+norm "LN", patch-embed v2, down/upsample v1, output v3, interact dual/m2p/p2m/single.
+"""
+from collections import OrderedDict
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .stft import spectro2wav, wav2spectro
+from .vmamba import PatchMerging2D, Permute, VSSBlock
+
+__all__ = ["PatchMerging2D", "PatchExpanding", "MambaUNet", "DualStreamInteractiveMambaUNet"]
+
+
+class PatchExpanding(nn.Module):
+    """(B,H,W,C) -> (B,2H,2W,C/2): Linear C->2C, pixel-shuffle, LayerNorm  (model/model.py:92-116)."""
+
+    def __init__(self, dim, dim_scale=2, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.expand = nn.Linear(dim, 2 * dim, bias=False) if dim_scale == 2 else nn.Identity()
+        self.norm = norm_layer(dim // dim_scale) if norm_layer is not None else nn.Identity()
+
+    def forward(self, x):
+        x = self.expand(x)
+        B, H, W, C = x.shape
+        c = C // 4
+        # "b h w (p1 p2 c) -> b (h p1) (w p2) c"
+        x = x.view(B, H, W, 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, c)
+        return self.norm(x)
+
+
+class GemmConv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict keys) evaluated as im2col + GEMM.
+
+    MIOpen has no tuned bf16 solver for the generator's tiny-channel convolutions (1->8 and 8->16
+    channels, 3x3 stride 2 on 512x512 / 256x256 planes): it falls back to `naive_conv_*` kernels
+    whose weight-gradient alone costs 27-84 ms per call on MI355X (profiles/r01_*).  unfold + a
+    hipBLASLt GEMM is the same arithmetic at memory speed."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
+        B, C, H, W = x.shape
+        kh, kw = self.kernel_size
+        Ho = (H + 2 * self.padding[0] - kh) // self.stride[0] + 1
+        Wo = (W + 2 * self.padding[1] - kw) // self.stride[1] + 1
+        cols = F.unfold(x, self.kernel_size, padding=self.padding, stride=self.stride)  # (B, C*kh*kw, Ho*Wo)
+        y = torch.matmul(self.weight.flatten(1).to(cols.dtype), cols)                    # (B, Cout, Ho*Wo)
+        if self.bias is not None:
+            y = y + self.bias.to(y.dtype).view(1, -1, 1)
+        return y.view(B, -1, Ho, Wo)
+
+
+class PointwiseConvCL(nn.Conv2d):
+    """1x1 nn.Conv2d (same parameters / keys) applied to CHANNEL-LAST (B,H,W,C) input as a Linear.
+    Replaces the reference's Permute -> Conv2d(1x1) -> Permute sandwiches (model/model.py:917-921,
+    862-864) without the two layout copies and without MIOpen's naive 1x1 fallbacks."""
+
+    def forward(self, x):
+        return F.linear(x, self.weight.flatten(1), self.bias)
+
+
+_ACT = dict(silu=nn.SiLU, gelu=nn.GELU, relu=nn.ReLU, sigmoid=nn.Sigmoid)
+
+
+def _vss_layer(dim, drop_path, norm_layer, sampler, concat_skip, blk_kw):
+    """skip_handler (1x1 conv over the concatenated skip) -> VSSBlocks -> sampler
+    (model/model.py:890-958).  Key names: skip_handler.1.*, blocks.N.*, sampler.*"""
+    skip = nn.Identity()
+    if concat_skip:
+        # index 1 keeps the reference's key `skip_handler.1.{weight,bias}`
+        skip = nn.Sequential(nn.Identity(), PointwiseConvCL(2 * dim, dim, kernel_size=1), nn.Identity())
+    blocks = [VSSBlock(hidden_dim=dim, drop_path=dp, norm_layer=norm_layer, channel_first=False, **blk_kw)
+              for dp in drop_path]
+    return nn.Sequential(OrderedDict([("skip_handler", skip), ("blocks", nn.Sequential(*blocks)),
+                                      ("sampler", sampler)]))
+
+
+class MambaUNet(nn.Module):
+    """Single-stream builder; DualStreamInteractiveMambaUNet deep-copies its parts."""
+
+    def __init__(self, patch_size=4, in_chans=1, depths=[2, 2, 9, 2], dims=[96, 192, 384, 768],
+                 ssm_d_state=16, ssm_ratio=2.0, ssm_dt_rank="auto", ssm_act_layer="silu", ssm_conv=3,
+                 ssm_conv_bias=True, ssm_drop_rate=0.0, ssm_init="v0", forward_type="v2", mlp_ratio=4.0,
+                 mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False, drop_path_rate=0.1, patch_norm=True,
+                 norm_layer="LN", patchembed_version="v2", downsample_version="v1", upsample_version="v1",
+                 output_version="v2", concat_skip=False, n_fft=512, hop_length=64, win_length=256,
+                 spectro_scale="log2", low_freq_replacement=False, **kwargs):
+        super().__init__()
+        if norm_layer.lower() != "ln":
+            raise NotImplementedError("norm_layer: only 'LN' is built (config.py:115; no yaml overrides it)")
+        if patchembed_version != "v2" or downsample_version != "v1" or upsample_version != "v1":
+            raise NotImplementedError("only patch-embed v2 / downsample v1 / upsample v1 are built (config.py:116-118)")
+        if output_version != "v3":
+            raise NotImplementedError("only output layer v3 is built (config.py:119; no yaml overrides it)")
+        if patch_size != 4:
+            raise NotImplementedError("patch_size must be 4 (model/model.py:612)")
+        self.channel_first = False
+        self.num_layers = len(depths)
+        self.depths = list(depths)
+        if isinstance(dims, int):
+            dims = [int(dims * 2 ** i) for i in range(self.num_layers)]
+        if len(dims) != self.num_layers:
+            raise NotImplementedError("the 5-entry dims (latent layer) variant is not reachable from any yaml")
+        self.dims = list(dims)
+        self.num_features = dims[-1]
+        self.dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.concat_skip = concat_skip
+        self.n_fft, self.hop_length, self.win_length = n_fft, hop_length, win_length
+        self.spectro_scale = spectro_scale
+        self.low_freq_replacement = low_freq_replacement
+
+        LN = nn.LayerNorm
+        blk_kw = dict(ssm_d_state=ssm_d_state, ssm_ratio=ssm_ratio, ssm_dt_rank=ssm_dt_rank,
+                      ssm_act_layer=_ACT[ssm_act_layer.lower()], ssm_conv=ssm_conv, ssm_conv_bias=ssm_conv_bias,
+                      ssm_drop_rate=ssm_drop_rate, ssm_init=ssm_init, forward_type=forward_type,
+                      mlp_ratio=mlp_ratio, mlp_act_layer=_ACT[mlp_act_layer.lower()], mlp_drop_rate=mlp_drop_rate,
+                      gmlp=gmlp)
+        d, nl, dep = self.dims, self.num_layers, self.depths
+
+        # patch embed v2 (model/model.py:603-633): 2 stride-2 convs with LN/GELU in between
+        e = d[0]
+        self.patch_embed = nn.Sequential(
+            GemmConv2d(in_chans, e // 2, kernel_size=3, stride=2, padding=1), Permute(0, 2, 3, 1),
+            LN(e // 2) if patch_norm else nn.Identity(), Permute(0, 3, 1, 2), nn.GELU(),
+            GemmConv2d(e // 2, e, kernel_size=3, stride=2, padding=1), Permute(0, 2, 3, 1),
+            LN(e) if patch_norm else nn.Identity())
+
+        self.layers_encoder = nn.ModuleList()
+        for i in range(nl):
+            down = PatchMerging2D(d[i], d[i + 1], norm_layer=LN) if i < nl - 1 else nn.Identity()
+            self.layers_encoder.append(_vss_layer(d[i], self.dpr[sum(dep[:i]):sum(dep[:i + 1])], LN, down, False, blk_kw))
+        self.layers_latent = nn.ModuleList()
+
+        # decoders run i_layer = nl .. 1; the first has no blocks (empty drop-path slice) and no sampler
+        self.layers_decoder = nn.ModuleList()
+        for i in range(nl, 0, -1):
+            dim = d[i] if i < nl - 1 else d[nl - 1]
+            up = PatchExpanding(d[i], dim_scale=2, norm_layer=LN) if i < nl else nn.Identity()
+            self.layers_decoder.append(_vss_layer(dim, self.dpr[sum(dep[:i]):sum(dep[:i + 1])], LN, up,
+                                                  concat_skip if i < nl else False, blk_kw))
+
+        # output layer v3 (model/model.py:773-887)
+        last = self.dpr[-1:]
+        self.output_layer = nn.Sequential(
+            _vss_layer(e, last, nn.Identity, PatchExpanding(e, 2, LN), concat_skip, blk_kw),
+            _vss_layer(e // 2, last, LN, PatchExpanding(e // 2, 2, LN), False, blk_kw),
+            nn.Identity(), PointwiseConvCL(e // 4, in_chans, kernel_size=1), nn.Identity(),  # key `output_layer.3.*`
+            _vss_layer(in_chans, last, nn.Identity, nn.Identity(), False, blk_kw),
+            Permute(0, 3, 1, 2))
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m: nn.Module):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ---- STFT front-end (model/model.py:424-445) -------------------------------------------
+    def _mag_phase(self, x):
+        if x.shape[-1] % self.hop_length:
+            x = F.pad(x, (0, self.hop_length - x.shape[-1] % self.hop_length))
+        return wav2spectro(x, self.n_fft, self.hop_length, self.win_length, self.spectro_scale)
+
+    def _i_mag_phase(self, mag, phase):
+        return spectro2wav(mag, phase, self.n_fft, self.hop_length, self.win_length, self.spectro_scale)
+
+    def __str__(self):
+        n = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        return super().__str__() + f"\nTrainable parameters: {n}"
+
+
+class DualStreamInteractiveMambaUNet(MambaUNet):
+    def __init__(self, *args, interact="dual", **kwargs):
+        super().__init__(*args, **kwargs)
+        if interact not in ("dual", "m2p", "p2m", "single"):
+            raise ValueError(f"interact='{interact}'")
+        self.interact = interact
+        self.patch_embed_mag = deepcopy(self.patch_embed)
+        self.layers_encoder_mag = deepcopy(self.layers_encoder)
+        self.layers_latent_mag = None
+        self.layers_decoder_mag = deepcopy(self.layers_decoder)
+        self.output_layer_mag = deepcopy(self.output_layer)
+        if interact != "single":
+            self.patch_embed_phase = deepcopy(self.patch_embed)
+            self.layers_encoder_phase = deepcopy(self.layers_encoder)
+            self.layers_latent_phase = None
+            self.layers_decoder_phase = deepcopy(self.layers_decoder)
+            self.output_layer_phase = deepcopy(self.output_layer)
+        del self.patch_embed, self.layers_encoder, self.layers_latent, self.layers_decoder, self.output_layer
+        self.apply(self._init_weights)  # the reference re-draws every Linear after the copy
+
+    def _interact(self, mag, phase):
+        if self.interact in ("dual", "p2m"):
+            mag = mag + phase
+        if self.interact in ("dual", "m2p"):
+            phase = phase + mag
+        return mag, phase
+
+    def forward(self, x, hf):
+        length = x.shape[-1]
+        mag_in, phase_in = self._mag_phase(x)          # (B,1,F,M) fp32
+        mag_dc, phase_dc = mag_in[..., :1, :], phase_in[..., :1, :]
+        mag, phase = mag_in[..., 1:, :], phase_in[..., 1:, :]
+        residual_mag = mag
+        single = self.interact == "single"
+
+        mag = self.patch_embed_mag(mag)
+        skips_m = [mag]
+        if not single:
+            phase = self.patch_embed_phase(phase)
+            skips_p = [phase]
+            for i in range(self.num_layers):
+                mag = self.layers_encoder_mag[i](mag)
+                phase = self.layers_encoder_phase[i](phase)
+                if i < self.num_layers - 1:
+                    skips_m.append(mag)
+                    skips_p.append(phase)
+                mag, phase = self._interact(mag, phase)
+            for i in range(self.num_layers):
+                dec_m, dec_p = self.layers_decoder_mag[i], self.layers_decoder_phase[i]
+                if i != 0:
+                    ms, ps = skips_m.pop(), skips_p.pop()
+                    if self.concat_skip:
+                        mag = dec_m(torch.cat((mag, ms), dim=-1))
+                        phase = dec_m(torch.cat((phase, ps), dim=-1))  # sic: magnitude decoder (model/model.py:1187)
+                    else:
+                        mag, phase = dec_m(mag + ms), dec_p(phase + ps)
+                else:
+                    mag, phase = dec_m(mag), dec_p(phase)
+                mag, phase = self._interact(mag, phase)
+            ms, ps = skips_m.pop(), skips_p.pop()
+            if self.concat_skip:
+                mag = self.output_layer_mag(torch.cat((mag, ms), dim=-1))
+                phase = self.output_layer_phase(torch.cat((phase, ps), dim=-1))
+            else:
+                mag, phase = self.output_layer_mag(mag + ms), self.output_layer_phase(phase + ps)
+        else:
+            for i in range(self.num_layers):
+                mag = self.layers_encoder_mag[i](mag)
+                if i < self.num_layers - 1:
+                    skips_m.append(mag)
+            for i in range(self.num_layers):
+                if i != 0:
+                    ms = skips_m.pop()
+                    mag = self.layers_decoder_mag[i](torch.cat((mag, ms), dim=-1) if self.concat_skip else mag + ms)
+                else:
+                    mag = self.layers_decoder_mag[i](mag)
+            ms = skips_m.pop()
+            mag = self.output_layer_mag(torch.cat((mag, ms), dim=-1) if self.concat_skip else mag + ms)
+
+        mag = mag.float() + residual_mag
+        mag = torch.cat([mag_dc, mag], dim=-2)
+        if not single:
+            phase = torch.cat([phase_dc, phase.float()], dim=-2)
+        else:
+            phase = phase_in
+        if self.low_freq_replacement:
+            # reference: y = spectro(x); y[i, :hf[i], :] = out[i, :hf[i], :] on a (1,F,M) slice ->
+            # copies everything unless hf[i] == 0 (model/model.py:447-451,1217-1221)
+            keep = (hf.to(mag.device) > 0).view(-1, 1, 1, 1)
+            mag = torch.where(keep, mag, mag_in)
+            if not single:
+                phase = torch.where(keep, phase, phase_in)
+        wav = self._i_mag_phase(mag, phase)
+        return wav[..., :length]

@@ -1,0 +1,422 @@
+"""Training harness: the reference's BaseTrainer / Trainer surface on one process per GPU.
+
+Mirrors base/base_trainer.py:12-231 and trainer/trainer.py:10-495 (constructor arguments,
+`train`, `_train_epoch`, `_valid_epoch`, `_save_checkpoint`, `_resume_checkpoint`, checkpoint
+file names and dict layout), re-designed for MI355X data parallelism, which the reference does
+not have (README.md:31):
+
+  * one process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI); the clip batch
+    is sharded across ranks, gradients are all-reduced by DistributedDataParallel buckets
+    overlapped with backward; no data-path collective;
+  * the 129 `layers_decoder_phase` tensors never receive a gradient in the reference either
+    (model/model.py:1187) — they are excluded from the DDP reducer statically instead of paying
+    `find_unused_parameters` every step;
+  * the generator's adversarial/feature losses run through the discriminator with its
+    parameters frozen, so the 164 MB MPD gradient is produced and all-reduced once per step
+    (the reference fills and discards it during the G update, trainer/trainer.py:428-438);
+  * bf16 autocast without GradScaler (the reference: fp16 + GradScaler, :106-107); the scan
+    still runs fp32 (forward type v5, model/vmamba.py:842-848);
+  * no anomaly mode (:320) and no per-loss `.item()` syncs (:158-176): scalars are read every
+    PRINT_FREQ steps.
+"""
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+from . import metric as metric_mod
+from .loss import HiFiGANLoss, MultiResolutionSTFTLoss, mae_loss, mse_loss
+
+__all__ = ["BaseTrainer", "Trainer", "SyntheticVCTK", "CosineWarmupScheduler", "build_optimizer",
+           "set_weight_decay", "init_distributed", "unwrap"]
+
+
+def init_distributed():
+    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*). Returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def unwrap(m):
+    return m.module if isinstance(m, DDP) else m
+
+
+class SyntheticVCTK(torch.utils.data.Dataset):
+    """Synthetic clips with the reference's batch contract
+    `(wave_in (1,T), wave_tgt (1,T), highcut int64, name, pad)` — CustomVCTK_092._load_sample
+    (data_loader/data_loaders.py:490-513); T = int(SEGMENT * TARGET_SR) (:138-140);
+    highcut = int((n_fft/2+1) * sr_in / sr_tgt) (:482-486).  Seeds follow SURVEY.md §8d."""
+
+    def __init__(self, config, length=64, sr_in=16000, seed=123):
+        self.T = int(config.DATA.SEGMENT * config.DATA.TARGET_SR)
+        self.n = length
+        self.seed = seed
+        self.highcut = int((config.DATA.STFT.N_FFT // 2 + 1) * sr_in / config.DATA.TARGET_SR)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed + i)
+        tgt = 0.1 * torch.randn(1, self.T, generator=g)
+        g2 = torch.Generator().manual_seed(self.seed + 1 + 7919 * (i + 1))
+        inp = 0.1 * torch.randn(1, self.T, generator=g2)
+        return inp, tgt, torch.tensor(self.highcut, dtype=torch.int64), f"synthetic_{i:06d}", 0
+
+
+def set_weight_decay(models):
+    """1-D tensors, biases and `_no_weight_decay` params get weight_decay 0 (utils/optimizer.py:53-77)."""
+    decay, no_decay = [], []
+    for model in models:
+        for name, p in unwrap(model).named_parameters():
+            if not p.requires_grad:
+                continue
+            (no_decay if (p.ndim == 1 or name.endswith(".bias") or getattr(p, "_no_weight_decay", False))
+             else decay).append(p)
+    return [{"params": decay}, {"params": no_decay, "weight_decay": 0.0}]
+
+
+def build_optimizer(config, models):
+    if not isinstance(models, (list, tuple)):
+        models = [models]
+    groups = set_weight_decay(models)
+    name = config.TRAIN.OPTIMIZER.NAME.lower()
+    if name == "adamw":
+        return torch.optim.AdamW(groups, lr=config.TRAIN.BASE_LR, eps=config.TRAIN.OPTIMIZER.EPS,
+                                 betas=tuple(config.TRAIN.OPTIMIZER.BETAS), weight_decay=config.TRAIN.WEIGHT_DECAY)
+    if name == "sgd":
+        return torch.optim.SGD(groups, lr=config.TRAIN.BASE_LR, momentum=config.TRAIN.OPTIMIZER.MOMENTUM,
+                               nesterov=True, weight_decay=config.TRAIN.WEIGHT_DECAY)
+    raise NotImplementedError(name)
+
+
+class CosineWarmupScheduler:
+    """Linear warm-up from MIN_LR then one cosine cycle to MIN_LR, stepped per update
+    (`step_update`), like the timm scheduler the reference configures (utils/lr_scheduler.py:15-41)."""
+
+    def __init__(self, optimizer, total_steps, warmup_steps, base_lr, min_lr, warmup_prefix=True):
+        self.opt, self.base_lr, self.min_lr = optimizer, base_lr, min_lr
+        self.warm = max(0, int(warmup_steps))
+        self.t_initial = max(1, int(total_steps - self.warm if warmup_prefix else total_steps))
+        self.prefix = warmup_prefix
+        self.step_update(0)
+
+    def lr_at(self, t):
+        if t < self.warm:
+            return self.min_lr + (self.base_lr - self.min_lr) * t / max(1, self.warm)
+        tt = t - self.warm if self.prefix else t
+        if tt >= self.t_initial:
+            return self.min_lr
+        return self.min_lr + 0.5 * (self.base_lr - self.min_lr) * (1 + math.cos(math.pi * tt / self.t_initial))
+
+    def step_update(self, num_updates):
+        lr = self.lr_at(num_updates)
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+
+
+class _Logger:
+    def info(self, m):
+        print(m, flush=True)
+
+    warning = info
+
+
+class BaseTrainer:
+    def __init__(self, models, metric_ftns, optimizer, config, logger=None):
+        self.config, self.logger = config, logger or _Logger()
+        self.models, self.metric_ftns, self.optimizer = models, metric_ftns, optimizer
+        self.epochs, self.monitor = config.TRAIN.EPOCHS, config.MONITOR
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if self.monitor == "off":
+            self.mnt_mode, self.mnt_best = "off", 0
+        else:
+            self.mnt_mode, self.mnt_metric = self.monitor.split()
+            assert self.mnt_mode in ("min", "max")
+            self.mnt_best = math.inf if self.mnt_mode == "min" else -math.inf
+            self.early_stop = config.TRAIN.EARLY_STOPPING if config.TRAIN.EARLY_STOPPING > 0 else math.inf
+        self.start_epoch = 1
+        self.log_dir = config.OUTPUT
+        self.epoch_log = {}
+        self.do_validation = False
+        if config.MODEL.RESUME_PATH is not None:
+            self._resume_checkpoint()
+
+    def _train_epoch(self, epoch):
+        raise NotImplementedError
+
+    def _valid_epoch(self, epoch):
+        raise NotImplementedError
+
+    def train(self):
+        not_improved = 0
+        for epoch in range(self.start_epoch, self.epochs + 1):
+            self._train_epoch(epoch)
+            if self.do_validation:
+                self._valid_epoch(epoch)
+            log = {"epoch": epoch, **self.epoch_log}
+            self._log_epoch(log)
+            best = False
+            if self.mnt_mode != "off":
+                if self.mnt_metric not in log:
+                    self.logger.warning(f"Metric '{self.mnt_metric}' is not found. Monitoring is disabled.")
+                    self.mnt_mode = "off"
+                else:
+                    v = log[self.mnt_metric]
+                    improved = v <= self.mnt_best if self.mnt_mode == "min" else v >= self.mnt_best
+                    if improved:
+                        self.mnt_best, not_improved, best = v, 0, True
+                    else:
+                        not_improved += 1
+                    if not_improved > self.early_stop:
+                        self.logger.info(f"Validation performance didn't improve for {self.early_stop} epochs. Stop.")
+                        break
+            self._save_checkpoint(epoch, save_best=best)
+
+    def _save_checkpoint(self, epoch, save_best=False):
+        """checkpoint-{latest,best,epoch-N}-{G|mpd}.pth with the reference's dict layout
+        (base/base_trainer.py:130-179); rank 0 writes."""
+        if self.rank != 0:
+            return
+        os.makedirs(self.log_dir, exist_ok=True)
+        for key, model in self.models.items():
+            if model is None:
+                continue
+            name = "G" if key == "generator" else key
+            mtype = "generator" if key == "generator" else "discriminator"
+            state = {"name": name, "epoch": epoch, "state_dict": unwrap(model).state_dict(),
+                     "optimizer": self.optimizer[mtype].state_dict(), "monitor_best": self.mnt_best,
+                     "config": self.config.dump() if hasattr(self.config, "dump") else self.config}
+            torch.save(state, os.path.join(self.log_dir, f"checkpoint-latest-{name}.pth"))
+            if self.config.SAVE_EPOCH_FREQ != -1 and epoch % self.config.SAVE_EPOCH_FREQ == 0:
+                torch.save(state, os.path.join(self.log_dir, f"checkpoint-epoch-{epoch}-{name}.pth"))
+            if save_best:
+                torch.save(state, os.path.join(self.log_dir, f"checkpoint-best-{name}.pth"))
+
+    def _resume_checkpoint(self):
+        """Loads `checkpoint-best-*.pth` (falls back to latest) from MODEL.RESUME_PATH
+        (utils/utils.py:112-178): state_dict strict, optimizer state, epoch, monitor_best."""
+        path = self.config.MODEL.RESUME_PATH
+        for key, model in self.models.items():
+            if model is None:
+                continue
+            name = "G" if key == "generator" else key
+            mtype = "generator" if key == "generator" else "discriminator"
+            for kind in ("best", "latest"):
+                f = os.path.join(path, f"checkpoint-{kind}-{name}.pth")
+                if os.path.exists(f):
+                    ck = torch.load(f, map_location="cpu", weights_only=False)
+                    unwrap(model).load_state_dict(ck["state_dict"], strict=True)
+                    if self.optimizer and mtype in self.optimizer and "optimizer" in ck:
+                        self.optimizer[mtype].load_state_dict(ck["optimizer"])
+                    self.start_epoch = ck["epoch"] + 1
+                    self.mnt_best = ck.get("monitor_best", self.mnt_best)
+                    self.logger.info(f"Resumed {name} from {f} (epoch {ck['epoch']})")
+                    break
+
+    def _log_epoch(self, logs):
+        if self.rank == 0:
+            self.logger.info(" | ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in logs.items()))
+        bad = [k for k, v in logs.items() if isinstance(v, float) and (math.isnan(v) or math.isinf(v))]
+        if bad:
+            self.logger.warning(f"Found invalid values: {bad}. Terminating.")
+            raise SystemExit(1)
+
+
+class Trainer(BaseTrainer):
+    def __init__(self, models, metric_ftns, optimizers, config, device, data_loader_train, data_loader_val=None,
+                 lr_schedulers=None, amp=False, gan=False, logger=None, len_epoch=None):
+        super().__init__(models, metric_ftns, optimizers, config, logger)
+        self.device = device[0] if isinstance(device, (tuple, list)) else device
+        self.data_loader, self.data_loader_val = data_loader_train, data_loader_val
+        self.len_epoch = len_epoch if len_epoch is not None else (len(data_loader_train) if data_loader_train is not None else 0)
+        self.do_validation = data_loader_val is not None and config.DATA.VALID_SPLIT > 0.0
+        self.amp, self.gan = amp, gan
+        lr_schedulers = lr_schedulers or {}
+        self.optimizer_G = optimizers["generator"]
+        self.lr_scheduler_G = lr_schedulers.get("generator")
+        if self.gan:
+            self.optimizer_D = optimizers["discriminator"]
+            self.lr_scheduler_D = lr_schedulers.get("discriminator")
+        self._init_losses()
+        for k, m in list(self.models.items()):
+            if m is not None:
+                self.models[k] = m.to(self.device)
+        self._wrap_ddp()
+        self.global_step = 0
+
+    # ---- distributed -----------------------------------------------------------------------
+    def _wrap_ddp(self):
+        if self.world <= 1:
+            return
+        gen = self.models["generator"]
+        if not isinstance(gen, DDP):
+            ignore = []
+            if getattr(gen, "concat_skip", False) and getattr(gen, "interact", "dual") != "single":
+                ignore = [n for n, _ in gen.named_parameters()
+                          if n.startswith("layers_decoder_phase.") and not n.startswith("layers_decoder_phase.0.")]
+            DDP._set_params_and_buffers_to_ignore_for_model(gen, ignore)
+            ids = [self.device.index] if self.device.type == "cuda" else None
+            # xGMI is point-to-point: a ring all-reduce is bound by one link, so prefer few large
+            # buckets (whole generator = 12 MB in one bucket; MPD 164 MB in ~4)
+            self.models["generator"] = DDP(gen, device_ids=ids, bucket_cap_mb=48, gradient_as_bucket_view=True,
+                                           broadcast_buffers=False)
+        if self.gan and self.models.get("mpd") is not None and not isinstance(self.models["mpd"], DDP):
+            ids = [self.device.index] if self.device.type == "cuda" else None
+            self.models["mpd"] = DDP(self.models["mpd"], device_ids=ids, bucket_cap_mb=48,
+                                     gradient_as_bucket_view=True, broadcast_buffers=True)
+
+    # ---- losses (trainer/trainer.py:88-96, 318-399) ----------------------------------------
+    def _init_losses(self):
+        a = self.config.TRAIN.ADVERSARIAL
+        self.multi_resolution_stft = MultiResolutionSTFTLoss(factor_sc=a.STFT_LOSS.SC_FACTOR,
+                                                             factor_mag=a.STFT_LOSS.MAG_FACTOR,
+                                                             emphasize_high_freq=a.STFT_LOSS.EMPHASIZE_HIGH_FREQ)
+        self.higi_gan_loss = HiFiGANLoss(gan_loss_type=a.GAN_LOSS_TYPE, gp_weight=a.GP_LAMBDA)
+
+    def _get_stft_loss(self, wave_out, wave_target):
+        sc, mag = self.multi_resolution_stft(wave_out.squeeze(1), wave_target.squeeze(1))
+        return sc + mag
+
+    def _generator_losses(self, wave_out, wave_target, fmap_real=None):
+        cfg, out = self.config.TRAIN, {}
+        wave_out = wave_out.float()
+        if "l1" in cfg.LOSSES.GEN:
+            out["l1"] = mae_loss(wave_out, wave_target)
+        if "l2" in cfg.LOSSES.GEN:
+            out["l2"] = mse_loss(wave_out, wave_target)
+        if "multi_resolution_stft" in cfg.LOSSES.GEN:
+            out["multi_resolution_stft"] = self._get_stft_loss(wave_out, wave_target)
+        if self.gan and "mpd" in cfg.ADVERSARIAL.DISCRIMINATORS:
+            mpd = unwrap(self.models["mpd"])  # frozen pass: no MPD gradients, no DDP hooks
+            flags = [p.requires_grad for p in mpd.parameters()]
+            for p in mpd.parameters():
+                p.requires_grad_(False)
+            try:
+                if fmap_real is None:  # the reference recomputes the real-signal features here
+                    with torch.no_grad():
+                        _, fmap_real = mpd.forward_single(wave_target)
+                y_gen, fmap_gen = mpd.forward_single(wave_out)
+            finally:
+                for p, f in zip(mpd.parameters(), flags):
+                    p.requires_grad_(f)
+            if not cfg.ADVERSARIAL.ONLY_FEATURE_LOSS:
+                out["adversarial_mpd"] = self.higi_gan_loss.generator_loss(y_gen)
+            if not cfg.ADVERSARIAL.ONLY_ADVERSARIAL_LOSS:
+                out["features_mpd"] = cfg.ADVERSARIAL.FEATURE_LOSS_LAMBDA * self.higi_gan_loss.feature_loss(fmap_real, fmap_gen)
+        return out
+
+    def _discriminator_losses(self, wave_out, wave_target):
+        """-> (losses, detached real-signal feature maps for the generator's feature-matching loss:
+        same discriminator weights, same input, so they equal what the reference recomputes)."""
+        out, fmap_real = {}, None
+        if self.gan and "mpd" in self.config.TRAIN.ADVERSARIAL.DISCRIMINATORS:
+            fake = wave_out.detach().float()
+            y_real, y_gen, fr, _ = self.models["mpd"](wave_target, fake)
+            fmap_real = [[f.detach() for f in fs] for fs in fr]
+            d = self.higi_gan_loss.discriminator_loss(y_real, y_gen)
+            if self.config.TRAIN.ADVERSARIAL.GAN_LOSS_TYPE == "wgan-gp":
+                d = d + self.higi_gan_loss.gradient_penalty(wave_target, fake, unwrap(self.models["mpd"]))
+            out["mpd"] = d
+        return out, fmap_real
+
+    # ---- one optimisation step (the unit bench.py times) ------------------------------------
+    def train_step(self, wave_input, wave_target, highcut):
+        """forward -> losses -> backward -> optimiser for G, then for D; returns dict of loss tensors."""
+        acc = self.config.TRAIN.ACCUMULATION_STEPS
+        with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
+            wave_out = self.models["generator"](wave_input, highcut)
+            # D loss first, with the same D weights the G pass sees (reference order, trainer/trainer.py:369-399)
+            d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
+            g_losses = self._generator_losses(wave_out, wave_target, fmap_real)
+        total_g = sum(g_losses.values()) / acc
+        self.optimizer_G.zero_grad(set_to_none=True)
+        total_g.backward()
+        self.optimizer_G.step()
+        logs = {"total_loss": total_g.detach()}
+        logs.update({f"generator/{k}": v.detach() for k, v in g_losses.items()})
+        if self.gan:
+            total_d = sum(d_losses.values()) / acc
+            self.optimizer_D.zero_grad(set_to_none=True)
+            total_d.backward()
+            self.optimizer_D.step()
+            logs["total_disc_loss"] = total_d.detach()
+        self.global_step += 1
+        return wave_out.detach(), logs
+
+    def _to_dev(self, batch):
+        wave_input, wave_target, highcut = batch[0], batch[1], batch[2]
+        return (wave_input.to(self.device, non_blocking=True), wave_target.to(self.device, non_blocking=True),
+                highcut.to(self.device, non_blocking=True))
+
+    def _metrics(self, wave_out, wave_target, highcut):
+        out = {}
+        for met in self.metric_ftns or []:
+            out[met.__name__] = float(met(wave_out.float().squeeze(1), wave_target.squeeze(1), hf=highcut))
+        return out
+
+    def _train_epoch(self, epoch):
+        for m in self.models.values():
+            if m is not None:
+                m.train()
+        sums, count, t0 = {}, 0, time.time()
+        for batch_idx, batch in enumerate(self.data_loader):
+            if batch_idx >= self.len_epoch:
+                break
+            wave_input, wave_target, highcut = self._to_dev(batch)
+            wave_out, logs = self.train_step(wave_input, wave_target, highcut)
+            if batch_idx % self.config.PRINT_FREQ == 0 or batch_idx == self.len_epoch - 1:
+                vals = {k: float(v) for k, v in logs.items()}
+                vals.update(self._metrics(wave_out, wave_target, highcut))
+                for k, v in vals.items():
+                    sums[k] = sums.get(k, 0.0) + v
+                count += 1
+                if self.rank == 0:
+                    self.logger.info(f"Epoch {epoch} [{batch_idx + 1}/{self.len_epoch}] " +
+                                     " ".join(f"{k}={v:.4f}" for k, v in vals.items()))
+            step = (epoch - 1) * self.len_epoch + batch_idx
+            if self.lr_scheduler_G is not None:
+                self.lr_scheduler_G.step_update(step // self.config.TRAIN.ACCUMULATION_STEPS)
+            if self.gan and getattr(self, "lr_scheduler_D", None) is not None:
+                self.lr_scheduler_D.step_update(step // self.config.TRAIN.ACCUMULATION_STEPS)
+        self.epoch_log = {k: v / max(1, count) for k, v in sums.items()}
+        self.epoch_log["epoch_seconds"] = time.time() - t0
+
+    @torch.no_grad()
+    def _valid_epoch(self, epoch):
+        for m in self.models.values():
+            if m is not None:
+                m.eval()
+        sums, count = {}, 0
+        for batch in self.data_loader_val:
+            wave_input, wave_target, highcut = self._to_dev(batch)
+            with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
+                wave_out = unwrap(self.models["generator"])(wave_input, highcut)
+            vals = {"total_loss": float(sum(self._generator_losses(wave_out, wave_target).values()))} if not self.gan else {}
+            vals.update(self._metrics(wave_out, wave_target, highcut))
+            for k, v in vals.items():
+                sums[k] = sums.get(k, 0.0) + v
+            count += 1
+        if self.world > 1:
+            keys = sorted(sums)
+            t = torch.tensor([sums[k] for k in keys] + [float(count)], device=self.device, dtype=torch.float64)
+            dist.all_reduce(t)
+            sums, count = {k: t[i].item() for i, k in enumerate(keys)}, int(t[-1].item())
+        self.epoch_log.update({f"val_{k}": v / max(1, count) for k, v in sums.items()})
+        if self.mnt_mode != "off" and self.mnt_metric in sums:
+            self.epoch_log[self.mnt_metric] = sums[self.mnt_metric] / max(1, count)
+
+
+def default_metric_ftns(config):
+    return [getattr(metric_mod, m) for m in config.TRAIN.METRICS]

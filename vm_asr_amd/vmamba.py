@@ -266,7 +266,11 @@ class SS2D(nn.Module):
 
     # ---- module forward (model/vmamba.py:1533-1552) ----------------------------------------
     def _conv_act(self, x):
-        """conv2d + act; the SiLU case is one fused HIP kernel."""
+        """conv2d + act; the SiLU case is one fused HIP kernel.  `conv_act_fn` is a test hook in
+        the spirit of forward_corev2's operator keywords (the CPU oracle plugs in there)."""
+        hook = getattr(self, "conv_act_fn", None)
+        if hook is not None:
+            return hook(x, self.conv2d.weight, self.conv2d.bias)
         if self.d_conv == 3 and self._act_is_silu and x.is_cuda:
             return dwconv3x3_silu(x, self.conv2d.weight, self.conv2d.bias)
         if self.d_conv == 3 and self._act_is_silu:
