@@ -8,23 +8,29 @@
 //   * unit of work = one WAVE-TILE: 64 lanes x 4 consecutive steps = 256 steps of R rows
 //     that share one (batch, group) and therefore one B/C tile (loaded once per wave);
 //   * the recurrence h_t = a_t h_{t-1} + b_t is a scan over the monoid (a,b): 4 steps are
-//     composed per lane, the 64 lane aggregates are scanned across the wave with
-//     cross-lane shuffles, and the running state is a wave-uniform register (N==1) or an
-//     LDS slot (general N);  there is no block-wide barrier in the forward;
-//   * the sequence axis is parallelised two ways, chosen per call shape:
-//       mode 0  one wave walks a whole row tile by tile (rows*batch fills the chip);
-//       mode 1  tile-parallel 3-phase scan: per-tile aggregates -> scan of aggregates
-//               (this produces the saved states x) -> per-tile apply;
+//     composed per lane, the 64 lane aggregates are scanned inside each 16-lane DPP row with
+//     row_shr / row_shl moves and across the four rows with v_readlane (no LDS traffic, no
+//     ds_bpermute), and the running state is a wave-uniform register (N==1) or an LDS slot
+//     (general N);
+//   * the sequence axis is parallelised three ways, chosen per call shape:
+//       walk   one wave walks a whole row tile by tile            (rows*batch fills the chip)
+//       block  the W<=16 waves of a workgroup take consecutive tiles of one row and exchange
+//              tile totals through LDS: one pass, W-fold parallelism along L   (forward)
+//       split  tile-parallel 3-phase scan: per-tile aggregates -> scan of aggregates -> apply
+//              (the longest sequences with the fewest rows; also the backward's adjoint carry);
 //   * x holds the state at the END of every 256-step tile, so the backward restarts the
 //     forward recurrence of every tile independently; only the reverse (adjoint) scan
-//     carries across tiles, handled with the same two modes;
+//     carries across tiles;
 //   * dB/dC (summed over the rows of a group) are reduced across the waves of a workgroup
 //     in LDS and leave as 256-B contiguous float atomics (or plain stores when one
-//     workgroup owns the whole group).
+//     workgroup owns the whole group); dA/dD/ddelta_bias leave the split backward as
+//     per-task partials that a small kernel reduces (no same-address atomics).
 //
 // HBM roofline: algorithmic bytes are (3 KD + 2 K N) L s forward and (5 KD + 4 K N) L s
 // backward per clip.
 #include "common.h"
+
+#include <stdlib.h>
 
 namespace vmasr {
 namespace {
@@ -33,6 +39,7 @@ constexpr int kItems = 4;
 constexpr int kTile = kWave * kItems;  // 256 == VMASR_SSCAN_CHUNK
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kMaxDState = 256;
+constexpr int kMaxBlockWaves = 16;
 static_assert(kTile == VMASR_SSCAN_CHUNK, "tile must equal the saved-state chunk");
 
 struct Pair {
@@ -44,30 +51,74 @@ __device__ __forceinline__ Pair then(Pair first, Pair second) {
     return {second.a * first.a, fmaf(second.a, first.b, second.b)};
 }
 
-// forward inclusive scan across the wave: lane i <- p_0 then p_1 ... then p_i
-__device__ __forceinline__ Pair wave_scan_fwd(Pair v, int lane) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        Pair o{__shfl_up(v.a, off), __shfl_up(v.b, off)};
-        if (lane >= off) v = then(o, v);
-    }
-    return v;
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+constexpr int kRowShr = 0x110, kRowShl = 0x100;
+
+template <int CTRL>
+__device__ __forceinline__ Pair dpp_pair(Pair v) {  // lanes without a source in their row get the identity
+    return {dpp_mov<CTRL>(1.f, v.a), dpp_mov<CTRL>(0.f, v.b)};
 }
 
-// reverse inclusive scan: lane i <- p_63 then ... then p_i   (g_i = b_i + a_i * g_{i+1})
-__device__ __forceinline__ Pair wave_scan_rev(Pair v, int lane) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        Pair o{__shfl_down(v.a, off), __shfl_down(v.b, off)};
-        if (lane + off < kWave) v = then(o, v);
-    }
-    return v;
+__device__ __forceinline__ Pair lane_pair(Pair v, int lane) { return {readlane_f(v.a, lane), readlane_f(v.b, lane)}; }
+
+// Forward scan of the 64 lane aggregates: `excl` = composition of lanes [0, lane), `total` =
+// composition of all lanes (wave-uniform).
+__device__ __forceinline__ void wave_scan_fwd(Pair v, int lane, Pair &excl, Pair &total) {
+    v = then(dpp_pair<kRowShr + 1>(v), v);
+    v = then(dpp_pair<kRowShr + 2>(v), v);
+    v = then(dpp_pair<kRowShr + 4>(v), v);
+    v = then(dpp_pair<kRowShr + 8>(v), v);  // inclusive inside each 16-lane row
+    const Pair t0 = lane_pair(v, 15), t1 = lane_pair(v, 31), t2 = lane_pair(v, 47), t3 = lane_pair(v, 63);
+    const Pair p2 = then(t0, t1), p3 = then(p2, t2);
+    total = then(p3, t3);
+    const int row = lane >> 4;
+    const Pair pre = row == 0 ? Pair{1.f, 0.f} : (row == 1 ? t0 : (row == 2 ? p2 : p3));
+    excl = then(pre, dpp_pair<kRowShr + 1>(v));
 }
 
+// Reverse scan (g_i = b_i + a_i g_{i+1}): `excl` = composition of lanes (lane, 63] applied from the
+// right, `total` = all lanes.
+__device__ __forceinline__ void wave_scan_rev(Pair v, int lane, Pair &excl, Pair &total) {
+    v = then(dpp_pair<kRowShl + 1>(v), v);
+    v = then(dpp_pair<kRowShl + 2>(v), v);
+    v = then(dpp_pair<kRowShl + 4>(v), v);
+    v = then(dpp_pair<kRowShl + 8>(v), v);  // suffix-inclusive inside each row
+    const Pair t0 = lane_pair(v, 0), t1 = lane_pair(v, 16), t2 = lane_pair(v, 32), t3 = lane_pair(v, 48);
+    const Pair s1 = then(t3, t2), s0 = then(s1, t1);  // rows to the right of row 1 / row 0
+    total = then(s0, t0);
+    const int row = lane >> 4;
+    const Pair suf = row == 3 ? Pair{1.f, 0.f} : (row == 2 ? t3 : (row == 1 ? s1 : s0));
+    excl = then(suf, dpp_pair<kRowShl + 1>(v));
+}
+
+// value of lane+1 (lane 63 gets `last`)
+__device__ __forceinline__ float shift_from_next_lane(float v, int lane, float last) {
+    float r = dpp_mov<kRowShl + 1>(0.f, v);
+    const float f16 = readlane_f(v, 16), f32 = readlane_f(v, 32), f48 = readlane_f(v, 48);
+    r = lane == 15 ? f16 : r;
+    r = lane == 31 ? f32 : r;
+    r = lane == 47 ? f48 : r;
+    return lane == 63 ? last : r;
+}
+
+// softplus with the reference's threshold (cus/selective_scan_fwd_kernel.cuh:115-118).
+// log1p(e) without the libm call: a 4-term series below 2^-6, Kahan's log(u)*e/(u-1) above.
 __device__ __forceinline__ float softplus_f(float x) {
-    // threshold 20 as in the reference (cus/selective_scan_fwd_kernel.cuh:115-118)
-    return x <= 20.f ? log1pf(__expf(x)) : x;
+    const float e = __expf(fminf(x, 20.f));
+    const float u = 1.f + e;
+    const float big = __logf(u) * __fdividef(e, u - 1.f);
+    const float small = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.33333334f), -0.5f), 1.f);
+    const float sp = e < 0.015625f ? small : big;
+    return x <= 20.f ? sp : x;
 }
+
+// ---- task geometry ----------------------------------------------------------------------
+struct FwdGeom {
+    int tiles_per_task, nseg;
+};
 
 struct TaskMap {
     int b, d0, g, tile0, tile1;
@@ -94,25 +145,43 @@ __device__ __forceinline__ TaskMap map_task(const vmasr_sscan_params &p, int tas
 
 // =====================================================================================
 // forward
-//   MODE 0: carry-in zero at tile 0, sequential over [tile0,tile1), writes x per tile
-//   MODE 1: carry-in from x[tile0-1] (already scanned by the carry kernel), no x write
-//   MODE 2: aggregates only: writes the tile-local pair (prod a, h_end | h_in = 0) to x
-// DYN: general d_state (runtime loop over states, running state in LDS, R must be 1);
-// otherwise d_state == 1 and the running state lives in registers.
+//   MODE 0 walk : carry-in zero at tile 0, sequential over [tile0,tile1), writes x per tile
+//   MODE 1 apply: carry-in from x[tile0-1] (already scanned by the carry kernel), no x write
+//   MODE 2 agg  : aggregates only: writes the tile-local pair (prod a, h_end | h_in = 0) to x
+//   MODE 3 block: the waves of the workgroup own consecutive tiles of one row-block, exchange
+//                 tile totals through LDS (one barrier per W tiles), write x per tile
+// DYN: general d_state (runtime loop over states, running state in LDS, R must be 1).
+// x[...,1] is the state at the end of a tile; x[...,0] is diagnostic (a product of decays).
 // =====================================================================================
 template <typename T, int R, bool DYN, bool VEC, int MODE>
-__global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params p,
-                                                        const int tiles_per_task, const int nseg) {
+__global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const vmasr_sscan_params p,
+                                                                           const FwdGeom geo) {
     static_assert(!DYN || R == 1, "general-N path handles one row per wave");
+    static_assert(!(DYN && MODE == 3), "block mode is the d_state == 1 path");
     __shared__ float s_h[DYN ? 4 * kMaxDState : 1];
     __shared__ float s_p[DYN ? 4 * kMaxDState : 1];
+    __shared__ float2 s_tot[MODE == 3 ? 2 * kMaxBlockWaves * R : 1];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const TaskMap m = map_task<R>(p, bid * 4 + wave, tiles_per_task, nseg, ntiles);
-    if (!m.valid) return;
+    TaskMap m;
+    int W = 1;
+    if constexpr (MODE == 3) {
+        W = blockDim.x >> 6;
+        const int nrb = p.dim / R;
+        const int bid = xcd_remap(blockIdx.x, gridDim.x);
+        m.b = bid / nrb;
+        m.d0 = (bid % nrb) * R;
+        m.g = m.d0 / (p.dim / p.n_groups);
+        m.tile0 = 0;
+        m.tile1 = ntiles;
+        m.valid = true;
+    } else {
+        const int bid = xcd_remap(blockIdx.x, gridDim.x);
+        m = map_task<R>(p, bid * 4 + wave, geo.tiles_per_task, geo.nseg, ntiles);
+        if (!m.valid) return;
+    }
     const int L = p.seqlen, N = DYN ? p.dstate : 1;
 
     const T *__restrict__ Bg = static_cast<const T *>(p.B_ptr) + m.b * p.B_batch_stride + m.g * p.B_group_stride;
@@ -122,7 +191,7 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params
 
     const T *u_row[R], *dl_row[R];
     T *out_row[R];
-    float Dv[R], bias[R], h_in[R], p_in[R];
+    float Dv[R], bias[R], h_in[R], p_in[R], An1[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int d = m.d0 + r;
@@ -131,6 +200,7 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params
         out_row[r] = static_cast<T *>(p.out_ptr) + m.b * p.out_batch_stride + d * p.out_d_stride;
         Dv[r] = p.D_ptr ? static_cast<const float *>(p.D_ptr)[d] : 0.f;
         bias[r] = p.delta_bias_ptr ? static_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
+        An1[r] = DYN ? 0.f : Ap[d * p.A_d_stride] * kLog2e;
         h_in[r] = 0.f;
         p_in[r] = 1.f;
     }
@@ -155,8 +225,10 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params
         }
     }
 
-    for (int tile = m.tile0; tile < m.tile1; ++tile) {
-        const int t0 = tile * kTile + lane * kItems;
+    const int step = MODE == 3 ? W : 1;
+    for (int tbase = m.tile0, it = 0; tbase < m.tile1; tbase += step, ++it) {
+        const int tile = MODE == 3 ? tbase + wave : tbase;
+        const int t0 = tile * kTile + lane * kItems;  // >= L for the idle waves of a ragged block
         float uv[R][kItems], dl[R][kItems], outv[R][kItems];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -167,7 +239,7 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int i = 0; i < kItems; ++i) {
-                float v = dl[r][i] + bias[r];
+                const float v = dl[r][i] + bias[r];
                 dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
                 outv[r][i] = Dv[r] * uv[r][i];
             }
@@ -178,7 +250,7 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params
             if (MODE != 2) load4<T, VEC>(Cg + n * p.C_dstate_stride, t0, L, Cv);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float An = Ap[(m.d0 + r) * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
+                const float An = DYN ? Ap[(m.d0 + r) * p.A_d_stride + n * p.A_dstate_stride] * kLog2e : An1[r];
                 float a[kItems], bb[kItems];
 #pragma unroll
                 for (int i = 0; i < kItems; ++i) {
@@ -186,49 +258,58 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params
                     a[i] = in ? __builtin_amdgcn_exp2f(dl[r][i] * An) : 1.f;
                     bb[i] = in ? dl[r][i] * uv[r][i] * Bv[i] : 0.f;
                 }
-                // lane aggregate, then wave scan of aggregates
                 Pair agg{a[0], bb[0]};
 #pragma unroll
                 for (int i = 1; i < kItems; ++i) agg = then(agg, Pair{a[i], bb[i]});
-                const Pair inc = wave_scan_fwd(agg, lane);
-                const float tot_a = readlane_f(inc.a, kWave - 1), tot_b = readlane_f(inc.b, kWave - 1);
+                Pair excl, tot;
+                wave_scan_fwd(agg, lane, excl, tot);
                 if constexpr (MODE == 2) {
                     if (lane == 0) {
                         const size_t xi = (((xrow0 + (size_t)r * p.n_chunks) + tile) * N + n) * 2;
-                        xp[xi] = tot_a;
-                        xp[xi + 1] = tot_b;
+                        *reinterpret_cast<float2 *>(xp + xi) = make_float2(tot.a, tot.b);
                     }
                 } else {
                     float hin, pin;
                     if constexpr (DYN) {
                         hin = s_h[wave * kMaxDState + n];
                         pin = s_p[wave * kMaxDState + n];
+                    } else if constexpr (MODE == 3) {
+                        // exchange tile totals; carry-in = running state composed with the waves before
+                        float2 *slot = s_tot + ((it & 1) * kMaxBlockWaves) * R;
+                        if (lane == 0) slot[wave * R + r] = make_float2(tot.a, tot.b);
+                        __syncthreads();
+                        float hrun = h_in[r];
+                        hin = hrun;
+                        for (int w = 0; w < W; ++w) {
+                            const float2 tw = slot[w * R + r];
+                            hrun = fmaf(tw.x, hrun, tw.y);
+                            if (w + 1 == wave) hin = hrun;  // state after waves [0, wave)
+                        }
+                        h_in[r] = hrun;  // state after the whole super-tile (same in every wave)
+                        pin = 1.f;
                     } else {
                         hin = h_in[r];
                         pin = p_in[r];
                     }
-                    float ea = __shfl_up(inc.a, 1), eb = __shfl_up(inc.b, 1);
-                    if (lane == 0) { ea = 1.f; eb = 0.f; }
-                    float h = fmaf(ea, hin, eb);
+                    float h = fmaf(excl.a, hin, excl.b);
 #pragma unroll
                     for (int i = 0; i < kItems; ++i) {
                         h = fmaf(a[i], h, bb[i]);
                         outv[r][i] = fmaf(h, Cv[i], outv[r][i]);
                     }
-                    const float hout = fmaf(tot_a, hin, tot_b), pout = tot_a * pin;
+                    const float hout = fmaf(tot.a, hin, tot.b), pout = tot.a * pin;
                     if constexpr (DYN) {
                         if (lane == 0) {
                             s_h[wave * kMaxDState + n] = hout;
                             s_p[wave * kMaxDState + n] = pout;
                         }
-                    } else {
+                    } else if constexpr (MODE != 3) {
                         h_in[r] = hout;
                         p_in[r] = pout;
                     }
-                    if (MODE == 0 && lane == 0) {
+                    if ((MODE == 0 || MODE == 3) && lane == 0 && tile < ntiles) {
                         const size_t xi = (((xrow0 + (size_t)r * p.n_chunks) + tile) * N + n) * 2;
-                        xp[xi] = pout;
-                        xp[xi + 1] = hout;
+                        *reinterpret_cast<float2 *>(xp + xi) = make_float2(pout, hout);
                     }
                 }
             }
@@ -243,7 +324,7 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const vmasr_sscan_params
 // In-place inclusive scan of the per-tile aggregates of one (batch,row,state) sequence:
 // x[c] <- x[0] then ... then x[c].  One wave per sequence; lanes own contiguous runs.
 // REVERSE: exclusive scan from the right over (alpha, beta) pairs, used by the backward:
-// ws[c] <- g entering tile c from tile c+1 (beta slot), alpha slot unused afterwards.
+// ws[c].y <- adjoint entering tile c from tile c+1.
 template <bool REVERSE>
 __global__ __launch_bounds__(256) void sscan_carry_kernel(float *__restrict__ x, const int nseq,
                                                           const int n_chunks, const int N) {
@@ -254,13 +335,13 @@ __global__ __launch_bounds__(256) void sscan_carry_kernel(float *__restrict__ x,
     float *base = x + ((size_t)row * n_chunks * N + n) * 2;
     const size_t cstride = (size_t)N * 2;
     const int per = (n_chunks + kWave - 1) / kWave;
+    Pair excl, tot;
     if constexpr (!REVERSE) {
         const int c0 = lane * per, c1 = min(n_chunks, c0 + per);
         Pair agg{1.f, 0.f};
         for (int c = c0; c < c1; ++c) agg = then(agg, Pair{base[c * cstride], base[c * cstride + 1]});
-        const Pair inc = wave_scan_fwd(agg, lane);
-        Pair run{__shfl_up(inc.a, 1), __shfl_up(inc.b, 1)};
-        if (lane == 0) run = Pair{1.f, 0.f};
+        wave_scan_fwd(agg, lane, excl, tot);
+        Pair run = excl;
         for (int c = c0; c < c1; ++c) {
             run = then(run, Pair{base[c * cstride], base[c * cstride + 1]});
             base[c * cstride] = run.a;
@@ -271,13 +352,11 @@ __global__ __launch_bounds__(256) void sscan_carry_kernel(float *__restrict__ x,
         const int c1 = n_chunks - lane * per, c0 = max(0, c1 - per);
         Pair agg{1.f, 0.f};  // composition "later tile first": g_out = b + a*g_in
         for (int c = c1 - 1; c >= c0; --c) agg = then(agg, Pair{base[c * cstride], base[c * cstride + 1]});
-        // scan across lanes in lane order (lane 0 = rightmost run = applied first)
-        const Pair inc = wave_scan_fwd(c1 > 0 ? agg : Pair{1.f, 0.f}, lane);
-        Pair run{__shfl_up(inc.a, 1), __shfl_up(inc.b, 1)};
-        if (lane == 0) run = Pair{1.f, 0.f};
+        wave_scan_fwd(agg, lane, excl, tot);  // lane order == right-to-left order
+        Pair run = excl;
         for (int c = c1 - 1; c >= c0; --c) {
             const Pair mine{base[c * cstride], base[c * cstride + 1]};
-            base[c * cstride + 1] = run.b;  // g entering tile c from the right (g_in = 0 at the end)
+            base[c * cstride + 1] = run.b;  // adjoint entering tile c from the right (0 at the end)
             run = then(run, mine);
         }
     }
@@ -286,22 +365,24 @@ __global__ __launch_bounds__(256) void sscan_carry_kernel(float *__restrict__ x,
 // =====================================================================================
 // backward
 //   MODE 0: one workgroup walks [tile0,tile1) from the right, adjoint state in registers
-//   MODE 1: adjoint carry-in per tile read from ws (scanned by the reverse carry kernel)
+//   MODE 1: adjoint carry-in per task read from ws (scanned by the reverse carry kernel)
 //   MODE 2: per-tile reverse aggregates (prod alpha, beta-chain) written to ws
 // Workgroup = W waves (blockDim.x/64) that own W consecutive row-blocks of ONE group and
 // walk the same tiles in lockstep; dB/dC are reduced over the W*R rows in LDS.
 // =====================================================================================
 struct BwdGeom {
     int tiles_per_task, nseg, W, wg_per_group;  // wg_per_group = (rows_per_group / R) / W
+    float *part;                                // MODE 1, d_state 1: (batch*dim, nseg, 3) partial sums or null
+    int fused_carry;                            // MODE 1, d_state 1: fold the reverse aggregates in the prologue
 };
 
 template <typename T, int R, bool DYN, bool VEC, int MODE>
-__global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_params q, const BwdGeom geo) {
+__global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_params q, const BwdGeom geo) {
     static_assert(!DYN || R == 1, "general-N path handles one row per wave");
     const vmasr_sscan_params &p = q.f;
     __shared__ float s_g[DYN ? 4 * kMaxDState : 1];   // adjoint carry per state (general N)
     __shared__ float s_an[DYN ? 4 * kMaxDState : 1];  // a of the first step of the tile to the right
-    __shared__ __attribute__((aligned(16))) float s_red[2][4][kTile];  // dB / dC partials per wave
+    extern __shared__ __attribute__((aligned(16))) float s_red[];  // dB / dC partials: 2 x W x 256 floats (W > 1 only)
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -362,14 +443,30 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
             } else {
                 const float An = Ap[(d0 + r) * p.A_d_stride] * kLog2e;
                 a_nx[r] = tn < L ? __builtin_amdgcn_exp2f(dnx * An) : 1.f;
-                if (MODE == 1 && tn < L) g_in[r] = ws[((xrow0 + (size_t)r * p.n_chunks) + tile1 - 1) * 2 + 1];
+                if (MODE == 1 && tn < L) {
+                    if (geo.fused_carry) {
+                        // compose the reverse aggregates of every tile to the right of this task:
+                        // lane l owns tiles tile1 + l*per .. (right-to-left order == descending tile)
+                        const float *agg = ws + (xrow0 + (size_t)r * p.n_chunks) * 2;
+                        const int nright = ntiles - tile1, per = (nright + kWave - 1) / kWave;
+                        // adjoint entering from the right end is 0: fold tiles from the last one down
+                        Pair mine{1.f, 0.f};
+                        const int c_hi = ntiles - 1 - lane * per, c_lo = max(tile1, c_hi - per + 1);
+                        for (int c = c_hi; c >= c_lo; --c) mine = then(mine, Pair{agg[c * 2], agg[c * 2 + 1]});
+                        Pair ex, tt;
+                        wave_scan_fwd(mine, lane, ex, tt);  // lane order == right-to-left order
+                        g_in[r] = tt.b;                     // applied to an incoming adjoint of 0
+                    } else {
+                        g_in[r] = ws[((xrow0 + (size_t)r * p.n_chunks) + tile1 - 1) * 2 + 1];
+                    }
+                }
             }
         }
     }
 
     for (int tile = tile1 - 1; tile >= tile0; --tile) {
         const int t0 = tile * kTile + lane * kItems;
-        float uv[R][kItems], dl[R][kItems], dov[R][kItems], duv[R][kItems], ddv[R][kItems];
+        float uv[R][kItems], dl[R][kItems], dov[R][kItems], duv[R][kItems], ddv[R][kItems], sig[R][kItems];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             load4<T, VEC>(dl_row[r], t0, L, dl[r]);
@@ -383,6 +480,8 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
                 const float v = dl[r][i] + bias[r];
                 dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
                 if (MODE != 2) {
+                    // d softplus / dv = sigmoid(v) (1 above the threshold)
+                    sig[r][i] = (p.delta_softplus && v <= 20.f) ? __fdividef(1.f, 1.f + __expf(-v)) : 1.f;
                     duv[r][i] = Dv[r] * dov[r][i];
                     ddv[r][i] = 0.f;
                     accD[r] = fmaf(dov[r][i], uv[r][i], accD[r]);
@@ -406,8 +505,7 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
                 if constexpr (DYN) { anx = s_an[wave * kMaxDState + n]; gin = s_g[wave * kMaxDState + n]; }
                 else { anx = a_nx[r]; gin = g_in[r]; }
                 // alpha_i = a_{t+1}: next item, next lane's first item, or the tile to the right
-                float a_up = __shfl_down(a[0], 1);
-                if (lane == kWave - 1) a_up = anx;
+                const float a_up = shift_from_next_lane(a[0], lane, anx);
 #pragma unroll
                 for (int i = 0; i < kItems; ++i) {
                     al[i] = (i + 1 < kItems) ? a[i + 1] : a_up;
@@ -417,14 +515,13 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
                 Pair ragg{al[kItems - 1], be[kItems - 1]};
 #pragma unroll
                 for (int i = kItems - 2; i >= 0; --i) ragg = then(ragg, Pair{al[i], be[i]});
-                const Pair rinc = wave_scan_rev(ragg, lane);
-                const float rt_a = readlane_f(rinc.a, 0), rt_b = readlane_f(rinc.b, 0);
+                Pair rexcl, rtot;
+                wave_scan_rev(ragg, lane, rexcl, rtot);
                 const float a_first = readlane_f(a[0], 0);
                 if constexpr (MODE == 2) {
                     if (lane == 0) {
                         const size_t wi = (((xrow0 + (size_t)r * p.n_chunks) + tile) * N + n) * 2;
-                        ws[wi] = rt_a;
-                        ws[wi + 1] = rt_b;
+                        *reinterpret_cast<float2 *>(ws + wi) = make_float2(rtot.a, rtot.b);
                     }
                     continue;
                 }
@@ -437,17 +534,14 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
                 Pair agg{a[0], bb[0]};
 #pragma unroll
                 for (int i = 1; i < kItems; ++i) agg = then(agg, Pair{a[i], bb[i]});
-                const Pair inc = wave_scan_fwd(agg, lane);
-                float ea = __shfl_up(inc.a, 1), eb = __shfl_up(inc.b, 1);
-                if (lane == 0) { ea = 1.f; eb = 0.f; }
-                float h = fmaf(ea, hin, eb);
+                Pair excl, tot;
+                wave_scan_fwd(agg, lane, excl, tot);
+                float h = fmaf(excl.a, hin, excl.b);
                 float hv[kItems];
 #pragma unroll
                 for (int i = 0; i < kItems; ++i) { h = fmaf(a[i], h, bb[i]); hv[i] = h; }
                 // adjoint recurrence inside the lane
-                float ra = __shfl_down(rinc.a, 1), rb = __shfl_down(rinc.b, 1);
-                if (lane == kWave - 1) { ra = 1.f; rb = 0.f; }
-                float gcur = fmaf(ra, gin, rb);  // g of the first step of the next lane
+                float gcur = fmaf(rexcl.a, gin, rexcl.b);  // adjoint of the first step of the next lane
 #pragma unroll
                 for (int i = kItems - 1; i >= 0; --i) {
                     gcur = fmaf(al[i], gcur, be[i]);
@@ -459,7 +553,7 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
                     dBv[i] = fmaf(gcur * dl[r][i], uv[r][i], dBv[i]);
                     dCv[i] = fmaf(dov[r][i], hv[i], dCv[i]);
                 }
-                const float gout = fmaf(rt_a, gin, rt_b);
+                const float gout = fmaf(rtot.a, gin, rtot.b);
                 if constexpr (DYN) {
                     // one (row, state) per iteration: flush dA now
                     const float s = wave_sum(accA[r]);
@@ -478,22 +572,29 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
                 // reduce dB/dC over the W waves (rows) of the workgroup, then leave as 256-B runs
                 const int tbase = tile * kTile;
                 if (W == 1) {
+                    if (VEC && t0 + 3 < L && geo.wg_per_group == 1) {
+                        *reinterpret_cast<float4 *>(dBg + (size_t)n * L + t0) = make_float4(dBv[0], dBv[1], dBv[2], dBv[3]);
+                        *reinterpret_cast<float4 *>(dCg + (size_t)n * L + t0) = make_float4(dCv[0], dCv[1], dCv[2], dCv[3]);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < kItems; ++i) {
-                        const int t = t0 + i;
-                        if (t < L) {
-                            if (geo.wg_per_group == 1) { dBg[(size_t)n * L + t] = dBv[i]; dCg[(size_t)n * L + t] = dCv[i]; }
-                            else { atomicAdd(dBg + (size_t)n * L + t, dBv[i]); atomicAdd(dCg + (size_t)n * L + t, dCv[i]); }
+                        for (int i = 0; i < kItems; ++i) {
+                            const int t = t0 + i;
+                            if (t < L) {
+                                if (geo.wg_per_group == 1) { dBg[(size_t)n * L + t] = dBv[i]; dCg[(size_t)n * L + t] = dCv[i]; }
+                                else { atomicAdd(dBg + (size_t)n * L + t, dBv[i]); atomicAdd(dCg + (size_t)n * L + t, dCv[i]); }
+                            }
                         }
                     }
                 } else {
-                    *reinterpret_cast<float4 *>(&s_red[0][wave][lane * kItems]) = make_float4(dBv[0], dBv[1], dBv[2], dBv[3]);
-                    *reinterpret_cast<float4 *>(&s_red[1][wave][lane * kItems]) = make_float4(dCv[0], dCv[1], dCv[2], dCv[3]);
+                    float *redB = s_red, *redC = s_red + W * kTile;
+                    *reinterpret_cast<float4 *>(redB + wave * kTile + lane * kItems) = make_float4(dBv[0], dBv[1], dBv[2], dBv[3]);
+                    *reinterpret_cast<float4 *>(redC + wave * kTile + lane * kItems) = make_float4(dCv[0], dCv[1], dCv[2], dCv[3]);
                     __syncthreads();
                     for (int e = threadIdx.x; e < 2 * kTile; e += blockDim.x) {
                         const int which = e / kTile, idx = e % kTile;
+                        const float *src = which ? redC : redB;
                         float s = 0.f;
-                        for (int w = 0; w < W; ++w) s += s_red[which][w][idx];
+                        for (int w = 0; w < W; ++w) s += src[w * kTile + idx];
                         const int t = tbase + idx;
                         if (t < L) {
                             float *dst = (which ? dCg : dBg) + (size_t)n * L + t;
@@ -507,17 +608,11 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
         if constexpr (MODE != 2) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (p.delta_softplus) {
-                    float raw[kItems];
-                    load4<T, VEC>(dl_row[r], t0, L, raw);
 #pragma unroll
-                    for (int i = 0; i < kItems; ++i) {
-                        const float v = raw[i] + bias[r];
-                        if (v <= 20.f) ddv[r][i] = ddv[r][i] / (1.f + __expf(-v));
-                    }
+                for (int i = 0; i < kItems; ++i) {
+                    ddv[r][i] *= sig[r][i];
+                    accBias[r] += (t0 + i < L) ? ddv[r][i] : 0.f;
                 }
-#pragma unroll
-                for (int i = 0; i < kItems; ++i) accBias[r] += (t0 + i < L) ? ddv[r][i] : 0.f;
                 store4<T, VEC>(du_row[r], t0, L, duv[r]);
                 store4<T, VEC>(dd_row[r], t0, L, ddv[r]);
             }
@@ -530,11 +625,41 @@ __global__ __launch_bounds__(256) void sscan_bwd_kernel(const vmasr_sscan_bwd_pa
             const float sA = DYN ? 0.f : wave_sum(accA[r]);
             const float sD = wave_sum(accD[r]), sB = wave_sum(accBias[r]);
             if (lane == 0) {
-                if (!DYN) atomicAdd(static_cast<float *>(q.dA_ptr) + d * q.dA_d_stride, sA);
-                if (q.dD_ptr) atomicAdd(static_cast<float *>(q.dD_ptr) + d, sD);
-                if (q.ddelta_bias_ptr) atomicAdd(static_cast<float *>(q.ddelta_bias_ptr) + d, sB);
+                if (!DYN && geo.part) {  // per-task partials, reduced by sscan_bwd_reduce_kernel
+                    float *pp = geo.part + (((size_t)b * p.dim + d) * geo.nseg + seg) * 3;
+                    pp[0] = sA; pp[1] = sD; pp[2] = sB;
+                } else {
+                    if (!DYN) atomicAdd(static_cast<float *>(q.dA_ptr) + d * q.dA_d_stride, sA);
+                    if (q.dD_ptr) atomicAdd(static_cast<float *>(q.dD_ptr) + d, sD);
+                    if (q.ddelta_bias_ptr) atomicAdd(static_cast<float *>(q.ddelta_bias_ptr) + d, sB);
+                }
             }
         }
+    }
+}
+
+// one wave per row d: sum the (batch, segment) partials of dA / dD / ddelta_bias
+__global__ __launch_bounds__(256) void sscan_bwd_reduce_kernel(const float *__restrict__ part, const int batch,
+                                                               const int dim, const int nseg, float *__restrict__ dA,
+                                                               const long dA_stride, float *__restrict__ dD,
+                                                               float *__restrict__ dbias) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d >= dim) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const float *pp = part + ((size_t)b * dim + d) * nseg * 3;
+        for (int s = lane; s < nseg; s += kWave) {
+            s0 += pp[s * 3 + 0];
+            s1 += pp[s * 3 + 1];
+            s2 += pp[s * 3 + 2];
+        }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        dA[d * dA_stride] += s0;  // caller zero-initialised; this launch is the only writer of row d
+        if (dD) dD[d] += s1;
+        if (dbias) dbias[d] += s2;
     }
 }
 
@@ -555,42 +680,53 @@ int validate(const vmasr_sscan_params &p) {
     return 0;
 }
 
-bool vec_ok(const vmasr_sscan_params &p, int esz, std::initializer_list<const void *> ptrs,
-            std::initializer_list<int64_t> strides) {
+bool vec_ok(int esz, std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> strides) {
     const size_t bytes = esz == 4 ? 16 : 8;
     for (const void *q : ptrs)
         if (q && !aligned_to(q, bytes)) return false;
     for (int64_t s : strides)
         if (s % 4 != 0) return false;
-    (void)p;
     return true;
 }
 
+// launch plan.  split: 0 walk, 1 tile-parallel 3-phase, 2 block (forward only; the backward of a
+// block-planned call uses the split path).
 struct Plan {
-    int R, split, tiles_per_task, nseg;
+    int R, split, tiles_per_task, nseg, W;
 };
 
-Plan make_plan(const vmasr_sscan_params &p, bool dyn) {
-    Plan pl;
+constexpr long kEnoughWaves = 2048;  // 2 waves per SIMD over 1024 SIMDs
+
+Plan make_plan(const vmasr_sscan_params &p, bool dyn, bool backward) {
+    Plan pl{1, 0, 1, 1, 1};
     const int rpg = p.dim / p.n_groups;
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
     int R = 1;
-    if (!dyn) {
-        // share B/C loads between rows while keeping enough waves in flight
-        const long waves1 = (long)p.batch * p.dim * (long)ntiles;  // upper bound on wave-tiles
-        if (rpg % 4 == 0 && waves1 / 4 >= 16384) R = 4;
-        else if (rpg % 2 == 0 && waves1 / 2 >= 8192) R = 2;
-        if (rpg == 2) R = 2;
-        if (g_tune_rows > 0 && rpg % g_tune_rows == 0 && (g_tune_rows == 1 || g_tune_rows == 2 || g_tune_rows == 4))
-            R = g_tune_rows;
-    }
+    // two-row groups (the 512x512 output block, KD = 8): one wave carries the whole group, so B/C are
+    // loaded once; elsewhere one row per wave measured faster (more waves beat the shared loads)
+    if (!dyn && !backward && rpg == 2) R = 2;
+    if (!dyn && g_tune_rows > 0 && rpg % g_tune_rows == 0 && (g_tune_rows == 1 || g_tune_rows == 2 || g_tune_rows == 4))
+        R = g_tune_rows;
     pl.R = R;
-    const long rows_tasks = (long)p.batch * (p.dim / R);
-    int split = (ntiles > 1 && rows_tasks < 2048) ? 1 : 0;
-    if (g_tune_split >= 0) split = (ntiles > 1) ? g_tune_split : 0;
-    pl.split = split;
-    pl.tiles_per_task = split ? 1 : ntiles;
-    pl.nseg = split ? ntiles : 1;
+    const long row_tasks = (long)p.batch * (p.dim / R);
+    int mode = 0;
+    if (ntiles > 1 && row_tasks < kEnoughWaves) {
+        const int W = ntiles < kMaxBlockWaves ? ntiles : kMaxBlockWaves;
+        mode = (!dyn && !backward && row_tasks * W >= kEnoughWaves) ? 2 : 1;
+    }
+    if (g_tune_split >= 0 && ntiles > 1) mode = (g_tune_split == 2 && (dyn || backward)) ? 1 : g_tune_split;
+    pl.split = mode;
+    if (mode == 1) {
+        // a few tiles per task once there are plenty of tasks (amortises the prologue)
+        int tpt = 1;
+        while (tpt < 8 && row_tasks * ((ntiles + 2 * tpt - 1) / (2 * tpt)) >= 4 * kEnoughWaves) tpt *= 2;
+        pl.tiles_per_task = tpt;
+        pl.nseg = (ntiles + tpt - 1) / tpt;
+    } else {
+        pl.tiles_per_task = ntiles;
+        pl.nseg = 1;
+        pl.W = mode == 2 ? (ntiles < kMaxBlockWaves ? ntiles : kMaxBlockWaves) : 1;
+    }
     return pl;
 }
 
@@ -599,23 +735,36 @@ int launch_fwd(const vmasr_sscan_params &p, const Plan &pl, hipStream_t st) {
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
     const long ntasks = (long)p.batch * (p.dim / R) * pl.nseg;
     const int nblocks = (int)((ntasks + 3) / 4);
+    const FwdGeom geo{pl.tiles_per_task, pl.nseg};
     // algorithmic bytes: read u, delta, B, C; write out
     const double es = sizeof(T), KD = p.dim, KN = (double)p.n_groups * p.dstate, BL = (double)p.batch * p.seqlen;
     const double full = (3 * KD + 2 * KN) * BL * es, agg = (2 * KD + KN) * BL * es;
     const double xb = (double)p.batch * p.dim * ntiles * p.dstate * 2 * 4 * 2;
-    if (!pl.split) {
-        VMASR_LAUNCH(VMASR_K_SSCAN_FWD, full, (sscan_fwd_kernel<T, R, DYN, VEC, 0>), dim3(nblocks), dim3(256), 0, st, p,
-                     pl.tiles_per_task, pl.nseg);
+    if (pl.split == 0) {
+        VMASR_LAUNCH(VMASR_K_SSCAN_FWD, full, (sscan_fwd_kernel<T, R, DYN, VEC, 0>), dim3(nblocks), dim3(256), 0, st, p, geo);
         return check_launch("sscan_fwd");
     }
-    VMASR_LAUNCH(VMASR_K_SSCAN_FWD_AGG, agg, (sscan_fwd_kernel<T, R, DYN, VEC, 2>), dim3(nblocks), dim3(256), 0, st, p,
-                 pl.tiles_per_task, pl.nseg);
+    if constexpr (!DYN) {
+        if (pl.split == 2) {
+            VMASR_LAUNCH(VMASR_K_SSCAN_FWD, full, (sscan_fwd_kernel<T, R, false, VEC, 3>), dim3(p.batch * (p.dim / R)),
+                         dim3(64 * pl.W), 0, st, p, geo);
+            return check_launch("sscan_fwd(block)");
+        }
+    }
+    VMASR_LAUNCH(VMASR_K_SSCAN_FWD_AGG, agg, (sscan_fwd_kernel<T, R, DYN, VEC, 2>), dim3(nblocks), dim3(256), 0, st, p, geo);
     const int nseq = p.batch * p.dim * p.dstate;
     VMASR_LAUNCH(VMASR_K_SSCAN_FWD_CARRY, xb, (sscan_carry_kernel<false>), dim3((nseq + 3) / 4), dim3(256), 0, st,
                  static_cast<float *>(p.x_ptr), nseq, ntiles, p.dstate);
-    VMASR_LAUNCH(VMASR_K_SSCAN_FWD_APPLY, full, (sscan_fwd_kernel<T, R, DYN, VEC, 1>), dim3(nblocks), dim3(256), 0, st, p,
-                 pl.tiles_per_task, pl.nseg);
+    VMASR_LAUNCH(VMASR_K_SSCAN_FWD_APPLY, full, (sscan_fwd_kernel<T, R, DYN, VEC, 1>), dim3(nblocks), dim3(256), 0, st, p, geo);
     return check_launch("sscan_fwd(split)");
+}
+
+size_t bwd_ws_floats(const vmasr_sscan_params &p, const Plan &pl) {
+    if (pl.split != 1) return 0;
+    const size_t ntiles = (p.seqlen + kTile - 1) / kTile;
+    size_t n = (size_t)p.batch * p.dim * ntiles * p.dstate * 2;  // reverse aggregates / adjoint carries
+    if (p.dstate == 1) n += (size_t)p.batch * p.dim * pl.nseg * 3;  // dA/dD/dbias partials
+    return n;
 }
 
 template <typename T, int R, bool DYN, bool VEC>
@@ -623,23 +772,38 @@ int launch_bwd(const vmasr_sscan_bwd_params &q, const Plan &pl, hipStream_t st) 
     const vmasr_sscan_params &p = q.f;
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
     const int rbg = (p.dim / p.n_groups) / R;  // row-blocks per group
-    int W = 4;
+    static const int env_w = [] { const char *e = getenv("VMASR_BWD_WAVES"); return e ? atoi(e) : 0; }();
+    int W = DYN ? 4 : (env_w > 0 ? env_w : 8);  // 8 measured best (2..16); general N keeps per-wave LDS state: 4
     while (rbg % W) W >>= 1;
-    BwdGeom geo{pl.tiles_per_task, pl.nseg, W, rbg / W};
+    BwdGeom geo{pl.tiles_per_task, pl.nseg, W, rbg / W, nullptr, 0};
     const long nblocks = (long)p.batch * pl.nseg * p.n_groups * geo.wg_per_group;
+    const size_t smem = W > 1 ? (size_t)2 * W * kTile * sizeof(float) : 0;
     // algorithmic bytes: read u, delta, dout, B, C; write du, ddelta, dB, dC (dB/dC fp32)
     const double es = sizeof(T), KD = p.dim, KN = (double)p.n_groups * p.dstate, BL = (double)p.batch * p.seqlen;
     const double full = (5 * KD * es + 2 * KN * es + 2 * KN * 4) * BL, agg = (2 * KD + KN) * BL * es;
     const double xb = (double)p.batch * p.dim * ntiles * p.dstate * 2 * 4 * 2;
-    if (!pl.split) {
-        VMASR_LAUNCH(VMASR_K_SSCAN_BWD, full, (sscan_bwd_kernel<T, R, DYN, VEC, 0>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
+    if (pl.split != 1) {
+        VMASR_LAUNCH(VMASR_K_SSCAN_BWD, full, (sscan_bwd_kernel<T, R, DYN, VEC, 0>), dim3((int)nblocks), dim3(64 * W), smem, st, q, geo);
         return check_launch("sscan_bwd");
     }
     VMASR_LAUNCH(VMASR_K_SSCAN_BWD_AGG, agg, (sscan_bwd_kernel<T, R, DYN, VEC, 2>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
-    const int nseq = p.batch * p.dim * p.dstate;
-    VMASR_LAUNCH(VMASR_K_SSCAN_BWD_CARRY, xb, (sscan_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st,
-                 static_cast<float *>(q.ws_ptr), nseq, ntiles, p.dstate);
-    VMASR_LAUNCH(VMASR_K_SSCAN_BWD_APPLY, full, (sscan_bwd_kernel<T, R, DYN, VEC, 1>), dim3((int)nblocks), dim3(64 * W), 0, st, q, geo);
+    // moderate tile counts: every apply task folds the aggregates to its right itself (one launch less);
+    // few segments: dA/dD/dbias leave as atomics (little contention) instead of partials + reduce
+    const bool fuse = !DYN && ntiles <= 256;
+    const bool partials = !DYN && (long)p.batch * pl.nseg > 64;
+    if (!fuse) {
+        const int nseq = p.batch * p.dim * p.dstate;
+        VMASR_LAUNCH(VMASR_K_SSCAN_BWD_CARRY, xb, (sscan_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st,
+                     static_cast<float *>(q.ws_ptr), nseq, ntiles, p.dstate);
+    }
+    geo.fused_carry = fuse;
+    if (partials) geo.part = static_cast<float *>(q.ws_ptr) + (size_t)p.batch * p.dim * ntiles * 2;
+    VMASR_LAUNCH(VMASR_K_SSCAN_BWD_APPLY, full, (sscan_bwd_kernel<T, R, DYN, VEC, 1>), dim3((int)nblocks), dim3(64 * W), smem, st, q, geo);
+    if (partials)
+        VMASR_LAUNCH(VMASR_K_SSCAN_BWD_CARRY, (double)p.batch * p.dim * pl.nseg * 12, sscan_bwd_reduce_kernel,
+                     dim3((p.dim + 3) / 4), dim3(256), 0, st, geo.part, p.batch, p.dim, pl.nseg,
+                     static_cast<float *>(q.dA_ptr), (long)q.dA_d_stride, static_cast<float *>(q.dD_ptr),
+                     static_cast<float *>(q.ddelta_bias_ptr));
     return check_launch("sscan_bwd(split)");
 }
 
@@ -684,11 +848,11 @@ VMASR_EXPORT int vmasr_sscan_fwd(const vmasr_sscan_params *pp, vmasr_stream_t st
     VMASR_REQUIRE(p.out_ptr, VMASR_EINVAL, "sscan_fwd: null out");
     const bool dyn = p.dstate != 1;
     const int esz = p.dtype == VMASR_F32 ? 4 : 2;
-    const bool vec = vec_ok(p, esz, {p.u_ptr, p.delta_ptr, p.B_ptr, p.C_ptr, p.out_ptr},
+    const bool vec = vec_ok(esz, {p.u_ptr, p.delta_ptr, p.B_ptr, p.C_ptr, p.out_ptr},
                             {p.u_batch_stride, p.u_d_stride, p.delta_batch_stride, p.delta_d_stride,
                              p.out_batch_stride, p.out_d_stride, p.B_batch_stride, p.B_group_stride,
                              p.B_dstate_stride, p.C_batch_stride, p.C_group_stride, p.C_dstate_stride});
-    const Plan pl = make_plan(p, dyn);
+    const Plan pl = make_plan(p, dyn, false);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (p.dtype) {
         case VMASR_F32: return dispatch_fwd<float>(p, pl, dyn, vec, st);
@@ -700,9 +864,8 @@ VMASR_EXPORT int vmasr_sscan_fwd(const vmasr_sscan_params *pp, vmasr_stream_t st
 VMASR_EXPORT size_t vmasr_sscan_bwd_workspace(const vmasr_sscan_bwd_params *q) {
     if (!q) return 0;
     const vmasr_sscan_params &p = q->f;
-    if (p.batch <= 0 || p.dim <= 0 || p.seqlen <= 0 || p.dstate <= 0) return 0;
-    const size_t ntiles = (p.seqlen + kTile - 1) / kTile;
-    return ntiles > 1 ? (size_t)p.batch * p.dim * ntiles * p.dstate * 2 * sizeof(float) : 0;
+    if (p.batch <= 0 || p.dim <= 0 || p.seqlen <= 0 || p.dstate <= 0 || p.n_groups <= 0 || p.dim % p.n_groups) return 0;
+    return bwd_ws_floats(p, make_plan(p, p.dstate != 1, true)) * sizeof(float);
 }
 
 VMASR_EXPORT int vmasr_sscan_bwd(const vmasr_sscan_bwd_params *qq, vmasr_stream_t stream) {
@@ -714,15 +877,16 @@ VMASR_EXPORT int vmasr_sscan_bwd(const vmasr_sscan_bwd_params *qq, vmasr_stream_
                   "sscan_bwd: null tensor");
     const bool dyn = p.dstate != 1;
     const int esz = p.dtype == VMASR_F32 ? 4 : 2;
-    const bool vec = vec_ok(p, esz, {p.u_ptr, p.delta_ptr, p.B_ptr, p.C_ptr, q.dout_ptr, q.du_ptr, q.ddelta_ptr},
+    const bool vec = vec_ok(esz, {p.u_ptr, p.delta_ptr, p.B_ptr, p.C_ptr, q.dout_ptr, q.du_ptr, q.ddelta_ptr, q.dB_ptr, q.dC_ptr},
                             {p.u_batch_stride, p.u_d_stride, p.delta_batch_stride, p.delta_d_stride,
                              q.dout_batch_stride, q.dout_d_stride, q.du_batch_stride, q.du_d_stride,
                              q.ddelta_batch_stride, q.ddelta_d_stride, p.B_batch_stride, p.B_group_stride,
-                             p.B_dstate_stride, p.C_batch_stride, p.C_group_stride, p.C_dstate_stride});
-    const Plan pl = make_plan(p, dyn);
-    if (pl.split)
-        VMASR_REQUIRE(q.ws_ptr && q.ws_bytes >= vmasr_sscan_bwd_workspace(qq), VMASR_ENOSPACE,
-                      "sscan_bwd: workspace too small (%zu < %zu)", q.ws_bytes, vmasr_sscan_bwd_workspace(qq));
+                             p.B_dstate_stride, p.C_batch_stride, p.C_group_stride, p.C_dstate_stride, (int64_t)p.seqlen});
+    const Plan pl = make_plan(p, dyn, true);
+    const size_t need = bwd_ws_floats(p, pl) * sizeof(float);
+    if (need)
+        VMASR_REQUIRE(q.ws_ptr && q.ws_bytes >= need, VMASR_ENOSPACE, "sscan_bwd: workspace too small (%zu < %zu)",
+                      q.ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (p.dtype) {
         case VMASR_F32: return dispatch_bwd<float>(q, pl, dyn, vec, st);
