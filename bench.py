@@ -51,7 +51,7 @@ def make_config(workload, batch):
     return update_config(c)
 
 
-def build_trainer(config, device, amp=True):
+def build_trainer(config, device, amp=True, capturable=False):
     import vm_asr_amd
     from vm_asr_amd.trainer import Trainer, build_optimizer
     torch.manual_seed(config.SEED)
@@ -59,10 +59,10 @@ def build_trainer(config, device, amp=True):
     gan = config.TRAIN.ADVERSARIAL.ENABLE
     for m in models.values():
         m.to(device)
-    opts = {"generator": build_optimizer(config, models["generator"])}
+    opts = {"generator": build_optimizer(config, models["generator"], capturable)}
     if gan:
-        opts["discriminator"] = build_optimizer(config, [models["mpd"]])
-    return Trainer(models, [], opts, config, device, None, None, {}, amp=amp, gan=gan, len_epoch=0)
+        opts["discriminator"] = build_optimizer(config, [models["mpd"]], capturable)
+    return Trainer(models, [], opts, config, device, None, None, {}, amp=amp, gan=gan, len_epoch=0, dp_mode="flat")
 
 
 def synth_batch(config, device, rank):
@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-amp", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     args = ap.parse_args()
 
     from vm_asr_amd import _lib
@@ -119,17 +120,17 @@ def main():
     torch.cuda.set_device(device)
 
     config = make_config(args.workload, args.batch)
-    trainer = build_trainer(config, device, amp=not args.no_amp)
+    trainer = build_trainer(config, device, amp=not args.no_amp, capturable=not args.no_graphs)
     for m in trainer.models.values():
         m.train()
+    torch.manual_seed(config.SEED + 1 + rank)  # per-rank DropPath streams
     batch = synth_batch(config, device, rank)
 
+    graphed = False
+    if not args.no_graphs:
+        graphed = trainer.enable_graphs(batch, warmup=max(2, min(3, args.warmup)))
     for _ in range(args.warmup):
         trainer.train_step(*batch)
-    timing = not args.no_kernel_timing
-    if timing:
-        _lib.prof_reset()
-        _lib.prof_enable(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -140,12 +141,24 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if timing:
-        _lib.prof_enable(False)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+
+    # per-kernel device time: HIP events recorded by the library around each of its launches, on the
+    # launch stream.  Events cannot be read inside a replayed graph, so this is a second pass of the
+    # same K steps, executed eagerly right after the timed region (rank 0's numbers are reported).
+    timing = not args.no_kernel_timing
+    if timing:
+        g_saved, trainer._graphed = trainer._graphed, None
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        for _ in range(args.steps):
+            trainer.train_step(*batch)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        trainer._graphed = g_saved
 
     B = config.DATA.BATCH_SIZE
     out = {
@@ -156,7 +169,9 @@ def main():
         "config": {"workload": f"{args.workload}.yaml full train step (G fwd+bwd, "
                                f"{'MR-STFT+LSGAN+feature losses, MPD fwd+bwd, ' if config.TRAIN.ADVERSARIAL.ENABLE else 'MR-STFT loss, '}"
                                f"AdamW); DIMS 16, d_state 1, clip 122640 @48 kHz, n_fft 1024 hop 240",
-                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world} (clip-sharded, DDP/RCCL)"},
+                   "per_gpu_batch": B, "global_batch": B * world,
+                   "parallelism": f"dp{world} (clip-sharded; one RCCL all-reduce per flat gradient buffer)",
+                   "execution": "HIP graph replay (fwd+bwd graph, optimiser graph)" if graphed else "eager"},
     }
     if rank == 0 and timing:
         prof = _lib.prof_collect()
@@ -172,6 +187,7 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": d["gbs"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"],
+                "timed_in": "eager pass of the same K steps right after the timed region (HIP events on the launch stream)",
                 "launches": d["launches"], "alg_bytes_per_launch": d["alg_bytes"] / d["launches"],
                 "selective_scan_op": {"achieved": op_bytes / (op_ms * 1e-3) / 1e9, "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "ms_per_step": op_ms / args.steps, "alg_bytes_per_step": op_bytes / args.steps},

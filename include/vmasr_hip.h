@@ -12,6 +12,7 @@
  *   vmasr_cross_merge    CrossMergeTriton.forward / CrossScanTriton.backward   model/csm_triton.py:340-366 (kernel :82-154), model/vmamba.py:50-73
  *   vmasr_dwconv_silu_*  SS2D.conv2d + act (depthwise 3x3, pad 1)               model/vmamba.py:859-868,1543-1545
  *   vmasr_stft           wav2spectro                                            utils/stft.py:22-68
+ *   vmasr_stft_bwd       autograd of torch.stft in the MR-STFT loss             model/loss.py:17-45
  *   vmasr_istft(_bwd)    spectro2wav (+ its autograd)                           utils/stft.py:71-115
  *
  * All functions are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
@@ -122,6 +123,13 @@ int vmasr_dwconv_silu_bwd(const void *x, const float *w, const float *bias, cons
 int vmasr_stft(const float *wav, float *out0, float *out1, int32_t B, int32_t T, int32_t n_fft,
                int32_t hop, int32_t win, int32_t normalized, int32_t logmag,
                vmasr_stream_t stream);
+/* gradient of vmasr_stft(..., logmag=0) wrt the wave: (gRe, gIm) (B,F,M) -> gwav (B,T).  Needed by
+ * the multi-resolution STFT loss (model/loss.py:17-45 differentiates torch.stft).  ws: scratch of
+ * vmasr_stft_bwd_workspace() bytes. */
+size_t vmasr_stft_bwd_workspace(int32_t B, int32_t T, int32_t n_fft, int32_t hop);
+int vmasr_stft_bwd(const float *gre, const float *gim, float *gwav, int32_t B, int32_t T, int32_t n_fft,
+                   int32_t hop, int32_t win, int32_t normalized, void *ws, size_t ws_bytes,
+                   vmasr_stream_t stream);
 /* mag,phase (B,F,M) fp32 -> wav (B, hop*(M-1)) fp32; n_fft = 2F-2, normalized=True,
  * center=True.  ws: scratch of vmasr_istft_workspace() bytes. */
 size_t vmasr_istft_workspace(int32_t B, int32_t F, int32_t M, int32_t hop);

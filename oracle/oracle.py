@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(_HERE, "libvmasr_oracle.so")
 _lib = None
 
 __all__ = ["build", "lib", "num_threads", "sscan_fwd", "sscan_bwd", "cross_scan", "cross_merge",
-           "dwconv_silu_fwd", "dwconv_silu_bwd", "stft", "istft", "istft_bwd", "lsd", "snr"]
+           "dwconv_silu_fwd", "dwconv_silu_bwd", "stft", "stft_bwd", "istft", "istft_bwd", "lsd", "snr"]
 
 
 def build(force=False):
@@ -127,6 +127,16 @@ def stft(wav, n_fft, hop, win, normalized=True, logmag=True):
     lib().vmasr_oracle_stft(_p(w2), w2.shape[0], T, n_fft, hop, win, int(normalized), int(logmag),
                             _p(o0), _p(o1))
     return o0.reshape(*lead, F, M), o1.reshape(*lead, F, M)
+
+
+def stft_bwd(gre, gim, T, n_fft, hop, win, normalized=False):
+    """adjoint of stft(..., logmag=False): (gre, gim) (..., F, M) -> gwav (..., T)."""
+    gre, gim = _f(gre), _f(gim)
+    lead, (F, M) = gre.shape[:-2], gre.shape[-2:]
+    g0, g1 = gre.reshape(-1, F, M), gim.reshape(-1, F, M)
+    gw = np.empty((g0.shape[0], T), np.float32)
+    lib().vmasr_oracle_stft_bwd(_p(g0), _p(g1), g0.shape[0], T, n_fft, hop, win, int(normalized), _p(gw))
+    return gw.reshape(*lead, T)
 
 
 def istft(mag, phase, hop, win):

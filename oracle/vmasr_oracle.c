@@ -469,3 +469,36 @@ VMASR_API void vmasr_oracle_istft_bwd(const float *mag, const float *phase, cons
     }
     free(wnd); free(env);
 }
+
+/* ------------------------------------------------------------------------------------
+ * Gradient of vmasr_oracle_stft(..., logmag=0) wrt the wave: the adjoint of
+ * reflect-pad -> frame -> window -> one-sided DFT (what autograd does for torch.stft in the
+ * MR-STFT loss, model/loss.py:17-45).  gre,gim (B,F,M) -> gwav (B,T).
+ * ---------------------------------------------------------------------------------- */
+VMASR_API void vmasr_oracle_stft_bwd(const float *gre, const float *gim, int Bn, int T, int n_fft,
+                                     int hop, int win, int normalized, float *gwav) {
+    const int F = n_fft / 2 + 1, M = 1 + T / hop, pad = n_fft / 2;
+    double *wnd = (double *)malloc(sizeof(double) * n_fft);
+    make_window(wnd, n_fft, win);
+    const double scale = normalized ? 1.0 / sqrt((double)n_fft) : 1.0;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < Bn; ++b) {
+        double *re = (double *)malloc(sizeof(double) * n_fft);
+        double *im = (double *)malloc(sizeof(double) * n_fft);
+        double *acc = (double *)calloc((size_t)T, sizeof(double));
+        for (int m = 0; m < M; ++m) {
+            /* x_n = sum_f [gRe_f cos(2 pi f n / N) - gIm_f sin(...)] = Re(sum_f G_f e^{+i theta}) */
+            for (int f = 0; f < n_fft; ++f) { re[f] = 0.0; im[f] = 0.0; }
+            for (int f = 0; f < F; ++f) {
+                const size_t o = ((size_t)b * F + f) * M + m;
+                re[f] = gre[o]; im[f] = gim[o];
+            }
+            fft_inplace(re, im, n_fft, 1);
+            for (int n = 0; n < n_fft; ++n)
+                acc[reflect_idx(m * hop + n - pad, T)] += wnd[n] * re[n] * scale;
+        }
+        for (int t = 0; t < T; ++t) gwav[(size_t)b * T + t] = (float)acc[t];
+        free(re); free(im); free(acc);
+    }
+    free(wnd);
+}

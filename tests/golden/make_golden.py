@@ -13,6 +13,7 @@ Fixture families:
   stft.npz        wav2spectro / spectro2wav                (utils/stft.py:22-115)
   model_tiny.npz  DualStreamInteractiveMambaUNet dims=8, n_fft=128 fwd + grads + LSD
   metric.npz      LSD / SNR / LSD-HF / LSD-LF on fixed pairs (model/metric.py)
+  loss.npz        MultiResolutionSTFTLoss values + d/dx (model/loss.py:137-184)
 """
 import os
 import sys
@@ -277,6 +278,22 @@ def gen_model(ns):
     save("model_tiny.npz", **out)
 
 
+def gen_loss(ns):
+    """MultiResolutionSTFTLoss (model/loss.py:137-184) values and d/dx on a fixed pair."""
+    g = torch.Generator().manual_seed(6)
+    x = (0.1 * torch.randn(2, 6000, generator=g)).requires_grad_()
+    y = 0.1 * torch.randn(2, 6000, generator=g)
+    out = {}
+    for tag, emph in (("plain", False), ("emph", True)):
+        L = ns.loss.MultiResolutionSTFTLoss(factor_sc=0.5, factor_mag=0.5, emphasize_high_freq=emph)
+        x.grad = None
+        sc, mag = L(x, y)
+        (sc + mag).backward()
+        out.update({f"{tag}_sc": np.array(sc.item()), f"{tag}_mag": np.array(mag.item()), f"{tag}_dx": _np(x.grad)})
+    out.update(x=_np(x), y=_np(y))
+    save("loss.npz", **out)
+
+
 def gen_metric(ns):
     out = {}
     g = torch.Generator().manual_seed(5)
@@ -291,7 +308,7 @@ def gen_metric(ns):
 
 if __name__ == "__main__":
     ns = load_reference()
-    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric"]
+    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"](ns)

@@ -31,7 +31,7 @@ def _tiny_config(gan=True, batch=2):
     return update_config(c)
 
 
-def _make_trainer(cfg):
+def _make_trainer(cfg, dp_mode="flat"):
     import vm_asr_amd
     from oracle.torch_backend import use_oracle
     from vm_asr_amd.trainer import Trainer, build_optimizer
@@ -42,7 +42,7 @@ def _make_trainer(cfg):
     if cfg.TRAIN.ADVERSARIAL.ENABLE:
         opts["discriminator"] = build_optimizer(cfg, [models["mpd"]])
     return Trainer(models, [], opts, cfg, torch.device("cpu"), None, None, {}, amp=False,
-                   gan=cfg.TRAIN.ADVERSARIAL.ENABLE, len_epoch=0)
+                   gan=cfg.TRAIN.ADVERSARIAL.ENABLE, len_epoch=0, dp_mode=dp_mode)
 
 
 def _batch(cfg, n, seed=0):
@@ -77,7 +77,7 @@ def test_train_step_cpu_oracle_backend():
     assert any(not torch.equal(d_before[k], v) for k, v in unwrap(tr.models["mpd"]).state_dict().items())
 
 
-def _ddp_worker(rank, world, port, ret):
+def _ddp_worker(rank, world, port, ret, mode):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -86,7 +86,7 @@ def _ddp_worker(rank, world, port, ret):
     from vm_asr_amd.trainer import init_distributed, unwrap
     init_distributed()
     cfg = _tiny_config(gan=True, batch=1)
-    tr = _make_trainer(cfg)
+    tr = _make_trainer(cfg, dp_mode=mode)
     for m in tr.models.values():
         m.train()
     full = _batch(cfg, 2, seed=5)
@@ -99,13 +99,14 @@ def _ddp_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_ddp_gloo_world2_matches_single_process():
+@pytest.mark.parametrize("mode", ["flat", "ddp"])
+def test_ddp_gloo_world2_matches_single_process(mode):
     from oracle.torch_backend import oracle_stft_patch
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, ret)) for r in range(2)]
+    port = 29500 + (os.getpid() + (7 if mode == "ddp" else 0)) % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, ret, mode)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -114,6 +115,8 @@ def test_ddp_gloo_world2_matches_single_process():
     sd0, sd1 = ret[0], ret[1]
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), f"ranks diverged on {k}"
+    if mode == "ddp":
+        return
     # single process, batch of both clips: DDP averages gradients of per-rank mean losses, which equals
     # the gradient of the mean over the global batch for the losses that are batch means; the
     # spectral-convergence term is a ratio of norms over the batch (not a mean), so compare loosely.

@@ -61,6 +61,8 @@ SYMBOLS = {
     "vmasr_dwconv_silu_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                              c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_stft": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_stft_bwd_workspace": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "vmasr_stft_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "vmasr_istft_workspace": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "vmasr_istft": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "vmasr_istft_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -186,36 +186,48 @@ __global__ __launch_bounds__(256) void stft_like_kernel(const float *__restrict_
     }
 }
 
-// KIND 1 (spectro2wav, stage 1): windowed time frames -> frames (B, M, n)
+// Stage 1 of an inverse transform: one-sided spectra -> windowed time frames (B, M, n).
+//   SRC 0 (spectro2wav):   X = exp2(mag) e^{i phase};  c2r irfft, normalized=True undone
+//   SRC 1 (STFT adjoint):  X = (gRe + i gIm) weighted 1/2 on interior bins (the adjoint of a real->
+//                          one-sided transform), no 1/n; `normalized` multiplies by 1/sqrt(n)
+template <int SRC>
 __global__ __launch_bounds__(256) void istft_frames_kernel(const float *__restrict__ mag,
                                                            const float *__restrict__ phase,
                                                            float *__restrict__ frames, const int n, const int win,
-                                                           const int M) {
+                                                           const int M, const int normalized) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FftSmem s = carve(smem, n, false);
     const int F = n / 2 + 1;
     const int b = blockIdx.y, m0 = blockIdx.x * kFR;
     setup_tables(s, n, win);
     __syncthreads();
-    const float scale = sqrtf((float)n) / (float)n;  // undo normalized=True, then irfft 1/n
+    // SRC 0: undo normalized=True, then irfft 1/n.  SRC 1: plain adjoint (optionally normalized)
+    const float scale = SRC == 0 ? sqrtf((float)n) / (float)n : (normalized ? rsqrtf((float)n) : 1.f);
     for (int pr = 0; pr < kFR; pr += 2) {
         const int ma = m0 + pr, mb = ma + 1;
         if (ma >= M) break;
         for (int f = threadIdx.x; f < F; f += blockDim.x) {
             float2 xa = make_float2(0.f, 0.f), xb = make_float2(0.f, 0.f);
-            {
-                const size_t o = ((size_t)b * F + f) * M + ma;
-                const float a = exp2f(mag[o]);
-                float sn, c;
-                sincosf(phase[o], &sn, &c);
-                xa = make_float2(a * c, a * sn);
-            }
-            if (mb < M) {
-                const size_t o = ((size_t)b * F + f) * M + mb;
-                const float a = exp2f(mag[o]);
-                float sn, c;
-                sincosf(phase[o], &sn, &c);
-                xb = make_float2(a * c, a * sn);
+            if constexpr (SRC == 0) {
+                {
+                    const size_t o = ((size_t)b * F + f) * M + ma;
+                    const float a = exp2f(mag[o]);
+                    float sn, c;
+                    sincosf(phase[o], &sn, &c);
+                    xa = make_float2(a * c, a * sn);
+                }
+                if (mb < M) {
+                    const size_t o = ((size_t)b * F + f) * M + mb;
+                    const float a = exp2f(mag[o]);
+                    float sn, c;
+                    sincosf(phase[o], &sn, &c);
+                    xb = make_float2(a * c, a * sn);
+                }
+            } else {
+                const float wgt = (f == 0 || f == F - 1) ? 1.f : 0.5f;
+                const size_t oa = ((size_t)b * F + f) * M + ma;
+                xa = make_float2(wgt * mag[oa], wgt * phase[oa]);
+                if (mb < M) xb = make_float2(wgt * mag[oa + 1], wgt * phase[oa + 1]);
             }
             if (f == 0 || f == F - 1) { xa.y = 0.f; xb.y = 0.f; }  // c2r ignores imag of DC / Nyquist
             // Z = X_a + i X_b ;  Z[n-f] = conj(X_a[f]) + i conj(X_b[f])
@@ -237,23 +249,42 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float *__restri
 
 // stage 2: overlap-add the <= ceil(n/hop) frames that cover each sample, divide by the
 // window-square envelope, trim n/2 (center=True).  Gather form: deterministic, no atomics.
+__device__ __forceinline__ float ola_at(const float *__restrict__ frames, int b, int p, int n, int hop, int M) {
+    const int m_hi = min(M - 1, p / hop);
+    const int m_lo = max(0, (p - n + hop) / hop);
+    float acc = 0.f;
+    for (int m = m_lo; m <= m_hi; ++m) acc += frames[((size_t)b * M + m) * n + (p - m * hop)];
+    return acc;
+}
+
+// FOLD 0 (istft): overlap-add / window-square envelope, trim n/2.
+// FOLD 1 (STFT adjoint): overlap-add, then fold the reflect padding back onto the signal
+//        (x_pad[i] = x[reflect(i - n/2)]: sample t also collects padded positions n/2 - t and
+//        n/2 + 2(T-1) - t when they exist).
+template <int FOLD>
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float *__restrict__ frames, float *__restrict__ wav,
                                                         const int n, const int hop, const int win, const int M,
                                                         const int T) {
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const int p = t + n / 2;
-    const int m_hi = min(M - 1, p / hop);
-    const int m_lo = max(0, (p - n + hop) / hop);
-    float acc = 0.f, env = 0.f;
-    for (int m = m_lo; m <= m_hi; ++m) {
-        const int i = p - m * hop;
-        acc += frames[((size_t)b * M + m) * n + i];
-        const float w = hann_at(i, n, win);
-        env = fmaf(w, w, env);
+    const int pad = n / 2;
+    const int p = t + pad;
+    if constexpr (FOLD == 0) {
+        const int m_hi = min(M - 1, p / hop);
+        const int m_lo = max(0, (p - n + hop) / hop);
+        float env = 0.f;
+        for (int m = m_lo; m <= m_hi; ++m) {
+            const float w = hann_at(p - m * hop, n, win);
+            env = fmaf(w, w, env);
+        }
+        wav[(size_t)b * T + t] = ola_at(frames, b, p, n, hop, M) / env;
+    } else {
+        float acc = ola_at(frames, b, p, n, hop, M);
+        if (t >= 1 && t <= pad) acc += ola_at(frames, b, pad - t, n, hop, M);
+        if (t <= T - 2 && t >= T - 1 - pad) acc += ola_at(frames, b, pad + 2 * (T - 1) - t, n, hop, M);
+        wav[(size_t)b * T + t] = acc;
     }
-    wav[(size_t)b * T + t] = acc / env;
 }
 
 int check_fft(int n, int hop, int win, const char *what) {
@@ -263,16 +294,20 @@ int check_fft(int n, int hop, int win, const char *what) {
     return 0;
 }
 
+// Raise the dynamic-LDS limit of `kernel` once, to the largest size this library ever asks for
+// (n_fft 2048 with staged outputs).  Done on first use only: hipFuncSetAttribute is not a stream
+// operation and is refused while a stream is capturing, so it must not run inside a HIP graph.
 template <typename K>
-int allow_smem(K kernel, size_t bytes, const char *what) {
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) {
-            set_error("%s: cannot reserve %zu B of LDS: %s", what, bytes, hipGetErrorString(e));
-            return (int)e;
-        }
+int allow_smem(K kernel, size_t bytes, const char *what, bool *done) {
+    if (*done || bytes <= 64 * 1024) return 0;
+    const size_t cap = smem_bytes(2048, true);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+    if (e != hipSuccess) {
+        set_error("%s: cannot reserve %zu B of LDS: %s", what, cap, hipGetErrorString(e));
+        return (int)e;
     }
+    *done = true;
     return 0;
 }
 
@@ -289,7 +324,8 @@ VMASR_EXPORT int vmasr_stft(const float *wav, float *out0, float *out1, int32_t 
                   "stft: need 0 < B <= 65535 and T > n_fft/2 (reflect padding)");
     const int M = 1 + T / hop;
     const size_t sm = smem_bytes(n_fft, true);
-    if (int e = allow_smem(stft_like_kernel<0>, sm, "stft")) return e;
+    static bool smem_ok = false;
+    if (int e = allow_smem(stft_like_kernel<0>, sm, "stft", &smem_ok)) return e;
     const double bytes = (double)B * (T * 4.0 + 2.0 * (n_fft / 2 + 1) * M * 4.0);  // read wave, write 2 planes
     VMASR_LAUNCH(VMASR_K_STFT, bytes, stft_like_kernel<0>, dim3((M + kFR - 1) / kFR, B), dim3(256), sm,
                        static_cast<hipStream_t>(stream), wav, nullptr, nullptr, out0, out1, T, n_fft, hop, win, M,
@@ -314,9 +350,9 @@ VMASR_EXPORT int vmasr_istft(const float *mag, const float *phase, float *wav, i
     const size_t sm = smem_bytes(n, false);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double fbytes = (double)B * M * n * 4.0;
-    VMASR_LAUNCH(VMASR_K_ISTFT_FRAMES, 2.0 * B * F * M * 4.0 + fbytes, istft_frames_kernel, dim3((M + kFR - 1) / kFR, B), dim3(256), sm, st, mag, phase,
-                       static_cast<float *>(ws), n, win, M);
-    VMASR_LAUNCH(VMASR_K_ISTFT_OLA, fbytes + (double)B * T * 4.0, istft_ola_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, static_cast<const float *>(ws),
+    VMASR_LAUNCH(VMASR_K_ISTFT_FRAMES, 2.0 * B * F * M * 4.0 + fbytes, istft_frames_kernel<0>, dim3((M + kFR - 1) / kFR, B), dim3(256), sm, st, mag, phase,
+                       static_cast<float *>(ws), n, win, M, 1);
+    VMASR_LAUNCH(VMASR_K_ISTFT_OLA, fbytes + (double)B * T * 4.0, istft_ola_kernel<0>, dim3((T + 255) / 256, B), dim3(256), 0, st, static_cast<const float *>(ws),
                        wav, n, hop, win, M, T);
     return check_launch("istft");
 }
@@ -329,9 +365,35 @@ VMASR_EXPORT int vmasr_istft_bwd(const float *mag, const float *phase, const flo
     VMASR_REQUIRE(B > 0 && B <= 65535 && M > 1, VMASR_EINVAL, "istft_bwd: need 0 < B <= 65535 and at least 2 frames");
     const int T = hop * (M - 1);
     const size_t sm = smem_bytes(n, true);
-    if (int e = allow_smem(stft_like_kernel<2>, sm, "istft_bwd")) return e;
+    static bool smem_ok = false;
+    if (int e = allow_smem(stft_like_kernel<2>, sm, "istft_bwd", &smem_ok)) return e;
     const double bytes = (double)B * (T * 4.0 + 4.0 * F * M * 4.0);  // read g, mag, phase; write dmag, dphase
     VMASR_LAUNCH(VMASR_K_ISTFT_BWD, bytes, stft_like_kernel<2>, dim3((M + kFR - 1) / kFR, B), dim3(256), sm,
                        static_cast<hipStream_t>(stream), g, mag, phase, dmag, dphase, T, n, hop, win, M, 1, 0);
     return check_launch("istft_bwd");
+}
+
+VMASR_EXPORT size_t vmasr_stft_bwd_workspace(int32_t B, int32_t T, int32_t n_fft, int32_t hop) {
+    if (B <= 0 || T <= 0 || n_fft <= 0 || hop <= 0) return 0;
+    return (size_t)B * (1 + T / hop) * n_fft * sizeof(float);
+}
+
+VMASR_EXPORT int vmasr_stft_bwd(const float *gre, const float *gim, float *gwav, int32_t B, int32_t T, int32_t n_fft,
+                                int32_t hop, int32_t win, int32_t normalized, void *ws, size_t ws_bytes,
+                                vmasr_stream_t stream) {
+    if (int e = check_fft(n_fft, hop, win, "stft_bwd")) return e;
+    VMASR_REQUIRE(gre && gim && gwav, VMASR_EINVAL, "stft_bwd: null tensor");
+    VMASR_REQUIRE(B > 0 && B <= 65535 && T > n_fft / 2, VMASR_EINVAL,
+                  "stft_bwd: need 0 < B <= 65535 and T > n_fft/2 (reflect padding)");
+    VMASR_REQUIRE(ws && ws_bytes >= vmasr_stft_bwd_workspace(B, T, n_fft, hop), VMASR_ENOSPACE,
+                  "stft_bwd: workspace too small");
+    const int M = 1 + T / hop, F = n_fft / 2 + 1;
+    const size_t sm = smem_bytes(n_fft, false);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double fbytes = (double)B * M * n_fft * 4.0;
+    VMASR_LAUNCH(VMASR_K_ISTFT_FRAMES, 2.0 * B * F * M * 4.0 + fbytes, istft_frames_kernel<1>, dim3((M + kFR - 1) / kFR, B),
+                 dim3(256), sm, st, gre, gim, static_cast<float *>(ws), n_fft, win, M, normalized);
+    VMASR_LAUNCH(VMASR_K_ISTFT_OLA, fbytes + (double)B * T * 4.0, istft_ola_kernel<1>, dim3((T + 255) / 256, B), dim3(256),
+                 0, st, static_cast<const float *>(ws), gwav, n_fft, hop, win, M, T);
+    return check_launch("stft_bwd");
 }

@@ -2,11 +2,15 @@
 
 Re-statement of model/loss.py: multi-resolution STFT loss (:17-184; resolutions fft
 1024/2048/512, hop 120/240/50, win 600/1200/240 :142-144) and the HiFi-GAN style
-LSGAN / WGAN(-GP) / feature-matching losses (:188-260).  These need d/dx of an STFT, so
-they use torch.stft (hipFFT) rather than the forward-only HIP front-end.
+LSGAN / WGAN(-GP) / feature-matching losses (:188-260).  The STFTs (6 per step, 3 of them
+differentiated) run on the HIP front-end (`stft_reim`: vmasr_stft + vmasr_stft_bwd) instead of
+torch.stft — same arithmetic, and unlike rocFFT it can be captured in a HIP graph.  Only the
+reference's window ("hann_window") is supported.
 """
 import torch
 import torch.nn.functional as F
+
+from . import stft as _stft
 
 __all__ = ["mae_loss", "mse_loss", "stft_magnitude", "STFTLoss", "MultiResolutionSTFTLoss", "HiFiGANLoss"]
 
@@ -21,8 +25,8 @@ def mse_loss(output, target):
 
 def stft_magnitude(x, fft_size, hop_size, win_length, window, emphasize_high_freq=False):
     """(B,T) -> (B, frames, fft_size//2+1); sqrt(clamp(re^2+im^2, 1e-7))."""
-    s = torch.stft(x.float(), fft_size, hop_size, win_length, window=window, return_complex=True)
-    mag = torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=1e-7)).transpose(2, 1)
+    re, im = _stft.stft_reim(x.float(), fft_size, hop_size, win_length)  # window: periodic hann(win_length)
+    mag = torch.sqrt(torch.clamp(re ** 2 + im ** 2, min=1e-7)).transpose(2, 1)
     if emphasize_high_freq:
         # sic: the reference scales along dim 1 of the (B, frames, bins) tensor (model/loss.py:40-43)
         mag = mag * torch.linspace(1.0, 2.0, mag.size(1), device=x.device).view(1, -1, 1)
@@ -34,12 +38,15 @@ class STFTLoss(torch.nn.Module):
         super().__init__()
         self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
         self.emphasize_high_freq = emphasize_high_freq
-        self.register_buffer("window", getattr(torch, window)(win_length))
+        if window != "hann_window":
+            raise NotImplementedError("only window='hann_window' (the reference's choice) is built")
+        self.register_buffer("window", getattr(torch, window)(win_length))  # kept for state_dict parity
 
     def forward(self, x, y):
-        w = self.window.to(x.device)
-        x_mag = stft_magnitude(x, self.fft_size, self.shift_size, self.win_length, w, self.emphasize_high_freq)
-        y_mag = stft_magnitude(y, self.fft_size, self.shift_size, self.win_length, w, self.emphasize_high_freq)
+        # (the reference moves its window buffer to x.device on every call — a host->device copy per
+        # step; the HIP front-end builds the window in-kernel, so nothing is copied here)
+        x_mag = stft_magnitude(x, self.fft_size, self.shift_size, self.win_length, None, self.emphasize_high_freq)
+        y_mag = stft_magnitude(y, self.fft_size, self.shift_size, self.win_length, None, self.emphasize_high_freq)
         sc = torch.norm(y_mag - x_mag, p="fro") / torch.norm(y_mag, p="fro")
         mag = F.l1_loss(torch.log(y_mag), torch.log(x_mag))
         return sc, mag

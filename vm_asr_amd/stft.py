@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["wav2spectro", "spectro2wav", "stft_complex", "ISTFTFunction"]
+__all__ = ["wav2spectro", "spectro2wav", "stft_complex", "stft_reim", "ISTFTFunction", "STFTReImFunction"]
 
 
 def _p(t):
@@ -52,6 +52,42 @@ def wav2spectro(waveform: torch.Tensor, n_fft: int, hop_length: int, win_length:
 def stft_complex(waveform, n_fft, hop_length, win_length, normalized=False):
     """(re, im) of torch.stft(center=True, window=hann(win_length)) — used by loss/metrics."""
     return _stft(waveform, n_fft, hop_length, win_length, normalized, False)
+
+
+class STFTReImFunction(torch.autograd.Function):
+    """Differentiable (re, im) of torch.stft(center=True, window=hann(win_length)) for the losses:
+    forward = vmasr_stft(logmag=0), backward = vmasr_stft_bwd.  Unlike torch.stft (rocFFT) both
+    directions are plain kernel launches and therefore HIP-graph capturable."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, wave, n_fft, hop, win, normalized):
+        if not wave.is_cuda:
+            raise RuntimeError("stft_reim: expected a CUDA (HIP) tensor; vm_asr_amd has no CPU path")
+        ctx.cfg = (wave.shape, n_fft, hop, win, bool(normalized))
+        return _stft(wave, n_fft, hop, win, normalized, False)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gre, gim):
+        shape, n_fft, hop, win, normalized = ctx.cfg
+        T = shape[-1]
+        F, M = n_fft // 2 + 1, 1 + T // hop
+        gre, gim = gre.reshape(-1, F, M).float().contiguous(), gim.reshape(-1, F, M).float().contiguous()
+        Bn = gre.shape[0]
+        lib = _lib.lib()
+        with torch.cuda.device(gre.device):
+            gw = torch.empty((Bn, T), dtype=torch.float32, device=gre.device)
+            wsb = lib.vmasr_stft_bwd_workspace(Bn, T, n_fft, hop)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=gre.device)
+            _lib.check(lib.vmasr_stft_bwd(_p(gre), _p(gim), _p(gw), Bn, T, n_fft, hop, win, int(normalized), _p(ws), wsb,
+                                          _lib.current_stream(gre.device)), "stft_bwd")
+        return gw.view(shape), None, None, None, None
+
+
+def stft_reim(waveform, n_fft, hop_length, win_length, normalized=False):
+    """(re, im), each (..., n_fft/2+1, 1+T//hop); differentiable wrt `waveform`."""
+    return STFTReImFunction.apply(waveform, n_fft, hop_length, win_length, normalized)
 
 
 class ISTFTFunction(torch.autograd.Function):
