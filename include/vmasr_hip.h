@@ -140,6 +140,21 @@ int vmasr_istft_bwd(const float *mag, const float *phase, const float *g, float 
                     float *dphase, int32_t B, int32_t F, int32_t M, int32_t hop, int32_t win,
                     vmasr_stream_t stream);
 
+/* Channel-last LayerNorm over the last dimension (F.layer_norm on (rows, C) with C <= 1024):
+ * SS2D.out_norm, VSSBlock.norm/norm2, PatchMerging2D.norm, PatchExpanding.norm
+ * (model/vmamba.py:767-769,1793,1817; model/model.py:70,105-108,620,631).
+ * x (rows,C) `dtype`; gamma/beta (C) fp32 or NULL; y is fp32 when out_f32 != 0 (what autocast
+ * gives), else `dtype`; mean, rstd (rows) fp32 are saved for the backward. */
+int vmasr_layer_norm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean,
+                         float *rstd, int32_t rows, int32_t C, float eps, int32_t dtype, int32_t out_f32,
+                         vmasr_stream_t stream);
+/* dx (rows,C) `dtype`; gy fp32 when gy_f32 != 0 else `dtype`; dgamma/dbeta (C) fp32 or NULL (plainly
+ * written, no zero-init needed); ws: vmasr_layer_norm_bwd_workspace() bytes when dgamma/dbeta asked. */
+size_t vmasr_layer_norm_bwd_workspace(int32_t rows, int32_t C);
+int vmasr_layer_norm_bwd(const void *x, const void *gy, const float *gamma, const float *mean,
+                         const float *rstd, void *dx, float *dgamma, float *dbeta, float *ws, int32_t rows,
+                         int32_t C, int32_t dtype, int32_t gy_f32, vmasr_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents
  * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
@@ -164,6 +179,9 @@ enum {
     VMASR_K_ISTFT_FRAMES,
     VMASR_K_ISTFT_OLA,
     VMASR_K_ISTFT_BWD,
+    VMASR_K_LN_FWD,
+    VMASR_K_LN_BWD,
+    VMASR_K_LN_BWD_REDUCE,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

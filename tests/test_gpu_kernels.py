@@ -326,3 +326,35 @@ def test_stft_vs_oracle_batch4_full_clip():
     ore, oim = oracle.stft(wav.numpy()[:, 0], 2048, 512, 2048, normalized=False, logmag=False)
     _close(re, ore, 1e-4, 1e-4, "re")
     _close(im, oim, 1e-4, 1e-4, "im")
+
+
+# ------------------------------------------------------------------------------------------
+# LayerNorm (channel-last, small C): vs torch fp32 F.layer_norm (a floating-point kernel: the
+# oracle here is plain PyTorch fp32, as for any fp kernel)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C", [1, 2, 4, 8, 16, 24, 32, 64, 96, 128, 256, 512, 1024, 3, 130])
+def test_layer_norm_vs_torch(C):
+    from vm_asr_amd.layernorm import layer_norm
+    g = torch.Generator().manual_seed(C)
+    for rows_shape in ((2, 16, 16), (3, 5, 7), (1, 512, 512) if C <= 8 else (1, 33, 9)):
+        x = torch.randn(*rows_shape, C, generator=g) * 2 + 0.5
+        w = torch.randn(C, generator=g)
+        b = torch.randn(C, generator=g)
+        gy = torch.randn(*rows_shape, C, generator=g)
+        xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        yr = torch.nn.functional.layer_norm(xr.double(), (C,), wr.double(), br.double(), 1e-5)
+        yr.backward(gy.double())
+        xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+        y = layer_norm(xd, wd, bd, 1e-5)
+        y.backward(gy.to(DEV))
+        _close(y, yr.detach().numpy(), 1e-4, 1e-4, f"y C={C}")
+        _close(xd.grad, xr.grad.numpy(), 1e-4, _scaled(xr.grad.numpy()), f"dx C={C}")
+        _close(wd.grad, wr.grad.numpy(), 1e-4, _scaled(wr.grad.numpy()), f"dw C={C}")
+        _close(bd.grad, br.grad.numpy(), 1e-4, _scaled(br.grad.numpy()), f"db C={C}")
+    # bf16 input under autocast: fp32 output like torch's autocast policy
+    x = torch.randn(4, 64, 64, C, generator=g).to(torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = layer_norm(x.to(DEV), None, None, 1e-5)
+    assert y.dtype == torch.float32
+    want = torch.nn.functional.layer_norm(x.float(), (C,), None, None, 1e-5)
+    _close(y, want.numpy(), 1e-4, 1e-4, f"bf16 in C={C}")

@@ -32,7 +32,8 @@ hipEvent_t take_event() {
 const char *kNames[VMASR_K_COUNT] = {
     "sscan_fwd", "sscan_fwd_agg", "sscan_fwd_carry", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_agg",
     "sscan_bwd_carry", "sscan_bwd_apply", "cross_scan", "cross_merge", "dwconv_silu_fwd", "dwconv_silu_bwd_a",
-    "dwconv_silu_bwd_b", "stft", "istft_frames", "istft_ola", "istft_bwd"};
+    "dwconv_silu_bwd_b", "stft", "istft_frames", "istft_ola", "istft_bwd", "layer_norm_fwd", "layer_norm_bwd",
+    "layer_norm_bwd_reduce"};
 }  // namespace
 
 bool g_prof_on = false;

@@ -122,6 +122,123 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_b_kernel(const float *__r
     }
 }
 
+
+// ---- vectorised variants: 4 consecutive outputs of one image row per thread (W % 4 == 0) -------
+// Each thread loads the three input rows as one 16-B / 8-B vector plus the two halo scalars (L1
+// hits: the neighbouring thread fetched them as part of its vector), i.e. 3 vector + 6 scalar
+// loads per 4 outputs instead of 36 scalar loads.
+template <typename T>
+__device__ __forceinline__ void load_row6(const T *__restrict__ row, bool row_ok, int w0, int W, float (&v)[6]) {
+    if (!row_ok) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = 0.f;
+        return;
+    }
+    float q[4];
+    load4<T, true>(row, w0, W, q);
+    v[0] = w0 > 0 ? to_f32(row[w0 - 1]) : 0.f;
+    v[1] = q[0]; v[2] = q[1]; v[3] = q[2]; v[4] = q[3];
+    v[5] = w0 + 4 < W ? to_f32(row[w0 + 4]) : 0.f;
+}
+
+// MODE 0: y = silu(conv + bias).  MODE 1 (backward a): gp = gy * silu'(conv + bias) -> gp (fp32),
+// and the 9 + 1 weight/bias gradient sums of the block -> atomics.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void dwconv_silu_vec_kernel(const T *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, const T *__restrict__ gy,
+                                                              T *__restrict__ y, float *__restrict__ gp,
+                                                              float *__restrict__ dw, float *__restrict__ db,
+                                                              const int C, const int H, const int W) {
+    __shared__ float s_part[4][10];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int HW = H * W;
+    const size_t plane = ((size_t)b * C + c) * HW;
+    const T *xp = x + plane;
+    float wr[9], acc[10];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[k] = w[c * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    const float bv = bias ? bias[c] : 0.f;
+    const int l_end = min(HW, (int)(blockIdx.x + 1) * kChunk);
+    for (int l = blockIdx.x * kChunk + threadIdx.x * 4; l < l_end; l += 1024) {
+        const int h = l / W, w0 = l - h * W;
+        float r0[6], r1[6], r2[6];
+        load_row6(xp + (size_t)(h - 1) * W, h > 0, w0, W, r0);
+        load_row6(xp + (size_t)h * W, true, w0, W, r1);
+        load_row6(xp + (size_t)(h + 1) * W, h + 1 < H, w0, W, r2);
+        float o[4], g4[4];
+        if (MODE == 1) load4<T, true>(gy + plane, l, HW, g4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float pre = bv;
+            pre = fmaf(wr[0], r0[i], pre); pre = fmaf(wr[1], r0[i + 1], pre); pre = fmaf(wr[2], r0[i + 2], pre);
+            pre = fmaf(wr[3], r1[i], pre); pre = fmaf(wr[4], r1[i + 1], pre); pre = fmaf(wr[5], r1[i + 2], pre);
+            pre = fmaf(wr[6], r2[i], pre); pre = fmaf(wr[7], r2[i + 1], pre); pre = fmaf(wr[8], r2[i + 2], pre);
+            const float sg = sigmoid_f(pre);
+            if (MODE == 0) {
+                o[i] = pre * sg;
+            } else {
+                const float g = g4[i] * (sg * (1.f + pre * (1.f - sg)));
+                o[i] = g;
+                acc[0] = fmaf(g, r0[i], acc[0]); acc[1] = fmaf(g, r0[i + 1], acc[1]); acc[2] = fmaf(g, r0[i + 2], acc[2]);
+                acc[3] = fmaf(g, r1[i], acc[3]); acc[4] = fmaf(g, r1[i + 1], acc[4]); acc[5] = fmaf(g, r1[i + 2], acc[5]);
+                acc[6] = fmaf(g, r2[i], acc[6]); acc[7] = fmaf(g, r2[i + 1], acc[7]); acc[8] = fmaf(g, r2[i + 2], acc[8]);
+                acc[9] += g;
+            }
+        }
+        if (MODE == 0) store4<T, true>(y + plane, l, HW, o);
+        else store4<float, true>(gp + plane, l, HW, o);
+    }
+    if (MODE == 1) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float sres = wave_sum(acc[k]);
+            if (lane == 0) s_part[wave][k] = sres;
+        }
+        __syncthreads();
+        if (threadIdx.x < 10) {
+            const float sres = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+            if (threadIdx.x < 9) atomicAdd(dw + c * 9 + threadIdx.x, sres);
+            else if (db) atomicAdd(db + c, sres);
+        }
+    }
+}
+
+// backward b, vectorised: dx[h,w] = sum_{i,j} w[i,j] * gp[h-i+1, w-j+1]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_silu_bwd_b_vec_kernel(const float *__restrict__ gp, const float *__restrict__ w,
+                                                                    T *__restrict__ dx, const int C, const int H,
+                                                                    const int W) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int HW = H * W;
+    const size_t plane = ((size_t)b * C + c) * HW;
+    const float *gpp = gp + plane;
+    float wr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[k] = w[c * 9 + k];
+    const int l_end = min(HW, (int)(blockIdx.x + 1) * kChunk);
+    for (int l = blockIdx.x * kChunk + threadIdx.x * 4; l < l_end; l += 1024) {
+        const int h = l / W, w0 = l - h * W;
+        float r0[6], r1[6], r2[6];  // gp rows h+1, h, h-1 pair with kernel rows 0, 1, 2
+        load_row6(gpp + (size_t)(h + 1) * W, h + 1 < H, w0, W, r0);
+        load_row6(gpp + (size_t)h * W, true, w0, W, r1);
+        load_row6(gpp + (size_t)(h - 1) * W, h > 0, w0, W, r2);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // column offset: kernel column j pairs with gp column w - (j-1): j=0 -> w+1, j=2 -> w-1
+            float a = 0.f;
+            a = fmaf(wr[0], r0[i + 2], a); a = fmaf(wr[1], r0[i + 1], a); a = fmaf(wr[2], r0[i], a);
+            a = fmaf(wr[3], r1[i + 2], a); a = fmaf(wr[4], r1[i + 1], a); a = fmaf(wr[5], r1[i], a);
+            a = fmaf(wr[6], r2[i + 2], a); a = fmaf(wr[7], r2[i + 1], a); a = fmaf(wr[8], r2[i], a);
+            o[i] = a;
+        }
+        store4<T, true>(dx + plane, l, HW, o);
+    }
+}
+
 int check_shape(int B, int C, int H, int W, int dtype, const char *what) {
     VMASR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, VMASR_EINVAL, "%s: non-positive size", what);
     VMASR_REQUIRE(B <= 65535 && C <= 65535, VMASR_EINVAL, "%s: B and C must be <= 65535", what);
@@ -143,11 +260,22 @@ VMASR_EXPORT int vmasr_dwconv_silu_fwd(const void *x, const float *w, const floa
     const dim3 grid((H * W + kChunk - 1) / kChunk, C, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double bytes = 2.0 * B * C * H * W * (dtype == VMASR_F32 ? 4 : 2);  // read x, write y
+    const size_t al = dtype == VMASR_F32 ? 16 : 8;
+    const bool vec = W % 4 == 0 && aligned_to(x, al) && aligned_to(y, al);
+#define VMASR_DW_FWD(TT)                                                                                             \
+    do {                                                                                                             \
+        if (vec) VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, (dwconv_silu_vec_kernel<TT, 0>), grid, dim3(256), 0, st,     \
+                              (const TT *)x, w, bias, (const TT *)nullptr, (TT *)y, (float *)nullptr, (float *)nullptr, \
+                              (float *)nullptr, C, H, W);                                                            \
+        else VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<TT>, grid, dim3(256), 0, st, (const TT *)x, w, \
+                          bias, (TT *)y, C, H, W);                                                                   \
+    } while (0)
     switch (dtype) {
-        case VMASR_F32: VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<float>, grid, dim3(256), 0, st, (const float *)x, w, bias, (float *)y, C, H, W); break;
-        case VMASR_F16: VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t *)x, w, bias, (f16_t *)y, C, H, W); break;
-        default: VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, w, bias, (bf16_t *)y, C, H, W);
+        case VMASR_F32: VMASR_DW_FWD(float); break;
+        case VMASR_F16: VMASR_DW_FWD(f16_t); break;
+        default: VMASR_DW_FWD(bf16_t);
     }
+#undef VMASR_DW_FWD
     return check_launch("dwconv_silu_fwd");
 }
 
@@ -160,18 +288,27 @@ VMASR_EXPORT int vmasr_dwconv_silu_bwd(const void *x, const float *w, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double n = (double)B * C * H * W, es = dtype == VMASR_F32 ? 4 : 2;
     const double bytes_a = n * (2 * es + 4), bytes_b = n * (4 + es);  // a: read x, gy, write gp;  b: read gp, write dx
+    const size_t al = dtype == VMASR_F32 ? 16 : 8;
+    const bool vec = W % 4 == 0 && aligned_to(x, al) && aligned_to(gy, al) && aligned_to(dx, al) && aligned_to(ws, 16);
+#define VMASR_DW_BWD(TT)                                                                                              \
+    do {                                                                                                              \
+        if (vec) {                                                                                                    \
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, (dwconv_silu_vec_kernel<TT, 1>), grid, dim3(256), 0, st,        \
+                         (const TT *)x, w, bias, (const TT *)gy, (TT *)nullptr, ws, dw, db, C, H, W);                   \
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_vec_kernel<TT>, grid, dim3(256), 0, st, ws, w, \
+                         (TT *)dx, C, H, W);                                                                          \
+        } else {                                                                                                      \
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<TT>, grid, dim3(256), 0, st, (const TT *)x, \
+                         w, bias, (const TT *)gy, ws, dw, db, C, H, W);                                               \
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<TT>, grid, dim3(256), 0, st, ws, w,    \
+                         (TT *)dx, C, H, W);                                                                          \
+        }                                                                                                             \
+    } while (0)
     switch (dtype) {
-        case VMASR_F32:
-            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<float>, grid, dim3(256), 0, st, (const float *)x, w, bias, (const float *)gy, ws, dw, db, C, H, W);
-            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<float>, grid, dim3(256), 0, st, ws, w, (float *)dx, C, H, W);
-            break;
-        case VMASR_F16:
-            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t *)x, w, bias, (const f16_t *)gy, ws, dw, db, C, H, W);
-            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<f16_t>, grid, dim3(256), 0, st, ws, w, (f16_t *)dx, C, H, W);
-            break;
-        default:
-            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, w, bias, (const bf16_t *)gy, ws, dw, db, C, H, W);
-            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<bf16_t>, grid, dim3(256), 0, st, ws, w, (bf16_t *)dx, C, H, W);
+        case VMASR_F32: VMASR_DW_BWD(float); break;
+        case VMASR_F16: VMASR_DW_BWD(f16_t); break;
+        default: VMASR_DW_BWD(bf16_t);
     }
+#undef VMASR_DW_BWD
     return check_launch("dwconv_silu_bwd");
 }

@@ -31,6 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .stft import spectro2wav, wav2spectro
+from .layernorm import LayerNorm
 from .vmamba import PatchMerging2D, Permute, VSSBlock
 
 __all__ = ["PatchMerging2D", "PatchExpanding", "MambaUNet", "DualStreamInteractiveMambaUNet"]
@@ -39,7 +40,7 @@ __all__ = ["PatchMerging2D", "PatchExpanding", "MambaUNet", "DualStreamInteracti
 class PatchExpanding(nn.Module):
     """(B,H,W,C) -> (B,2H,2W,C/2): Linear C->2C, pixel-shuffle, LayerNorm  (model/model.py:92-116)."""
 
-    def __init__(self, dim, dim_scale=2, norm_layer=nn.LayerNorm):
+    def __init__(self, dim, dim_scale=2, norm_layer=LayerNorm):
         super().__init__()
         self.dim = dim
         self.expand = nn.Linear(dim, 2 * dim, bias=False) if dim_scale == 2 else nn.Identity()
@@ -135,7 +136,7 @@ class MambaUNet(nn.Module):
         self.spectro_scale = spectro_scale
         self.low_freq_replacement = low_freq_replacement
 
-        LN = nn.LayerNorm
+        LN = LayerNorm  # nn.LayerNorm subclass on the HIP kernel (same parameters / keys)
         blk_kw = dict(ssm_d_state=ssm_d_state, ssm_ratio=ssm_ratio, ssm_dt_rank=ssm_dt_rank,
                       ssm_act_layer=_ACT[ssm_act_layer.lower()], ssm_conv=ssm_conv, ssm_conv_bias=ssm_conv_bias,
                       ssm_drop_rate=ssm_drop_rate, ssm_init=ssm_init, forward_type=forward_type,

@@ -31,6 +31,7 @@ import torch.utils.checkpoint as checkpoint
 
 from .csm import CrossMergeHIP, CrossScanHIP
 from .dwconv import dwconv3x3_silu
+from .layernorm import LayerNorm
 from .selective_scan import SelectiveScanCore
 
 __all__ = ["SS2D", "VSSBlock", "VSSM", "Mlp", "DropPath", "LayerNorm2d", "Linear2d", "Permute"]
@@ -130,7 +131,7 @@ class SS2D(nn.Module):
             self.out_norm = LayerNorm2d(d_inner)
         else:
             self.out_norm_shape = "v0"
-            self.out_norm = nn.LayerNorm(d_inner)
+            self.out_norm = LayerNorm(d_inner)
 
         # the reference's v2 uses the PyTorch cross-scan, v5 the Triton one; both map to HIP here
         self.forward_core = partial(self.forward_corev2, force_fp32=(not self.disable_force32),
@@ -299,7 +300,7 @@ class SS2D(nn.Module):
 
 
 class VSSBlock(nn.Module):
-    def __init__(self, hidden_dim: int = 0, drop_path: float = 0, norm_layer=nn.LayerNorm, channel_first=False,
+    def __init__(self, hidden_dim: int = 0, drop_path: float = 0, norm_layer=LayerNorm, channel_first=False,
                  ssm_d_state: int = 16, ssm_ratio=2.0, ssm_dt_rank: Any = "auto", ssm_act_layer=nn.SiLU,
                  ssm_conv: int = 3, ssm_conv_bias=True, ssm_drop_rate: float = 0, ssm_init="v0",
                  forward_type="v2", mlp_ratio=4.0, mlp_act_layer=nn.GELU, mlp_drop_rate: float = 0.0,
@@ -346,7 +347,7 @@ class VSSBlock(nn.Module):
 class PatchMerging2D(nn.Module):
     """(B,H,W,C) -> (B,H/2,W/2,2C)  — model/model.py:57-89, model/vmamba.py PatchMerging2D."""
 
-    def __init__(self, dim, out_dim=-1, norm_layer=nn.LayerNorm, **kwargs):
+    def __init__(self, dim, out_dim=-1, norm_layer=LayerNorm, **kwargs):
         super().__init__()
         self.dim = dim
         self.reduction = nn.Linear(4 * dim, (2 * dim) if out_dim < 0 else out_dim, bias=False)
@@ -387,10 +388,10 @@ class VSSM(nn.Module):
         dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
         self.patch_embed = nn.Sequential(
             nn.Conv2d(in_chans, dims[0], kernel_size=patch_size, stride=patch_size, bias=True),
-            Permute(0, 2, 3, 1), nn.LayerNorm(dims[0]) if patch_norm else nn.Identity())
+            Permute(0, 2, 3, 1), LayerNorm(dims[0]) if patch_norm else nn.Identity())
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
-            blocks = [VSSBlock(hidden_dim=dims[i], drop_path=dpr[sum(depths[:i]) + j], norm_layer=nn.LayerNorm,
+            blocks = [VSSBlock(hidden_dim=dims[i], drop_path=dpr[sum(depths[:i]) + j], norm_layer=LayerNorm,
                                ssm_d_state=ssm_d_state, ssm_ratio=ssm_ratio, ssm_dt_rank=ssm_dt_rank,
                                ssm_act_layer=ssm_act, ssm_conv=ssm_conv, ssm_conv_bias=ssm_conv_bias,
                                ssm_drop_rate=ssm_drop_rate, ssm_init=ssm_init, forward_type=forward_type,
@@ -398,7 +399,7 @@ class VSSM(nn.Module):
                                gmlp=gmlp, use_checkpoint=use_checkpoint) for j in range(depths[i])]
             down = PatchMerging2D(dims[i], dims[i + 1]) if i < self.num_layers - 1 else nn.Identity()
             self.layers.append(nn.Sequential(nn.Sequential(*blocks), down))
-        self.classifier = nn.Sequential(nn.LayerNorm(self.num_features), Permute(0, 3, 1, 2),
+        self.classifier = nn.Sequential(LayerNorm(self.num_features), Permute(0, 3, 1, 2),
                                         nn.AdaptiveAvgPool2d(1), nn.Flatten(1),
                                         nn.Linear(self.num_features, num_classes))
         self.apply(self._init_weights)
