@@ -116,7 +116,7 @@ def main():
     rank, local, world = init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
     config = make_config(args.workload, args.batch)

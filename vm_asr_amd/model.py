@@ -71,10 +71,10 @@ class GemmConv2d(nn.Conv2d):
         Ho = (H + 2 * self.padding[0] - kh) // self.stride[0] + 1
         Wo = (W + 2 * self.padding[1] - kw) // self.stride[1] + 1
         cols = F.unfold(x, self.kernel_size, padding=self.padding, stride=self.stride)  # (B, C*kh*kw, Ho*Wo)
-        y = torch.matmul(self.weight.flatten(1).to(cols.dtype), cols)                    # (B, Cout, Ho*Wo)
-        if self.bias is not None:
-            y = y + self.bias.to(y.dtype).view(1, -1, 1)
-        return y.view(B, -1, Ho, Wo)
+        # pixels as the GEMM's M dimension: (B*Ho*Wo, C*kh*kw) @ (C*kh*kw, Cout).  The batched
+        # (Cout x K) @ (K x Ho*Wo) form picks a 32x32 hipBLASLt tile and takes 1.5 ms per call.
+        y = F.linear(cols.transpose(1, 2), self.weight.flatten(1), self.bias)            # (B, Ho*Wo, Cout)
+        return y.transpose(1, 2).reshape(B, -1, Ho, Wo)
 
 
 class PointwiseConvCL(nn.Conv2d):

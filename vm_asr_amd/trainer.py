@@ -40,9 +40,11 @@ def init_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        # "nccl" is RCCL on ROCm.  VMASR_DIST_BACKEND=gloo lets the multi-process path be exercised
+        # on a machine with fewer GPUs than ranks (ranks then share devices; test use only).
+        backend = os.environ.get("VMASR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
