@@ -155,6 +155,21 @@ int vmasr_layer_norm_bwd(const void *x, const void *gy, const float *gamma, cons
                          const float *rstd, void *dx, float *dgamma, float *dbeta, float *ws, int32_t rows,
                          int32_t C, int32_t dtype, int32_t gy_f32, vmasr_stream_t stream);
 
+/* nn.Linear with in/out features in {1,2,4,8} (in*out <= 32) over `rows` rows: the d_model = 1
+ * VSS block and the 4->1 pointwise conv of the output layer (model/model.py:862-885,
+ * model/vmamba.py:855,881,498-500).  x (rows,in) x_dtype; w (out,in), bias (out) fp32; y (rows,out)
+ * y_dtype; supported dtype pairs: equal, or fp32 -> fp16/bf16.  16-byte aligned pointers. */
+int vmasr_small_linear_supported(int32_t in_features, int32_t out_features);
+int vmasr_small_linear_fwd(const void *x, const float *w, const float *bias, void *y, int64_t rows,
+                           int32_t in_features, int32_t out_features, int32_t x_dtype, int32_t y_dtype,
+                           vmasr_stream_t stream);
+/* dx (rows,in) x_dtype or NULL; dw (out,in), db (out) fp32 or NULL (plainly written); gy (rows,out)
+ * gy_dtype; ws: vmasr_small_linear_bwd_workspace() bytes when dw/db are requested. */
+size_t vmasr_small_linear_bwd_workspace(int64_t rows, int32_t in_features, int32_t out_features);
+int vmasr_small_linear_bwd(const void *x, const float *w, const void *gy, void *dx, float *dw, float *db,
+                           float *ws, int64_t rows, int32_t in_features, int32_t out_features,
+                           int32_t x_dtype, int32_t gy_dtype, vmasr_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents
  * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
@@ -182,6 +197,9 @@ enum {
     VMASR_K_LN_FWD,
     VMASR_K_LN_BWD,
     VMASR_K_LN_BWD_REDUCE,
+    VMASR_K_SMALL_LINEAR_FWD,
+    VMASR_K_SMALL_LINEAR_BWD,
+    VMASR_K_SMALL_LINEAR_REDUCE,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

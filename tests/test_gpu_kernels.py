@@ -358,3 +358,35 @@ def test_layer_norm_vs_torch(C):
     assert y.dtype == torch.float32
     want = torch.nn.functional.layer_norm(x.float(), (C,), None, None, 1e-5)
     _close(y, want.numpy(), 1e-4, 1e-4, f"bf16 in C={C}")
+
+
+# ------------------------------------------------------------------------------------------
+# tiny-width Linear over many rows (the d_model = 1 block): vs torch fp64
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("io", [(1, 4), (2, 1), (4, 1), (1, 1), (4, 8), (8, 4), (2, 8), (8, 2)])
+def test_small_linear_vs_torch(io):
+    from vm_asr_amd.linear import linear
+    IN, OUT = io
+    g = torch.Generator().manual_seed(IN * 10 + OUT)
+    for shape in ((2, 128, 128), (1, 70001)):  # ragged row count too
+        x = torch.randn(*shape, IN, generator=g)
+        w = torch.randn(OUT, IN, generator=g)
+        b = torch.randn(OUT, generator=g)
+        gy = torch.randn(*shape, OUT, generator=g)
+        xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+        yr = torch.nn.functional.linear(xr, wr, br)
+        yr.backward(gy.double())
+        xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+        y = linear(xd, wd, bd)
+        y.backward(gy.to(DEV))
+        _close(y, yr.detach().numpy(), 1e-4, 1e-4, f"y {io}")
+        _close(xd.grad, xr.grad.numpy(), 1e-4, 1e-4, f"dx {io}")
+        _close(wd.grad, wr.grad.numpy(), 1e-4, _scaled(wr.grad.numpy()), f"dw {io}")
+        _close(bd.grad, br.grad.numpy(), 1e-4, _scaled(br.grad.numpy()), f"db {io}")
+    # autocast: fp32 activations in, bf16 out (what F.linear does under autocast)
+    x = torch.randn(4, 64, 64, IN, generator=g)
+    w = torch.randn(OUT, IN, generator=g)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = linear(x.to(DEV), w.to(DEV), None)
+    assert y.dtype == torch.bfloat16
+    _close(y, torch.nn.functional.linear(x, w).numpy(), 2e-2, 2e-2, f"bf16 out {io}")

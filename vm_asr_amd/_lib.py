@@ -53,6 +53,10 @@ SYMBOLS = {
     "vmasr_layer_norm_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, ctypes.c_float, c_i32, c_i32, c_vp]),
     "vmasr_layer_norm_bwd_workspace": (c_sz, [c_i32, c_i32]),
     "vmasr_layer_norm_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_small_linear_supported": (ctypes.c_int, [c_i32, c_i32]),
+    "vmasr_small_linear_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_small_linear_bwd_workspace": (c_sz, [c_i64, c_i32, c_i32]),
+    "vmasr_small_linear_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -114,7 +118,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 20
+K_COUNT = 23
 
 
 def prof_enable(on=True):

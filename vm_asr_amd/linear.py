@@ -1,0 +1,80 @@
+"""nn.Linear that routes tiny-feature / many-row cases to the HIP row-map kernels
+(vm_asr_amd/csrc/linear.hip): the d_model = 1 VSS block of the output layer and the 4->1
+pointwise conv in front of it (model/model.py:862-885).  Everything else stays F.linear
+(hipBLASLt).  Same parameters and state_dict keys as nn.Linear.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+__all__ = ["Linear", "linear"]
+
+_MIN_ROWS = 16384
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class _SmallLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_dtype):
+        out_f, in_f = weight.shape
+        x2 = x.reshape(-1, in_f)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        w32 = weight.detach().float().contiguous()
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        with torch.cuda.device(x.device):
+            y = torch.empty((rows, out_f), dtype=out_dtype, device=x.device)
+            _lib.check(_lib.lib().vmasr_small_linear_fwd(_p(x2), _p(w32), _p(b32), _p(y), rows, in_f, out_f,
+                                                         _lib.torch_dtype_code(x2.dtype), _lib.torch_dtype_code(out_dtype),
+                                                         _lib.current_stream(x.device)), "small_linear_fwd")
+        ctx.save_for_backward(x2, w32)
+        ctx.meta = (x.shape, weight.dtype, None if bias is None else bias.dtype, x.requires_grad)
+        return y.view(*x.shape[:-1], out_f)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w32 = ctx.saved_tensors
+        shape, wdt, bdt, need_dx = ctx.meta
+        out_f, in_f = w32.shape
+        rows = x2.shape[0]
+        gy2 = gy.reshape(rows, out_f)
+        # supported pairs: (x, gy) equal dtypes, or fp32 x with 16-bit gy
+        if gy2.dtype != x2.dtype and not (x2.dtype == torch.float32 and gy2.dtype in (torch.float16, torch.bfloat16)):
+            gy2 = gy2.to(x2.dtype)
+        if not gy2.is_contiguous():
+            gy2 = gy2.contiguous()
+        lib = _lib.lib()
+        with torch.cuda.device(x2.device):
+            dx = torch.empty_like(x2) if need_dx else None
+            dw = torch.empty((out_f, in_f), dtype=torch.float32, device=x2.device)
+            db = torch.empty(out_f, dtype=torch.float32, device=x2.device) if bdt is not None else None
+            ws = torch.empty(lib.vmasr_small_linear_bwd_workspace(rows, in_f, out_f) // 4, dtype=torch.float32,
+                             device=x2.device)
+            _lib.check(lib.vmasr_small_linear_bwd(_p(x2), _p(w32), _p(gy2), _p(dx), _p(dw), _p(db), _p(ws), rows, in_f,
+                                                  out_f, _lib.torch_dtype_code(x2.dtype), _lib.torch_dtype_code(gy2.dtype),
+                                                  _lib.current_stream(x2.device)), "small_linear_bwd")
+        return (dx.view(shape) if need_dx else None, dw.to(wdt), db.to(bdt) if bdt is not None else None, None)
+
+
+def linear(x, weight, bias=None):
+    """F.linear; tiny in/out features over many GPU rows go to the HIP row-map kernel."""
+    out_f, in_f = weight.shape
+    if (x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.numel() // max(1, in_f) >= _MIN_ROWS
+            and _lib.lib().vmasr_small_linear_supported(in_f, out_f)):
+        out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if out_dtype == x.dtype or x.dtype == torch.float32:
+            return _SmallLinearFn.apply(x, weight, bias, out_dtype)
+    return F.linear(x, weight, bias)
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)

@@ -32,6 +32,7 @@ import torch.nn.functional as F
 
 from .stft import spectro2wav, wav2spectro
 from .layernorm import LayerNorm
+from .linear import linear as _linear
 from .vmamba import PatchMerging2D, Permute, VSSBlock
 
 __all__ = ["PatchMerging2D", "PatchExpanding", "MambaUNet", "DualStreamInteractiveMambaUNet"]
@@ -83,7 +84,7 @@ class PointwiseConvCL(nn.Conv2d):
     862-864) without the two layout copies and without MIOpen's naive 1x1 fallbacks."""
 
     def forward(self, x):
-        return F.linear(x, self.weight.flatten(1), self.bias)
+        return _linear(x, self.weight.flatten(1), self.bias)
 
 
 _ACT = dict(silu=nn.SiLU, gelu=nn.GELU, relu=nn.ReLU, sigmoid=nn.Sigmoid)

@@ -32,6 +32,7 @@ import torch.utils.checkpoint as checkpoint
 from .csm import CrossMergeHIP, CrossScanHIP
 from .dwconv import dwconv3x3_silu
 from .layernorm import LayerNorm
+from .linear import Linear as _Linear
 from .selective_scan import SelectiveScanCore
 
 __all__ = ["SS2D", "VSSBlock", "VSSM", "Mlp", "DropPath", "LayerNorm2d", "Linear2d", "Permute"]
@@ -89,7 +90,7 @@ class Mlp(nn.Module):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        Linear = Linear2d if channels_first else nn.Linear
+        Linear = Linear2d if channels_first else _Linear
         self.fc1 = Linear(in_features, hidden_features)
         self.act = act_layer()
         self.fc2 = Linear(hidden_features, out_features)
@@ -117,7 +118,7 @@ class SS2D(nn.Module):
         self.d_conv = d_conv
         self.channel_first = channel_first
         self.k_group = 4
-        Linear = Linear2d if channel_first else nn.Linear
+        Linear = Linear2d if channel_first else _Linear  # nn.Linear subclass (HIP row map for tiny widths)
 
         self.disable_force32, forward_type = _strip("no32", forward_type)
         self.disable_z, forward_type = _strip("noz", forward_type)
