@@ -184,9 +184,20 @@ def main():
             # op-level: all scan kernels; algorithmic bytes counted once per op (apply/fwd/bwd kernels carry them)
             op_bytes = sum(v["alg_bytes"] for k, v in scan.items() if k in ("sscan_fwd", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_apply"))
             op_ms = sum(v["ms"] for v in scan.values())
+            # HBM bytes per launch from the committed PMC passes of this same workload (rocprofv3 cannot
+            # run inside bench.py): profiles/r01_pmc_traffic.json, made by tools/pmc_bench_report.py
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                traffic = pmc[dom]["hbm_bytes_per_launch"] if B == 4 and args.workload == "vm_asr_48k_MPD" else None
+            except Exception:
+                pass
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": d["gbs"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"],
+                "frac": d["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                  "FETCH_SIZE x2 per the gfx950 correction)" if traffic else None,
+                "avg_launch_us": d["avg_us"],
                 "timed_in": "eager pass of the same K steps right after the timed region (HIP events on the launch stream)",
                 "launches": d["launches"], "alg_bytes_per_launch": d["alg_bytes"] / d["launches"],
                 "selective_scan_op": {"achieved": op_bytes / (op_ms * 1e-3) / 1e9, "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

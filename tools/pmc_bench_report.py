@@ -1,0 +1,41 @@
+"""Per-kernel-id HBM traffic of one eager train step from two rocprofv3 PMC passes (dev tool).
+usage: pmc_bench_report.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM section)."""
+import csv, json, re, sys, collections
+
+def kid(name):
+    m = re.search(r"sscan_(fwd|bwd)_kernel<[^>]*?(\d)>", name)
+    if m:
+        d, mode = m.group(1), int(m.group(2))
+        return {("fwd", 0): "sscan_fwd", ("fwd", 3): "sscan_fwd", ("fwd", 2): "sscan_fwd_agg", ("fwd", 1): "sscan_fwd_apply",
+                ("bwd", 0): "sscan_bwd", ("bwd", 2): "sscan_bwd_agg", ("bwd", 1): "sscan_bwd_apply"}[(d, mode)]
+    for k in ("sscan_carry_kernel<false>", "sscan_carry_kernel<true>", "sscan_bwd_reduce_kernel", "cross_scan_kernel",
+              "cross_merge_kernel", "dwconv_silu", "stft_like_kernel", "istft_frames_kernel", "istft_ola_kernel",
+              "ln_fwd_kernel", "ln_bwd_kernel", "ln_bwd_reduce_kernel", "small_linear_fwd_kernel", "small_linear_bwd_kernel"):
+        if k in name:
+            return k
+    return None
+
+def load(path):
+    out = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if "vmasr" not in r["Kernel_Name"]:
+            continue
+        k = kid(r["Kernel_Name"])
+        if k:
+            a = out.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return out
+
+f, w = load(sys.argv[1]), load(sys.argv[2])
+res = {}
+for k in f:
+    n = f[k][0]
+    fb, wb = f[k][1] * 2 * 1024 / n, (w[k][1] * 1024 / w[k][0]) if k in w else 0.0
+    res[k] = {"launches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+    print(f"{k:28s} n={n:5d} fetch {fb/1e6:9.2f} MB  write {wb/1e6:9.2f} MB  total {(fb+wb)/1e6:9.2f} MB per launch")
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
+                   "`python bench.py --steps 1 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-timing`; "
+                   "KiB units, FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B)", "kernels": res},
+          open(sys.argv[3], "w"), indent=1)

@@ -95,9 +95,13 @@ def build_optimizer(config, models, capturable=False):
     name = config.TRAIN.OPTIMIZER.NAME.lower()
     if name == "adamw":
         lr = torch.tensor(float(config.TRAIN.BASE_LR)) if capturable else config.TRAIN.BASE_LR
+        on_gpu = any(p.is_cuda for g in groups for p in g["params"])
+        # fused: one multi-tensor kernel per step instead of ~10 foreach passes over 44 M parameters
+        extra = dict(fused=True) if (capturable and on_gpu and os.environ.get("VMASR_FUSED_ADAMW", "1") == "1") \
+            else dict(foreach=True if capturable else None)
         return torch.optim.AdamW(groups, lr=lr, eps=config.TRAIN.OPTIMIZER.EPS,
                                  betas=tuple(config.TRAIN.OPTIMIZER.BETAS), weight_decay=config.TRAIN.WEIGHT_DECAY,
-                                 capturable=capturable, foreach=True if capturable else None)
+                                 capturable=capturable, **extra)
     if name == "sgd":
         return torch.optim.SGD(groups, lr=config.TRAIN.BASE_LR, momentum=config.TRAIN.OPTIMIZER.MOMENTUM,
                                nesterov=True, weight_decay=config.TRAIN.WEIGHT_DECAY)
