@@ -107,6 +107,28 @@ int vmasr_cross_scan(const void *x, void *xs, int32_t B, int32_t C, int32_t H, i
 int vmasr_cross_merge(const void *ys, void *y, int32_t B, int32_t C, int32_t H, int32_t W,
                       int32_t dtype, vmasr_stream_t stream);
 
+/* dtype-converting variants: 16-bit x -> fp32 xs (scan), fp32 ys -> 16-bit y (merge); equal dtypes
+ * forward to the plain entry points. */
+int vmasr_cross_scan_cvt(const void *x, void *xs, int32_t B, int32_t C, int32_t H, int32_t W,
+                         int32_t in_dtype, int32_t out_dtype, vmasr_stream_t stream);
+int vmasr_cross_merge_cvt(const void *ys, void *y, int32_t B, int32_t C, int32_t H, int32_t W,
+                          int32_t in_dtype, int32_t out_dtype, vmasr_stream_t stream);
+
+/* SS2D's x_proj / dt_proj einsums (model/vmamba.py:1473-1491) as one memory-bound map:
+ *   xs (B,K,D,L) `dtype`; Wx (K, R+2N, D), Wdt (K, D, R) fp32  ->
+ *   dts (B,K*D,L), Bs (B,K,N,L), Cs (B,K,N,L) fp32 contiguous (scan-ready), dtr (B,K,R,L) fp32 (the
+ *   low-rank dt rows, kept by the caller for the backward).  R <= 8, R + 2N <= 16. */
+int vmasr_xproj_supported(int32_t d_state, int32_t dt_rank, int32_t d_inner);
+int vmasr_xproj_fwd(const void *xs, const float *Wx, const float *Wdt, float *dts, float *Bs, float *Cs,
+                    float *dtr, int32_t B, int32_t K, int32_t D, int32_t N, int32_t R, int32_t L,
+                    int32_t dtype, vmasr_stream_t stream);
+/* (ddts, dBs, dCs) fp32 [+ du (B,K*D,L) fp32 or NULL: added into dxs] -> dxs (B,K,D,L) `dtype`,
+ * dWx, dWdt fp32, ZERO-INITIALISED by the caller (accumulated).  ws: B*K*(R+2N)*L floats of scratch. */
+int vmasr_xproj_bwd(const void *xs, const float *Wx, const float *Wdt, const float *dtr, const float *ddts,
+                    const float *dBs, const float *dCs, const float *du, void *dxs, float *dWx, float *dWdt,
+                    float *ws, int32_t B, int32_t K, int32_t D, int32_t N, int32_t R, int32_t L,
+                    int32_t dtype, vmasr_stream_t stream);
+
 /* y = silu(dwconv3x3(x, w) + bias); x,y (B,C,H,W) contiguous `dtype`; w (C,3,3), bias (C)
  * fp32 (bias may be NULL). */
 int vmasr_dwconv_silu_fwd(const void *x, const float *w, const float *bias, void *y, int32_t B,
@@ -143,17 +165,18 @@ int vmasr_istft_bwd(const float *mag, const float *phase, const float *g, float 
 /* Channel-last LayerNorm over the last dimension (F.layer_norm on (rows, C) with C <= 1024):
  * SS2D.out_norm, VSSBlock.norm/norm2, PatchMerging2D.norm, PatchExpanding.norm
  * (model/vmamba.py:767-769,1793,1817; model/model.py:70,105-108,620,631).
- * x (rows,C) `dtype`; gamma/beta (C) fp32 or NULL; y is fp32 when out_f32 != 0 (what autocast
- * gives), else `dtype`; mean, rstd (rows) fp32 are saved for the backward. */
+ * x (rows,C) `dtype`; gamma/beta (C) fp32 or NULL; y (rows,C) `y_dtype` (equal to `dtype`, or fp32
+ * for 16-bit x — what autocast gives —, or 16-bit for fp32 x); mean, rstd (rows) fp32 are saved for
+ * the backward. */
 int vmasr_layer_norm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean,
-                         float *rstd, int32_t rows, int32_t C, float eps, int32_t dtype, int32_t out_f32,
+                         float *rstd, int32_t rows, int32_t C, float eps, int32_t dtype, int32_t y_dtype,
                          vmasr_stream_t stream);
-/* dx (rows,C) `dtype`; gy fp32 when gy_f32 != 0 else `dtype`; dgamma/dbeta (C) fp32 or NULL (plainly
+/* dx (rows,C) `dtype`; gy (rows,C) `gy_dtype` (same pairs); dgamma/dbeta (C) fp32 or NULL (plainly
  * written, no zero-init needed); ws: vmasr_layer_norm_bwd_workspace() bytes when dgamma/dbeta asked. */
 size_t vmasr_layer_norm_bwd_workspace(int32_t rows, int32_t C);
 int vmasr_layer_norm_bwd(const void *x, const void *gy, const float *gamma, const float *mean,
                          const float *rstd, void *dx, float *dgamma, float *dbeta, float *ws, int32_t rows,
-                         int32_t C, int32_t dtype, int32_t gy_f32, vmasr_stream_t stream);
+                         int32_t C, int32_t dtype, int32_t gy_dtype, vmasr_stream_t stream);
 
 /* nn.Linear with in/out features in {1,2,4,8} (in*out <= 32) over `rows` rows: the d_model = 1
  * VSS block and the 4->1 pointwise conv of the output layer (model/model.py:862-885,
@@ -200,6 +223,9 @@ enum {
     VMASR_K_SMALL_LINEAR_FWD,
     VMASR_K_SMALL_LINEAR_BWD,
     VMASR_K_SMALL_LINEAR_REDUCE,
+    VMASR_K_XPROJ_FWD,
+    VMASR_K_XPROJ_BWD_A,
+    VMASR_K_XPROJ_BWD_B,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

@@ -355,9 +355,11 @@ def test_layer_norm_vs_torch(C):
     x = torch.randn(4, 64, 64, C, generator=g).to(torch.bfloat16)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = layer_norm(x.to(DEV), None, None, 1e-5)
-    assert y.dtype == torch.float32
+        yb = layer_norm(x.float().to(DEV), None, None, 1e-5, feeds_gemm=True)
+    assert y.dtype == torch.float32 and yb.dtype == torch.bfloat16
     want = torch.nn.functional.layer_norm(x.float(), (C,), None, None, 1e-5)
     _close(y, want.numpy(), 1e-4, 1e-4, f"bf16 in C={C}")
+    assert torch.equal(yb.cpu(), want.to(torch.bfloat16)) or (yb.float().cpu() - want).abs().max() < 4e-2  # same rounding
 
 
 # ------------------------------------------------------------------------------------------
@@ -390,3 +392,44 @@ def test_small_linear_vs_torch(io):
         y = linear(x.to(DEV), w.to(DEV), None)
     assert y.dtype == torch.bfloat16
     _close(y, torch.nn.functional.linear(x, w).numpy(), 2e-2, 2e-2, f"bf16 out {io}")
+
+
+# ------------------------------------------------------------------------------------------
+# x_proj / dt_proj map vs the reference einsums (model/vmamba.py:1473-1477) in fp64
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(2, 2, 1, 1, 4096), (2, 32, 1, 1, 1024), (1, 256, 1, 8, 256), (2, 16, 4, 2, 300),
+                                 (1, 128, 1, 4, 1023)], ids=str)
+def test_xproj_vs_einsum(cfg):
+    from vm_asr_amd.xproj import x_proj_dt
+    Bn, D, N, R, L = cfg
+    K, C = 4, R + 2 * N
+    g = torch.Generator().manual_seed(D + L)
+    xs = torch.randn(Bn, K, D, L, generator=g)
+    Wx = torch.randn(K, C, D, generator=g) / D ** 0.5
+    Wdt = torch.randn(K, D, R, generator=g)
+    gd, gB, gC = torch.randn(Bn, K * D, L, generator=g), torch.randn(Bn, K, N, L, generator=g), torch.randn(Bn, K, N, L, generator=g)
+    xr, wxr, wdr = (t.double().requires_grad_() for t in (xs, Wx, Wdt))
+    x_dbl = torch.einsum("b k d l, k c d -> b k c l", xr, wxr)
+    dtsr, Bsr, Csr = torch.split(x_dbl, [R, N, N], dim=2)
+    dtsr = torch.einsum("b k r l, k d r -> b k d l", dtsr, wdr).reshape(Bn, -1, L)
+    ((dtsr * gd.double()).sum() + (Bsr * gB.double()).sum() + (Csr * gC.double()).sum()).backward()
+    xd, wxd, wdd = (t.to(DEV).requires_grad_() for t in (xs, Wx, Wdt))
+    dts, Bs, Cs = x_proj_dt(xd, wxd, wdd, N)
+    ((dts * gd.to(DEV)).sum() + (Bs * gB.to(DEV)).sum() + (Cs * gC.to(DEV)).sum()).backward()
+    _close(dts, dtsr.detach().numpy(), 1e-4, _scaled(dtsr.detach().numpy()), "dts")
+    _close(Bs, Bsr.detach().numpy(), 1e-4, 1e-4, "Bs")
+    _close(Cs, Csr.detach().numpy(), 1e-4, 1e-4, "Cs")
+    _close(xd.grad, xr.grad.numpy(), 1e-4, _scaled(xr.grad.numpy()), "dxs")
+    _close(wxd.grad, wxr.grad.numpy(), 1e-4, _scaled(wxr.grad.numpy()), "dWx")
+    _close(wdd.grad, wdr.grad.numpy(), 1e-4, _scaled(wdr.grad.numpy()), "dWdt")
+
+
+def test_cross_scan_merge_converting():
+    from vm_asr_amd import csm
+    x = torch.randn(2, 5, 33, 17).to(torch.bfloat16)
+    xs = csm.cross_scan(x.to(DEV), torch.float32)
+    assert xs.dtype == torch.float32 and np.array_equal(xs.cpu().numpy(), oracle.cross_scan(x.float().numpy()))
+    ys = torch.randn(2, 4, 5, 33, 17)
+    y = csm.cross_merge(ys.to(DEV), 33, 17, torch.bfloat16)
+    want = torch.from_numpy(oracle.cross_merge(ys.numpy())).to(torch.bfloat16)
+    assert y.dtype == torch.bfloat16 and torch.equal(y.cpu(), want)

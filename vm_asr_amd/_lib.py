@@ -57,6 +57,11 @@ SYMBOLS = {
     "vmasr_small_linear_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_small_linear_bwd_workspace": (c_sz, [c_i64, c_i32, c_i32]),
     "vmasr_small_linear_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_cross_scan_cvt": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_cross_merge_cvt": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_xproj_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
+    "vmasr_xproj_fwd": (ctypes.c_int, [c_vp] * 7 + [c_i32] * 7 + [c_vp]),
+    "vmasr_xproj_bwd": (ctypes.c_int, [c_vp] * 12 + [c_i32] * 7 + [c_vp]),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -118,7 +123,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 23
+K_COUNT = 26
 
 
 def prof_enable(on=True):

@@ -237,16 +237,22 @@ int launch_lpr(int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, 
 }
 
 template <int KIND>
-int dispatch(int dtype, bool out_f32, bool vec, int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, const void *gy,
+int dispatch(int dtype, int odt, bool vec, int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, const void *gy,
              const float *gamma, const float *beta, void *y, float *mean, float *rstd, float *part, const LnGeom g) {
 #define VMASR_LN_T(TT, TO)                                                                                             \
     (vec ? launch_lpr<TT, TO, true, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g)            \
          : launch_lpr<TT, TO, false, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g))
-    switch (dtype) {
-        case VMASR_F32: return VMASR_LN_T(float, float);
-        case VMASR_F16: return out_f32 ? VMASR_LN_T(f16_t, float) : VMASR_LN_T(f16_t, f16_t);
-        default: return out_f32 ? VMASR_LN_T(bf16_t, float) : VMASR_LN_T(bf16_t, bf16_t);
-    }
+    // (x dtype, y/gy dtype) pairs: equal, 16-bit x with fp32 y (what autocast gives F.layer_norm), and
+    // fp32 x with 16-bit y (the fp32 residual stream normalised straight into a GEMM operand)
+    if (dtype == VMASR_F32 && odt == VMASR_F32) return VMASR_LN_T(float, float);
+    if (dtype == VMASR_BF16 && odt == VMASR_BF16) return VMASR_LN_T(bf16_t, bf16_t);
+    if (dtype == VMASR_BF16 && odt == VMASR_F32) return VMASR_LN_T(bf16_t, float);
+    if (dtype == VMASR_F32 && odt == VMASR_BF16) return VMASR_LN_T(float, bf16_t);
+    if (dtype == VMASR_F16 && odt == VMASR_F16) return VMASR_LN_T(f16_t, f16_t);
+    if (dtype == VMASR_F16 && odt == VMASR_F32) return VMASR_LN_T(f16_t, float);
+    if (dtype == VMASR_F32 && odt == VMASR_F16) return VMASR_LN_T(float, f16_t);
+    set_error("layer_norm: unsupported dtype pair (%d, %d)", dtype, odt);
+    return VMASR_EINVAL;
 #undef VMASR_LN_T
 }
 
@@ -256,7 +262,7 @@ int dispatch(int dtype, bool out_f32, bool vec, int lpr, dim3 grid, hipStream_t 
 using namespace vmasr;
 
 VMASR_EXPORT int vmasr_layer_norm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean,
-                                      float *rstd, int32_t rows, int32_t C, float eps, int32_t dtype, int32_t out_f32,
+                                      float *rstd, int32_t rows, int32_t C, float eps, int32_t dtype, int32_t y_dtype,
                                       vmasr_stream_t stream) {
     if (int e = check(x, rows, C, dtype, "layer_norm_fwd")) return e;
     VMASR_REQUIRE(y && mean && rstd, VMASR_EINVAL, "layer_norm_fwd: null output");
@@ -264,9 +270,9 @@ VMASR_EXPORT int vmasr_layer_norm_fwd(const void *x, const float *gamma, const f
     const LnGeom g{rows, C, (C + 4 * lpr - 1) / (4 * lpr), eps};
     const size_t al = dtype == VMASR_F32 ? 16 : 8;
     const bool vec = C % 4 == 0 && aligned_to(x, al) && aligned_to(y, 16);
-    const double es = dtype == VMASR_F32 ? 4 : 2;
-    const double bytes = rows * (double)C * (es + (out_f32 ? 4 : es)) + 8.0 * rows;
-    if (int e = dispatch<0>(dtype, out_f32 != 0, vec, lpr, dim3(grid_for(rows, lpr)), static_cast<hipStream_t>(stream), bytes, x,
+    const double es = dtype == VMASR_F32 ? 4 : 2, eo = y_dtype == VMASR_F32 ? 4 : 2;
+    const double bytes = rows * (double)C * (es + eo) + 8.0 * rows;
+    if (int e = dispatch<0>(dtype, y_dtype, vec, lpr, dim3(grid_for(rows, lpr)), static_cast<hipStream_t>(stream), bytes, x,
                             nullptr, gamma, beta, y, mean, rstd, nullptr, g))
         return e;
     return check_launch("layer_norm_fwd");
@@ -279,7 +285,7 @@ VMASR_EXPORT size_t vmasr_layer_norm_bwd_workspace(int32_t rows, int32_t C) {
 
 VMASR_EXPORT int vmasr_layer_norm_bwd(const void *x, const void *gy, const float *gamma, const float *mean,
                                       const float *rstd, void *dx, float *dgamma, float *dbeta, float *ws, int32_t rows,
-                                      int32_t C, int32_t dtype, int32_t gy_f32, vmasr_stream_t stream) {
+                                      int32_t C, int32_t dtype, int32_t gy_dtype, vmasr_stream_t stream) {
     if (int e = check(x, rows, C, dtype, "layer_norm_bwd")) return e;
     VMASR_REQUIRE(gy && mean && rstd && dx, VMASR_EINVAL, "layer_norm_bwd: null tensor");
     const bool affine = dgamma || dbeta;
@@ -288,11 +294,11 @@ VMASR_EXPORT int vmasr_layer_norm_bwd(const void *x, const void *gy, const float
     const LnGeom g{rows, C, (C + 4 * lpr - 1) / (4 * lpr), 0.f};
     const size_t al = dtype == VMASR_F32 ? 16 : 8;
     const bool vec = C % 4 == 0 && aligned_to(x, al) && aligned_to(gy, 16) && aligned_to(dx, al);
-    const double es = dtype == VMASR_F32 ? 4 : 2;
-    const double bytes = rows * (double)C * (2 * es + (gy_f32 ? 4 : es)) + 8.0 * rows;
+    const double es = dtype == VMASR_F32 ? 4 : 2, eg = gy_dtype == VMASR_F32 ? 4 : 2;
+    const double bytes = rows * (double)C * (2 * es + eg) + 8.0 * rows;
     const int nblk = grid_for(rows, lpr);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (int e = dispatch<1>(dtype, gy_f32 != 0, vec, lpr, dim3(nblk), st, bytes, x, gy, gamma, nullptr, dx, const_cast<float *>(mean),
+    if (int e = dispatch<1>(dtype, gy_dtype, vec, lpr, dim3(nblk), st, bytes, x, gy, gamma, nullptr, dx, const_cast<float *>(mean),
                             const_cast<float *>(rstd), affine ? ws : nullptr, g))
         return e;
     if (affine)

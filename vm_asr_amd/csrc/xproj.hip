@@ -1,0 +1,292 @@
+// xproj.hip — SS2D's per-direction input projections (x_proj and dt_proj) for gfx950.
+//
+// Replaces the two einsums of SS2D.forward_corev2 and the copies/casts around them
+// (model/vmamba.py:1473-1491):
+//     x_dbl = einsum('b k d l, k c d -> b k c l', xs, x_proj_weight)      c = R + 2N
+//     dts, Bs, Cs = split(x_dbl, [R, N, N]);  dts = einsum('b k r l, k d r -> b k d l', dts, dt_projs_weight)
+//     .contiguous() x3, .to(float) x4
+// As batched GEMMs these are degenerate (inner dimensions D and R = 1..8, output width 3..10;
+// the weight gradient of the 512x512 block is a (2 x 10^6) @ (10^6 x 3) product that hipBLASLt
+// runs in 1.6 ms).  They are memory-bound maps over (b, k, l):
+//
+//   forward : one thread owns 4 consecutive positions l of one (b,k): it streams the D rows of xs
+//             once, keeps the c accumulators in registers, writes Bs/Cs (and the low-rank dt rows,
+//             kept for the backward) and expands dts = W_dt * dtr for the D rows.
+//             reads K D L, writes K D L (+ small)
+//   backward A (per position): d_dtr = W_dt^T ddts, dx_dbl = [d_dtr, dBs, dCs] (kept for B),
+//             dxs = W_x^T dx_dbl (+ du, the scan's own gradient wrt xs: fused add)
+//   backward B (per row d): dW_x[k,:,d] = sum_{b,l} dx_dbl * xs[d],  dW_dt[k,d,:] = sum ddts[d] * dtr
+//             one wave per (4 rows, 4096-position chunk), wave-reduced sums leave as float atomics
+// fp32 accumulation and fp32 weights; xs may be fp32 or 16-bit.  c <= 16 (d_state <= 4 at R <= 8).
+#include "common.h"
+
+namespace vmasr {
+namespace {
+
+constexpr int kMaxC = 16;  // R + 2N
+constexpr int kMaxR = 8;
+
+struct XpGeom {
+    int B, K, D, N, R, L;
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void xproj_fwd_kernel(const T *__restrict__ xs, const float *__restrict__ Wx,
+                                                        const float *__restrict__ Wdt, float *__restrict__ dts,
+                                                        float *__restrict__ Bs, float *__restrict__ Cs,
+                                                        float *__restrict__ dtr, const XpGeom g) {
+    extern __shared__ float s_w[];  // Wx[k]: C*D, then Wdt[k]: D*R
+    const int C = g.R + 2 * g.N;
+    const int k = blockIdx.y, b = blockIdx.z;
+    float *s_wx = s_w, *s_wdt = s_w + C * g.D;
+    for (int i = threadIdx.x; i < C * g.D; i += blockDim.x) s_wx[i] = Wx[(size_t)k * C * g.D + i];
+    for (int i = threadIdx.x; i < g.D * g.R; i += blockDim.x) s_wdt[i] = Wdt[(size_t)k * g.D * g.R + i];
+    __syncthreads();
+    const int l0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (l0 >= g.L) return;
+    const T *xp = xs + ((size_t)b * g.K + k) * g.D * g.L;
+    float acc[kMaxC][4];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f;
+    for (int d = 0; d < g.D; ++d) {
+        float v[4];
+        load4<T, VEC>(xp + (size_t)d * g.L, l0, g.L, v);
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) {
+                const float w = s_wx[c * g.D + d];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[c][i] = fmaf(w, v[i], acc[c][i]);
+            }
+    }
+    // dt rows (kept for the backward), then B and C
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+        if (c < C) {
+            float *dst;
+            if (c < g.R) dst = dtr + (((size_t)b * g.K + k) * g.R + c) * g.L;
+            else if (c < g.R + g.N) dst = Bs + (((size_t)b * g.K + k) * g.N + (c - g.R)) * g.L;
+            else dst = Cs + (((size_t)b * g.K + k) * g.N + (c - g.R - g.N)) * g.L;
+            store4<float, VEC>(dst, l0, g.L, acc[c]);
+        }
+    float *dp = dts + ((size_t)b * g.K + k) * g.D * g.L;
+    for (int d = 0; d < g.D; ++d) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r)
+            if (r < g.R) {
+                const float w = s_wdt[d * g.R + r];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = fmaf(w, acc[r][i], o[i]);
+            }
+        store4<float, VEC>(dp + (size_t)d * g.L, l0, g.L, o);
+    }
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void xproj_bwd_a_kernel(const float *__restrict__ ddts, const float *__restrict__ dBs,
+                                                          const float *__restrict__ dCs, const float *__restrict__ du,
+                                                          const float *__restrict__ Wx, const float *__restrict__ Wdt,
+                                                          T *__restrict__ dxs, float *__restrict__ dxdbl,
+                                                          const XpGeom g) {
+    extern __shared__ float s_w[];
+    const int C = g.R + 2 * g.N;
+    const int k = blockIdx.y, b = blockIdx.z;
+    float *s_wx = s_w, *s_wdt = s_w + C * g.D;
+    for (int i = threadIdx.x; i < C * g.D; i += blockDim.x) s_wx[i] = Wx[(size_t)k * C * g.D + i];
+    for (int i = threadIdx.x; i < g.D * g.R; i += blockDim.x) s_wdt[i] = Wdt[(size_t)k * g.D * g.R + i];
+    __syncthreads();
+    const int l0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (l0 >= g.L) return;
+    const size_t row0 = ((size_t)b * g.K + k) * g.D;
+    float acc[kMaxC][4];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f;
+    // d_dtr[r] = sum_d Wdt[d,r] * ddts[d]
+    for (int d = 0; d < g.D; ++d) {
+        float v[4];
+        load4<float, VEC>(ddts + (row0 + d) * g.L, l0, g.L, v);
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r)
+            if (r < g.R) {
+                const float w = s_wdt[d * g.R + r];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[r][i] = fmaf(w, v[i], acc[r][i]);
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+        if (c >= g.R && c < C) {
+            const float *src = c < g.R + g.N ? dBs + (((size_t)b * g.K + k) * g.N + (c - g.R)) * g.L
+                                             : dCs + (((size_t)b * g.K + k) * g.N + (c - g.R - g.N)) * g.L;
+            load4<float, VEC>(src, l0, g.L, acc[c]);
+        }
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+        if (c < C) store4<float, VEC>(dxdbl + (((size_t)b * g.K + k) * C + c) * g.L, l0, g.L, acc[c]);
+    // dxs[d] = sum_c Wx[c,d] * dx_dbl[c] (+ du[d])
+    for (int d = 0; d < g.D; ++d) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (du) load4<float, VEC>(du + (row0 + d) * g.L, l0, g.L, o);
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) {
+                const float w = s_wx[c * g.D + d];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = fmaf(w, acc[c][i], o[i]);
+            }
+        store4<T, VEC>(dxs + (row0 + d) * g.L, l0, g.L, o);
+    }
+}
+
+// one wave per (k, 4 rows d, 4096-position chunk of one batch element): partial dWx[k, c, d] and
+// dWdt[k, d, r] -> float atomics (a few hundred adds per address at most; outputs zero-initialised)
+constexpr int kXpChunk = 4096;
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void xproj_bwd_b_kernel(const T *__restrict__ xs, const float *__restrict__ ddts,
+                                                          const float *__restrict__ dxdbl, const float *__restrict__ dtr,
+                                                          float *__restrict__ dWx, float *__restrict__ dWdt,
+                                                          const XpGeom g) {
+    constexpr int RW = 4;  // rows per wave
+    const int C = g.R + 2 * g.N;
+    const int lane = threadIdx.x & 63;
+    const int nrb = (g.D + RW - 1) / RW;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);  // (k, row-block)
+    if (wid >= g.K * nrb) return;
+    const int k = wid / nrb, d0 = (wid % nrb) * RW;
+    const int b = blockIdx.z;
+    const int l_begin = blockIdx.y * kXpChunk, l_end = min(g.L, l_begin + kXpChunk);
+    float ax[RW][kMaxC], at[RW][kMaxR];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) ax[j][c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r) at[j][r] = 0.f;
+    }
+    const size_t bk = (size_t)b * g.K + k;
+    for (int l0 = l_begin + lane * 4; l0 < l_end; l0 += 256) {
+        float xv[RW][4], gv[RW][4];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            if (d0 + j < g.D) {
+                load4<T, VEC>(xs + (bk * g.D + d0 + j) * g.L, l0, g.L, xv[j]);
+                load4<float, VEC>(ddts + (bk * g.D + d0 + j) * g.L, l0, g.L, gv[j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xv[j][i] = 0.f; gv[j][i] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) {
+                float q[4];
+                load4<float, VEC>(dxdbl + (bk * C + c) * g.L, l0, g.L, q);
+#pragma unroll
+                for (int j = 0; j < RW; ++j)
+                    ax[j][c] += (q[0] * xv[j][0] + q[1] * xv[j][1]) + (q[2] * xv[j][2] + q[3] * xv[j][3]);
+            }
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r)
+            if (r < g.R) {
+                float q[4];
+                load4<float, VEC>(dtr + (bk * g.R + r) * g.L, l0, g.L, q);
+#pragma unroll
+                for (int j = 0; j < RW; ++j)
+                    at[j][r] += (q[0] * gv[j][0] + q[1] * gv[j][1]) + (q[2] * gv[j][2] + q[3] * gv[j][3]);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        if (d0 + j >= g.D) break;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) {
+                const float s = wave_sum(ax[j][c]);
+                if (lane == 0) atomicAdd(dWx + ((size_t)k * C + c) * g.D + d0 + j, s);
+            }
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r)
+            if (r < g.R) {
+                const float s = wave_sum(at[j][r]);
+                if (lane == 0) atomicAdd(dWdt + ((size_t)k * g.D + d0 + j) * g.R + r, s);
+            }
+    }
+}
+
+int check(const XpGeom &g, int dtype, const char *what) {
+    VMASR_REQUIRE(g.B > 0 && g.K > 0 && g.D > 0 && g.N > 0 && g.R > 0 && g.L > 0, VMASR_EINVAL, "%s: non-positive size", what);
+    VMASR_REQUIRE(g.R <= kMaxR && g.R + 2 * g.N <= kMaxC, VMASR_EINVAL, "%s: need dt_rank <= %d and dt_rank + 2*d_state <= %d",
+                  what, kMaxR, kMaxC);
+    VMASR_REQUIRE(g.B <= 65535 && g.K <= 65535, VMASR_EINVAL, "%s: batch / directions too large", what);
+    VMASR_REQUIRE((size_t)(g.R + 2 * g.N + g.R) * g.D * 4 <= 64 * 1024, VMASR_EINVAL, "%s: weights do not fit LDS", what);
+    VMASR_REQUIRE(dtype == VMASR_F32 || dtype == VMASR_F16 || dtype == VMASR_BF16, VMASR_EINVAL, "%s: bad dtype", what);
+    return 0;
+}
+
+}  // namespace
+}  // namespace vmasr
+
+using namespace vmasr;
+
+VMASR_EXPORT int vmasr_xproj_supported(int32_t d_state, int32_t dt_rank, int32_t d_inner) {
+    return (dt_rank >= 1 && dt_rank <= kMaxR && d_state >= 1 && dt_rank + 2 * d_state <= kMaxC &&
+            (size_t)(2 * dt_rank + 2 * d_state) * d_inner * 4 <= 64 * 1024) ? 1 : 0;
+}
+
+VMASR_EXPORT int vmasr_xproj_fwd(const void *xs, const float *Wx, const float *Wdt, float *dts, float *Bs, float *Cs,
+                                 float *dtr, int32_t B, int32_t K, int32_t D, int32_t N, int32_t R, int32_t L,
+                                 int32_t dtype, vmasr_stream_t stream) {
+    const XpGeom g{B, K, D, N, R, L};
+    if (int e = check(g, dtype, "xproj_fwd")) return e;
+    VMASR_REQUIRE(xs && Wx && Wdt && dts && Bs && Cs && dtr, VMASR_EINVAL, "xproj_fwd: null tensor");
+    const bool vec = L % 4 == 0 && aligned_to(xs, dtype == VMASR_F32 ? 16 : 8) && aligned_to(dts, 16) && aligned_to(Bs, 16) &&
+                     aligned_to(Cs, 16) && aligned_to(dtr, 16);
+    const int C = R + 2 * N;
+    const size_t sm = (size_t)(C + R) * D * sizeof(float);
+    const dim3 grid((L + 1023) / 1024, K, B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double es = dtype == VMASR_F32 ? 4 : 2;
+    const double bytes = (double)B * K * L * (D * (es + 4.0) + (C + 0.0) * 4.0);
+#define VMASR_XP(TT, V) VMASR_LAUNCH(VMASR_K_XPROJ_FWD, bytes, (xproj_fwd_kernel<TT, V>), grid, dim3(256), sm, st, (const TT *)xs, Wx, Wdt, dts, Bs, Cs, dtr, g)
+    if (dtype == VMASR_F32) { if (vec) VMASR_XP(float, true); else VMASR_XP(float, false); }
+    else if (dtype == VMASR_F16) { if (vec) VMASR_XP(f16_t, true); else VMASR_XP(f16_t, false); }
+    else { if (vec) VMASR_XP(bf16_t, true); else VMASR_XP(bf16_t, false); }
+#undef VMASR_XP
+    return check_launch("xproj_fwd");
+}
+
+VMASR_EXPORT int vmasr_xproj_bwd(const void *xs, const float *Wx, const float *Wdt, const float *dtr, const float *ddts,
+                                 const float *dBs, const float *dCs, const float *du, void *dxs, float *dWx, float *dWdt,
+                                 float *ws, int32_t B, int32_t K, int32_t D, int32_t N, int32_t R, int32_t L,
+                                 int32_t dtype, vmasr_stream_t stream) {
+    const XpGeom g{B, K, D, N, R, L};
+    if (int e = check(g, dtype, "xproj_bwd")) return e;
+    VMASR_REQUIRE(xs && Wx && Wdt && dtr && ddts && dBs && dCs && dxs && dWx && dWdt && ws, VMASR_EINVAL,
+                  "xproj_bwd: null tensor");
+    const bool vec = L % 4 == 0 && aligned_to(xs, dtype == VMASR_F32 ? 16 : 8) && aligned_to(dxs, dtype == VMASR_F32 ? 16 : 8) &&
+                     aligned_to(ddts, 16) && aligned_to(dBs, 16) && aligned_to(dCs, 16) && aligned_to(dtr, 16) &&
+                     aligned_to(ws, 16) && (!du || aligned_to(du, 16));
+    const int C = R + 2 * N;
+    const size_t sm = (size_t)(C + R) * D * sizeof(float);
+    const dim3 grid((L + 1023) / 1024, K, B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double es = dtype == VMASR_F32 ? 4 : 2;
+    const double bytes_a = (double)B * K * L * (D * (4.0 + es + (du ? 4.0 : 0.0)) + 2.0 * C * 4.0);
+    const double bytes_b = (double)B * K * L * (D * (4.0 + es) + (double)(C + R) * 4.0);
+    const int nwaves = K * ((D + 3) / 4);
+#define VMASR_XPB(TT, V)                                                                                                 \
+    do {                                                                                                                 \
+        VMASR_LAUNCH(VMASR_K_XPROJ_BWD_A, bytes_a, (xproj_bwd_a_kernel<TT, V>), grid, dim3(256), sm, st, ddts, dBs, dCs, du, \
+                     Wx, Wdt, (TT *)dxs, ws, g);                                                                         \
+        VMASR_LAUNCH(VMASR_K_XPROJ_BWD_B, bytes_b, (xproj_bwd_b_kernel<TT, V>),                                           \
+                     dim3((nwaves + 3) / 4, (L + kXpChunk - 1) / kXpChunk, B), dim3(256), 0, st,                          \
+                     (const TT *)xs, ddts, ws, dtr, dWx, dWdt, g);                                                       \
+    } while (0)
+    if (dtype == VMASR_F32) { if (vec) VMASR_XPB(float, true); else VMASR_XPB(float, false); }
+    else if (dtype == VMASR_F16) { if (vec) VMASR_XPB(f16_t, true); else VMASR_XPB(f16_t, false); }
+    else { if (vec) VMASR_XPB(bf16_t, true); else VMASR_XPB(bf16_t, false); }
+#undef VMASR_XPB
+    return check_launch("xproj_bwd");
+}

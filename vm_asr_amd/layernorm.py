@@ -24,7 +24,7 @@ def _p(t):
 
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, out_f32):
+    def forward(ctx, x, weight, bias, eps, out_dtype):
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         if not x2.is_contiguous():
@@ -32,13 +32,13 @@ class _LayerNormFn(torch.autograd.Function):
         rows = x2.shape[0]
         w32 = None if weight is None else weight.detach().float().contiguous()
         b32 = None if bias is None else bias.detach().float().contiguous()
-        out_f32 = bool(out_f32) or x2.dtype == torch.float32
         with torch.cuda.device(x.device):
-            y = torch.empty((rows, C), dtype=torch.float32 if out_f32 else x2.dtype, device=x.device)
+            y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
             mean = torch.empty(rows, dtype=torch.float32, device=x.device)
             rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
             _lib.check(_lib.lib().vmasr_layer_norm_fwd(_p(x2), _p(w32), _p(b32), _p(y), _p(mean), _p(rstd), rows, C,
-                                                       float(eps), _lib.torch_dtype_code(x2.dtype), int(out_f32),
+                                                       float(eps), _lib.torch_dtype_code(x2.dtype),
+                                                       _lib.torch_dtype_code(out_dtype),
                                                        _lib.current_stream(x.device)), "layer_norm_fwd")
         ctx.save_for_backward(x2, w32 if w32 is not None else torch.empty(0, device=x.device), mean, rstd)
         ctx.meta = (x.shape, weight is not None, bias is not None,
@@ -51,8 +51,8 @@ class _LayerNormFn(torch.autograd.Function):
         shape, has_w, has_b, wdt, bdt = ctx.meta
         rows, C = x2.shape
         gy2 = gy.reshape(rows, C)
-        if gy2.dtype not in (torch.float32, x2.dtype):
-            gy2 = gy2.float()
+        if gy2.dtype != x2.dtype and torch.float32 not in (gy2.dtype, x2.dtype):
+            gy2 = gy2.float()  # (fp16, bf16) mixes are not built: go through fp32
         if not gy2.is_contiguous():
             gy2 = gy2.contiguous()
         lib = _lib.lib()
@@ -65,22 +65,29 @@ class _LayerNormFn(torch.autograd.Function):
                 ws = torch.empty(lib.vmasr_layer_norm_bwd_workspace(rows, C) // 4, dtype=torch.float32, device=x2.device)
             _lib.check(lib.vmasr_layer_norm_bwd(_p(x2), _p(gy2), _p(w32) if has_w else None, _p(mean), _p(rstd), _p(dx),
                                                 _p(dg), _p(db), _p(ws), rows, C, _lib.torch_dtype_code(x2.dtype),
-                                                int(gy2.dtype == torch.float32), _lib.current_stream(x2.device)),
+                                                _lib.torch_dtype_code(gy2.dtype), _lib.current_stream(x2.device)),
                        "layer_norm_bwd")
         return (dx.view(shape), dg.to(wdt) if has_w else None, db.to(bdt) if has_b else None, None, None)
 
 
-def layer_norm(x, weight=None, bias=None, eps=1e-5):
-    """F.layer_norm over the last dimension."""
+def layer_norm(x, weight=None, bias=None, eps=1e-5, feeds_gemm=False):
+    """F.layer_norm over the last dimension.  Under autocast the result is fp32 (torch's policy for
+    layer_norm) unless `feeds_gemm`: the caller promises that the only consumer is an autocast GEMM,
+    which would round this very fp32 result to the autocast dtype first — so it is written in
+    that dtype directly (bit-identical GEMM operand, one cast pass fewer in each direction)."""
     C = x.shape[-1]
     if x.is_cuda and C <= 1024 and x.dtype in (torch.float32, torch.float16, torch.bfloat16):
-        out_f32 = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
-        return _LayerNormFn.apply(x, weight, bias, eps, out_f32)
+        out_dtype = x.dtype
+        if torch.is_autocast_enabled("cuda"):
+            out_dtype = torch.get_autocast_dtype("cuda") if feeds_gemm else torch.float32
+        return _LayerNormFn.apply(x, weight, bias, eps, out_dtype)
     return F.layer_norm(x, (C,), weight, bias, eps)
 
 
 class LayerNorm(nn.LayerNorm):
+    feeds_gemm = False  # set by owners whose next op is a Linear (VSSBlock.norm / norm2, PatchMerging2D.norm)
+
     def forward(self, x):
         if len(self.normalized_shape) == 1:
-            return layer_norm(x, self.weight, self.bias, self.eps)
+            return layer_norm(x, self.weight, self.bias, self.eps, self.feeds_gemm)
         return super().forward(x)

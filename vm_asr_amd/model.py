@@ -252,8 +252,11 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
                 if i != 0:
                     ms, ps = skips_m.pop(), skips_p.pop()
                     if self.concat_skip:
-                        mag = dec_m(torch.cat((mag, ms), dim=-1))
-                        phase = dec_m(torch.cat((phase, ps), dim=-1))  # sic: magnitude decoder (model/model.py:1187)
+                        # sic: the phase stream also runs through the MAGNITUDE decoder (model/model.py:1187).
+                        # Same weights for both streams -> one pass over the stacked batch (identical
+                        # arithmetic per sample, half the kernel launches of two separate calls).
+                        both = dec_m(torch.cat((torch.cat((mag, ms), dim=-1), torch.cat((phase, ps), dim=-1)), dim=0))
+                        mag, phase = both[: mag.shape[0]], both[mag.shape[0]:]
                     else:
                         mag, phase = dec_m(mag + ms), dec_p(phase + ps)
                 else:

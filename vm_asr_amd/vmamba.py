@@ -29,7 +29,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .csm import CrossMergeHIP, CrossScanHIP
+from .csm import CrossMergeHIP, CrossScanF32, CrossScanHIP
+from . import xproj as _xproj
 from .dwconv import dwconv3x3_silu
 from .layernorm import LayerNorm
 from .linear import Linear as _Linear
@@ -229,6 +230,19 @@ class SS2D(nn.Module):
         K, D, R = dt_projs_weight.shape
         L = H * W
 
+        if (x.is_cuda and force_fp32 and not no_einsum and CrossScan is CrossScanHIP and SelectiveScan is SelectiveScanCore
+                and _xproj.supported(N, R, D) and D <= 32):
+            # (D <= 32: the map is parallel over positions only; the deep stages have few positions and
+            #  D = 64..256 rows, where the batched-GEMM einsums below are the better fit)
+            # HIP fast path: the scan streams are produced in fp32 directly and x_proj/dt_proj are one
+            # memory-bound kernel writing scan-ready fp32 tensors (no einsum / contiguous / cast passes)
+            xs = CrossScanF32.apply(x)                                         # (B, K, D, L) fp32
+            dts, Bs, Cs = _xproj.x_proj_dt(xs, x_proj_weight, dt_projs_weight, N)
+            ys = SelectiveScan.apply(xs.view(B, -1, L), dts, -torch.exp(A_logs.to(torch.float)), Bs, Cs,
+                                     Ds.to(torch.float), dt_projs_bias.view(-1).to(torch.float), delta_softplus,
+                                     nrows, backnrows, ssoflex).view(B, K, -1, H, W)
+            return self._merge_norm(CrossMerge.apply(ys), x, B, H, W, to_dtype)
+
         xs = CrossScan.apply(x)  # (B, K, D, L)
         if no_einsum:
             x_dbl = F.conv1d(xs.view(B, -1, L), x_proj_weight.view(-1, D, 1), groups=K)
@@ -251,8 +265,11 @@ class SS2D(nn.Module):
 
         ys = SelectiveScan.apply(xs, dts, As, Bs, Cs, Ds, delta_bias, delta_softplus, nrows, backnrows,
                                  ssoflex).view(B, K, -1, H, W)
-        y = CrossMerge.apply(ys)  # (B, D, L)
+        return self._merge_norm(CrossMerge.apply(ys), x, B, H, W, to_dtype)
 
+    def _merge_norm(self, y, x, B, H, W, to_dtype):
+        """out_norm on the merged (B, D, L) tensor -> (B, H, W, D)  (model/vmamba.py:1517-1531)."""
+        out_norm = getattr(self, "out_norm", None)
         if self.channel_first:
             y = y.view(B, -1, H, W)
             if self.out_norm_shape == "v1":
@@ -318,12 +335,16 @@ class VSSBlock(nn.Module):
                            dropout=ssm_drop_rate, initialize=ssm_init, forward_type=forward_type,
                            channel_first=channel_first)
         self.drop_path = DropPath(drop_path)
+        if self.ssm_branch and isinstance(self.norm, LayerNorm) and not post_norm and not channel_first:
+            self.norm.feeds_gemm = True   # -> SS2D.in_proj
         if self.mlp_branch:
             if gmlp:
                 raise NotImplementedError("gMlp is not reachable from any shipped config (config.py:112)")
             self.norm2 = norm_layer(hidden_dim)
             self.mlp = Mlp(in_features=hidden_dim, hidden_features=int(hidden_dim * mlp_ratio),
                            act_layer=mlp_act_layer, drop=mlp_drop_rate, channels_first=channel_first)
+            if isinstance(self.norm2, LayerNorm) and not post_norm and not channel_first:
+                self.norm2.feeds_gemm = True  # -> Mlp.fc1
 
     def _forward(self, input: torch.Tensor):
         x = input
@@ -353,6 +374,8 @@ class PatchMerging2D(nn.Module):
         self.dim = dim
         self.reduction = nn.Linear(4 * dim, (2 * dim) if out_dim < 0 else out_dim, bias=False)
         self.norm = norm_layer(4 * dim)
+        if isinstance(self.norm, LayerNorm):
+            self.norm.feeds_gemm = True  # -> reduction
 
     @staticmethod
     def _patch_merging_pad(x: torch.Tensor):
