@@ -193,6 +193,12 @@ int vmasr_small_linear_bwd(const void *x, const float *w, const void *gy, void *
                            float *ws, int64_t rows, int32_t in_features, int32_t out_features,
                            int32_t x_dtype, int32_t gy_dtype, vmasr_stream_t stream);
 
+/* Power iteration of spectral normalisation (torch.nn.utils.parametrizations.spectral_norm, which
+ * the reference's MPD uses: model/discriminator.py:37): n_iter rounds of u <- normalize(W v),
+ * v <- normalize(W^T u), in place.  W (R,C) fp32 row-major, u (R), v (C) fp32; ws: R + C floats. */
+int vmasr_spectral_power_iter(const float *W, float *u, float *v, float *ws, int32_t R, int32_t C,
+                              int32_t n_iter, float eps, vmasr_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents
  * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
@@ -226,6 +232,7 @@ enum {
     VMASR_K_XPROJ_FWD,
     VMASR_K_XPROJ_BWD_A,
     VMASR_K_XPROJ_BWD_B,
+    VMASR_K_SPECTRAL,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

@@ -433,3 +433,20 @@ def test_cross_scan_merge_converting():
     y = csm.cross_merge(ys.to(DEV), 33, 17, torch.bfloat16)
     want = torch.from_numpy(oracle.cross_merge(ys.numpy())).to(torch.bfloat16)
     assert y.dtype == torch.bfloat16 and torch.equal(y.cpu(), want)
+
+
+def test_spectral_power_iteration_vs_torch():
+    from vm_asr_amd.discriminator import _SpectralNorm
+    for shape in ((32, 1, 5, 1), (128, 32, 5, 1), (1024, 512, 5, 1), (1, 1024, 3, 1), (7, 3, 5, 1)):
+        torch.manual_seed(sum(shape))
+        w = torch.randn(*shape)
+        sn_cpu = _SpectralNorm(w)                      # CPU: torch ops
+        sn_gpu = _SpectralNorm(w).to(DEV)
+        sn_gpu._u.copy_(sn_cpu._u); sn_gpu._v.copy_(sn_cpu._v)
+        sn_cpu.train(); sn_gpu.train()
+        sn_cpu.n_power_iterations = sn_gpu.n_power_iterations = 3
+        out_c = sn_cpu(w)
+        out_g = sn_gpu(w.to(DEV))                      # GPU: vmasr_spectral_power_iter
+        _close(sn_gpu._u, sn_cpu._u.numpy(), 1e-4, 1e-5, f"u {shape}")
+        _close(sn_gpu._v, sn_cpu._v.numpy(), 1e-4, 1e-5, f"v {shape}")
+        _close(out_g, out_c.detach().numpy(), 1e-4, 1e-5, f"w/sigma {shape}")

@@ -62,6 +62,7 @@ SYMBOLS = {
     "vmasr_xproj_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "vmasr_xproj_fwd": (ctypes.c_int, [c_vp] * 7 + [c_i32] * 7 + [c_vp]),
     "vmasr_xproj_bwd": (ctypes.c_int, [c_vp] * 12 + [c_i32] * 7 + [c_vp]),
+    "vmasr_spectral_power_iter": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, ctypes.c_float, c_vp]),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -123,7 +124,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 26
+K_COUNT = 27
 
 
 def prof_enable(on=True):

@@ -35,6 +35,18 @@ class _SpectralNorm(nn.Module):
 
     @torch.autograd.no_grad()
     def _power_method(self, w, n):
+        if w.is_cuda and n > 0 and w.dtype == torch.float32:
+            import ctypes
+            from . import _lib
+            w = w.contiguous()
+            R, C = w.shape
+            ws = torch.empty(R + C, dtype=torch.float32, device=w.device)
+            p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+            with torch.cuda.device(w.device):
+                _lib.check(_lib.lib().vmasr_spectral_power_iter(p(w), p(self._u), p(self._v), p(ws), R, C, int(n),
+                                                                float(self.eps), _lib.current_stream(w.device)),
+                           "spectral_power_iter")
+            return
         for _ in range(n):
             self._u = F.normalize((w @ self._v.unsqueeze(1)).squeeze(1), dim=0, eps=self.eps, out=self._u)
             self._v = F.normalize((w.t() @ self._u.unsqueeze(1)).squeeze(1), dim=0, eps=self.eps, out=self._v)
@@ -82,8 +94,10 @@ class PeriodDiscriminator(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.conv_post = norm(nn.Conv2d(hidden * 32, 1, (3, 1), 1, padding=(1, 0)))
 
-    def forward(self, x):
-        """Feature maps are returned channel-last (B, period, T', C): the losses that consume them
+    def forward(self, x, detach_weights=False):
+        """`detach_weights`: use the (spectrally normalised) weights as constants — the generator's pass
+        through the discriminator, where no discriminator gradient is wanted.
+        Feature maps are returned channel-last (B, period, T', C): the losses that consume them
         (L1 feature matching, LSGAN means) are layout-agnostic; the flattened score matches the
         reference's element set."""
         fmap = []
@@ -92,19 +106,23 @@ class PeriodDiscriminator(nn.Module):
             n_pad = self.period - (t % self.period)
             x = F.pad(x, (0, n_pad), "reflect")
             t = t + n_pad
+        wb = (lambda l: (l.weight.detach(), l.bias.detach())) if detach_weights else (lambda l: (l.weight, l.bias))
         if not x.is_cuda:  # host/CPU runs (tests, cpu_baseline) keep the plain convolutions
             x = x.view(b, c, t // self.period, self.period)
-            for layer in self.layers:
-                x = F.gelu(layer(x))
+            for layer in list(self.layers) + [self.conv_post]:
+                w, bias = wb(layer)
+                x = F.conv2d(x, w, bias, layer.stride, layer.padding)
+                if layer is not self.conv_post:
+                    x = F.gelu(x)
                 fmap.append(x)
-            x = self.conv_post(x)
-            fmap.append(x)
             return torch.flatten(x, 1, -1), fmap
         x = x.view(b, c, t // self.period, self.period).permute(0, 3, 2, 1)  # (B, P, T', C=1)
         for layer in self.layers:
-            x = F.gelu(_conv_kx1_cl(x, layer.weight, layer.bias, layer.stride[0], layer.padding[0]))
+            w, bias = wb(layer)
+            x = F.gelu(_conv_kx1_cl(x, w, bias, layer.stride[0], layer.padding[0]))
             fmap.append(x)
-        x = _conv_kx1_cl(x, self.conv_post.weight, self.conv_post.bias, 1, self.conv_post.padding[0])
+        w, bias = wb(self.conv_post)
+        x = _conv_kx1_cl(x, w, bias, 1, self.conv_post.padding[0])
         fmap.append(x)
         return torch.flatten(x, 1, -1), fmap
 
@@ -114,15 +132,29 @@ class MultiPeriodDiscriminator(nn.Module):
         super().__init__()
         self.discriminators = nn.ModuleList([PeriodDiscriminator(p, hidden=hidden) for p in periods])
 
-    def forward_single(self, x):
+    def forward_single(self, x, detach_weights=False):
         """scores and feature maps of ONE signal batch (used for the generator pass, where the
         real-signal features of the discriminator pass are reused instead of recomputed)."""
         ys, fmaps = [], []
         for disc in self.discriminators:
-            y, f = disc(x)
+            y, f = disc(x, detach_weights)
             ys.append(y)
             fmaps.append(f)
         return ys, fmaps
+
+    def forward_pair(self, y, y_hat):
+        """Same results as forward(y, y_hat) with ONE pass per discriminator over the stacked batch
+        [y; y_hat] (same weights, identical per-sample arithmetic, half the kernel launches)."""
+        n = y.shape[0]
+        y_real, y_gen, fmap_real, fmap_gen = [], [], [], []
+        for disc in self.discriminators:
+            s, f = disc(torch.cat((y, y_hat), dim=0))
+            y_real.append(s[:n]); y_gen.append(s[n:])
+            fmap_real.append([t[:n] for t in f]); fmap_gen.append([t[n:] for t in f])
+        return y_real, y_gen, fmap_real, fmap_gen
+
+    def spectral_norms(self):
+        return [m for m in self.modules() if isinstance(m, _SpectralNorm)]
 
     def forward(self, y, y_hat):
         y_real, y_gen, fmap_real, fmap_gen = [], [], [], []

@@ -322,18 +322,11 @@ class Trainer(BaseTrainer):
         if "multi_resolution_stft" in cfg.LOSSES.GEN:
             out["multi_resolution_stft"] = self._get_stft_loss(wave_out, wave_target)
         if self.gan and "mpd" in cfg.ADVERSARIAL.DISCRIMINATORS:
-            mpd = unwrap(self.models["mpd"])  # frozen pass: no MPD gradients, no DDP hooks
-            flags = [p.requires_grad for p in mpd.parameters()]
-            for p in mpd.parameters():
-                p.requires_grad_(False)
-            try:
-                if fmap_real is None:  # the reference recomputes the real-signal features here
-                    with torch.no_grad():
-                        _, fmap_real = mpd.forward_single(wave_target)
-                y_gen, fmap_gen = mpd.forward_single(wave_out)
-            finally:
-                for p, f in zip(mpd.parameters(), flags):
-                    p.requires_grad_(f)
+            mpd = unwrap(self.models["mpd"])  # weights used as constants: no MPD gradients, no DDP hooks
+            if fmap_real is None:  # the reference recomputes the real-signal features here
+                with torch.no_grad():
+                    _, fmap_real = mpd.forward_single(wave_target, detach_weights=True)
+            y_gen, fmap_gen = mpd.forward_single(wave_out, detach_weights=True)
             if not cfg.ADVERSARIAL.ONLY_FEATURE_LOSS:
                 out["adversarial_mpd"] = self.higi_gan_loss.generator_loss(y_gen)
             if not cfg.ADVERSARIAL.ONLY_ADVERSARIAL_LOSS:
@@ -346,7 +339,8 @@ class Trainer(BaseTrainer):
         out, fmap_real = {}, None
         if self.gan and "mpd" in self.config.TRAIN.ADVERSARIAL.DISCRIMINATORS:
             fake = wave_out.detach().float()
-            y_real, y_gen, fr, _ = self.models["mpd"](wave_target, fake)
+            mpd = self.models["mpd"]
+            y_real, y_gen, fr, _ = (mpd(wave_target, fake) if isinstance(mpd, DDP) else mpd.forward_pair(wave_target, fake))
             fmap_real = [[f.detach() for f in fs] for fs in fr]
             d = self.higi_gan_loss.discriminator_loss(y_real, y_gen)
             if self.config.TRAIN.ADVERSARIAL.GAN_LOSS_TYPE == "wgan-gp":
@@ -402,8 +396,9 @@ class Trainer(BaseTrainer):
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
             wave_out = self.models["generator"](wave_input, highcut)
             # D loss first, with the same D weights the G pass sees (reference order, trainer/trainer.py:369-399)
-            d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
-            g_losses = self._generator_losses(wave_out, wave_target, fmap_real)
+            with self._mpd_weights_once():
+                d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
+                g_losses = self._generator_losses(wave_out, wave_target, fmap_real)
         total_g = sum(g_losses.values()) / acc
         self._zero_grads("generator", self.optimizer_G)
         total_g.backward()
@@ -415,6 +410,33 @@ class Trainer(BaseTrainer):
             total_d.backward()
             logs["total_disc_loss"] = total_d.detach()
         return wave_out.detach(), logs
+
+    def _mpd_weights_once(self):
+        """The reference evaluates every spectrally-normalised MPD weight three times per step (real
+        and fake in the D pass, fake in the G pass), one power iteration each, although the weights do
+        not change in between.  Here the three power iterations run back to back at the first use
+        (same u/v state after the step) and the normalised weight is computed once and reused
+        (torch.nn.utils.parametrize.cached): the three passes see the sigma of the third iteration
+        instead of the first / second / third — a difference that vanishes as u, v converge."""
+        import contextlib
+        from torch.nn.utils import parametrize
+        mpd = unwrap(self.models.get("mpd")) if self.gan else None
+        if mpd is None or not mpd.training or not hasattr(mpd, "spectral_norms"):
+            return contextlib.nullcontext()
+        sns = mpd.spectral_norms()
+
+        @contextlib.contextmanager
+        def ctx():
+            saved = [m.n_power_iterations for m in sns]
+            for m in sns:
+                m.n_power_iterations = 3 * saved[0] if saved else 3
+            try:
+                with parametrize.cached():
+                    yield
+            finally:
+                for m, n in zip(sns, saved):
+                    m.n_power_iterations = n
+        return ctx()
 
     def _reduce_and_step(self):
         self._reduce_grads("generator")
