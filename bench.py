@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     args = ap.parse_args()
+    if os.environ.get("VMASR_BENCH_WATCHDOG"):      # debugging aid: dump all stacks and exit if the run wedges
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VMASR_BENCH_WATCHDOG"]), exit=True)
 
     from vm_asr_amd import _lib
     from vm_asr_amd.trainer import init_distributed

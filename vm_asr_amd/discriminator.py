@@ -12,6 +12,8 @@ import torch.nn.functional as F
 from torch.nn.utils import parametrize
 from torch.nn.utils.parametrizations import weight_norm
 
+from .streams import parallel as _parallel
+
 __all__ = ["PeriodDiscriminator", "MultiPeriodDiscriminator", "spectral_norm"]
 
 
@@ -135,20 +137,16 @@ class MultiPeriodDiscriminator(nn.Module):
     def forward_single(self, x, detach_weights=False):
         """scores and feature maps of ONE signal batch (used for the generator pass, where the
         real-signal features of the discriminator pass are reused instead of recomputed)."""
-        ys, fmaps = [], []
-        for disc in self.discriminators:
-            y, f = disc(x, detach_weights)
-            ys.append(y)
-            fmaps.append(f)
-        return ys, fmaps
+        res = _parallel([(lambda d=d: d(x, detach_weights)) for d in self.discriminators], x.device, "d")
+        return [r[0] for r in res], [r[1] for r in res]
 
     def forward_pair(self, y, y_hat):
         """Same results as forward(y, y_hat) with ONE pass per discriminator over the stacked batch
         [y; y_hat] (same weights, identical per-sample arithmetic, half the kernel launches)."""
         n = y.shape[0]
         y_real, y_gen, fmap_real, fmap_gen = [], [], [], []
-        for disc in self.discriminators:
-            s, f = disc(torch.cat((y, y_hat), dim=0))
+        both = torch.cat((y, y_hat), dim=0)
+        for s, f in _parallel([(lambda d=d: d(both)) for d in self.discriminators], y.device, "d"):
             y_real.append(s[:n]); y_gen.append(s[n:])
             fmap_real.append([t[:n] for t in f]); fmap_gen.append([t[n:] for t in f])
         return y_real, y_gen, fmap_real, fmap_gen

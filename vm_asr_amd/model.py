@@ -31,6 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .stft import spectro2wav, wav2spectro
+from .streams import parallel as _parallel
 from .layernorm import LayerNorm
 from .linear import linear as _linear
 from .vmamba import PatchMerging2D, Permute, VSSBlock
@@ -235,14 +236,14 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
         residual_mag = mag
         single = self.interact == "single"
 
-        mag = self.patch_embed_mag(mag)
-        skips_m = [mag]
+        dev = x.device
         if not single:
-            phase = self.patch_embed_phase(phase)
-            skips_p = [phase]
+            # the two streams are independent between interaction points: fork them onto two HIP streams
+            mag, phase = _parallel([lambda: self.patch_embed_mag(mag), lambda: self.patch_embed_phase(phase)], dev, "g")
+            skips_m, skips_p = [mag], [phase]
             for i in range(self.num_layers):
-                mag = self.layers_encoder_mag[i](mag)
-                phase = self.layers_encoder_phase[i](phase)
+                mag, phase = _parallel([lambda: self.layers_encoder_mag[i](mag),
+                                        lambda: self.layers_encoder_phase[i](phase)], dev, "g")
                 if i < self.num_layers - 1:
                     skips_m.append(mag)
                     skips_p.append(phase)
@@ -264,11 +265,14 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
                 mag, phase = self._interact(mag, phase)
             ms, ps = skips_m.pop(), skips_p.pop()
             if self.concat_skip:
-                mag = self.output_layer_mag(torch.cat((mag, ms), dim=-1))
-                phase = self.output_layer_phase(torch.cat((phase, ps), dim=-1))
+                mag, phase = _parallel([lambda: self.output_layer_mag(torch.cat((mag, ms), dim=-1)),
+                                        lambda: self.output_layer_phase(torch.cat((phase, ps), dim=-1))], dev, "g")
             else:
-                mag, phase = self.output_layer_mag(mag + ms), self.output_layer_phase(phase + ps)
+                mag, phase = _parallel([lambda: self.output_layer_mag(mag + ms),
+                                        lambda: self.output_layer_phase(phase + ps)], dev, "g")
         else:
+            mag = self.patch_embed_mag(mag)
+            skips_m = [mag]
             for i in range(self.num_layers):
                 mag = self.layers_encoder_mag[i](mag)
                 if i < self.num_layers - 1:
