@@ -151,3 +151,50 @@ def test_reference_parameter_count_and_keys():
     z = np.load(os.path.join(GOLDEN, "model_tiny.npz"))
     tiny = _tiny_model()
     assert sorted(tiny.state_dict().keys()) == sorted(k[4:] for k in z.files if k.startswith("sd::"))
+
+
+def test_splitk_linear_matches_f_linear():
+    """The split-K weight-gradient linear (vm_asr_amd/linear.py) is F.linear with a re-associated dW sum."""
+    from vm_asr_amd.linear import _SplitKLinearFn, splitk_plan, weight_grad
+    torch.manual_seed(0)
+    assert splitk_plan(327040, 32, 5) >= 4 and splitk_plan(1024, 32, 5) < 4 and splitk_plan(65536, 1024, 5120) < 4
+    gy, xx = torch.randn(10007, 8), torch.randn(10007, 3)
+    assert torch.allclose(weight_grad(gy, xx, splits=7), gy.t() @ xx, rtol=1e-4, atol=1e-3)
+    x = torch.randn(3, 5000, 6, requires_grad=True, dtype=torch.double)
+    w = torch.randn(4, 6, requires_grad=True, dtype=torch.double)
+    b = torch.randn(4, requires_grad=True, dtype=torch.double)
+    _SplitKLinearFn.apply(x, w, b, torch.double).square().sum().backward()
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    torch.nn.functional.linear(x, w, b).square().sum().backward()
+    for g, t in zip(got, (x, w, b)):
+        assert torch.allclose(g, t.grad, rtol=1e-10, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_splitk_linear_gpu(dtype):
+    """linear() on many rows x small weight takes the split-K path on the GPU: same y, dx, dW, db as F.linear."""
+    from vm_asr_amd.linear import linear, splitk_plan
+    torch.manual_seed(1)
+    rows, in_f, out_f = 65536 + 40, 16, 64
+    assert splitk_plan(rows, out_f, in_f) >= 4
+    x = torch.randn(4, rows // 4, in_f, device="cuda", requires_grad=True)
+    w = (0.2 * torch.randn(out_f, in_f, device="cuda")).requires_grad_()
+    b = torch.randn(out_f, device="cuda", requires_grad=True)
+    gy = torch.randn(4, rows // 4, out_f, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        y = linear(x, w, b)
+        assert y.dtype == dtype
+        y.backward(gy.to(dtype))
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref.backward(gy.double())
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert (y.double() - ref).abs().max() <= tol * ref.abs().max()
+    for g, t in zip(got, (x, w, b)):
+        assert g.dtype == torch.float32
+        assert (g.double() - t.grad.double()).abs().max() <= tol * t.grad.abs().max(), (g - t.grad).abs().max()

@@ -20,5 +20,5 @@ rows = prof.key_averages(group_by_input_shape=True)
 rows = sorted(rows, key=lambda r: -r.self_device_time_total)
 tot = sum(r.self_device_time_total for r in rows)
 print(f"total device time {tot/1e3:.1f} ms")
-for r in rows[:40]:
-    print(f"{r.self_device_time_total/1e3:8.2f} ms {r.count:5d}x  {r.key[:40]:40s} {str(r.input_shapes)[:110]}")
+for r in rows[:int(os.environ.get("TOP", 40))]:
+    print(f"{r.self_device_time_total/1e3:8.2f} ms {r.count:5d}x  {r.key[:40]:40s} {str(r.input_shapes)[:150]}")

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from torch.nn.utils import parametrize
 from torch.nn.utils.parametrizations import weight_norm
 
+from .linear import linear as _linear
 from .streams import parallel as _parallel
 
 __all__ = ["PeriodDiscriminator", "MultiPeriodDiscriminator", "spectral_norm"]
@@ -79,7 +80,7 @@ def _conv_kx1_cl(x, weight, bias, stride, pad):
     cols = x.unfold(2, k, stride)                      # (B, P, T_out, Cin, k) view
     Bn, P, To, Cin, _ = cols.shape
     w = weight[:, :, :, 0].reshape(weight.shape[0], Cin * k).to(x.dtype)   # (Cout, Cin*k), (c,k) order
-    y = F.linear(cols.reshape(Bn, P, To, Cin * k), w, None if bias is None else bias.to(x.dtype))
+    y = _linear(cols.reshape(Bn, P, To, Cin * k), w, None if bias is None else bias.to(x.dtype))
     return y
 
 

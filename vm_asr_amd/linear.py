@@ -1,7 +1,13 @@
-"""nn.Linear that routes tiny-feature / many-row cases to the HIP row-map kernels
-(vm_asr_amd/csrc/linear.hip): the d_model = 1 VSS block of the output layer and the 4->1
-pointwise conv in front of it (model/model.py:862-885).  Everything else stays F.linear
-(hipBLASLt).  Same parameters and state_dict keys as nn.Linear.
+"""nn.Linear for the shapes of this path.  Same parameters and state_dict keys as nn.Linear.
+
+* tiny-feature / many-row cases go to the HIP row-map kernels (vm_asr_amd/csrc/linear.hip): the
+  d_model = 1 VSS block of the output layer and the 4->1 pointwise conv in front of it
+  (model/model.py:862-885);
+* many-row cases with a small weight (every projection of the high-resolution stages, the first MPD
+  convolutions: rows = B*H*W up to 10^6, weight 32x5 ... 128x160) keep hipBLASLt for y and dx, but
+  compute the weight gradient  dW = gy^T x  as a split-K batched GEMM: as one GEMM it is a single
+  output tile reduced over all rows on one or two CUs (measured 170-380 us each, 12 ms/step);
+* everything else stays F.linear.
 """
 import ctypes
 
@@ -64,14 +70,73 @@ class _SmallLinearFn(torch.autograd.Function):
         return (dx.view(shape) if need_dx else None, dw.to(wdt), db.to(bdt) if bdt is not None else None, None)
 
 
+def splitk_plan(rows, out_f, in_f):
+    """Number of K-splits for dW (out_f, in_f) = gy^T (out_f, rows) @ x (rows, in_f); 1 = plain GEMM."""
+    tiles = -(-out_f // 64) * -(-in_f // 64)          # output tiles one GEMM would spread over the CUs
+    return min(rows // 2048, max(1, 512 // tiles))
+
+
+def weight_grad(gy2, x2, splits=None):
+    """dW (fp32 for 16-bit inputs) = gy2^T @ x2 for row-major (rows, out_f), (rows, in_f); split over the rows into a
+    batched GEMM + an fp32 sum of the partial products when the output is only a few tiles."""
+    rows, out_f = gy2.shape
+    in_f = x2.shape[1]
+    S = splitk_plan(rows, out_f, in_f) if splits is None else splits
+    acc = torch.float32 if gy2.dtype in (torch.float16, torch.bfloat16) else gy2.dtype
+    if S < 4:
+        return (gy2.t() @ x2).to(acc)
+    chunk = rows // S
+    main = chunk * S
+    part = torch.bmm(gy2[:main].view(S, chunk, out_f).transpose(1, 2), x2[:main].view(S, chunk, in_f))
+    dw = part.sum(0, dtype=acc)
+    if main < rows:
+        dw += (gy2[main:].t() @ x2[main:]).to(acc)
+    return dw
+
+
+class _SplitKLinearFn(torch.autograd.Function):
+    """F.linear whose weight gradient is the split-K GEMM above (inputs are cast to the autocast
+    dtype here, so dW is accumulated across splits in fp32 and returned in the parameter's dtype)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cdt):
+        out_f, in_f = weight.shape
+        x2 = x.reshape(-1, in_f).to(cdt)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        wc = weight.detach().to(cdt)
+        y = F.linear(x2, wc, None if bias is None else bias.detach().to(cdt))
+        ctx.save_for_backward(x2, wc)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y.view(*x.shape[:-1], out_f)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, wc = ctx.saved_tensors
+        shape, xdt, wdt, bdt = ctx.meta
+        gy2 = gy.reshape(x2.shape[0], wc.shape[0]).to(x2.dtype)
+        if not gy2.is_contiguous():
+            gy2 = gy2.contiguous()
+        dx = (gy2 @ wc).view(shape).to(xdt) if ctx.needs_input_grad[0] else None
+        dw = weight_grad(gy2, x2).to(wdt) if ctx.needs_input_grad[1] else None
+        db = gy2.sum(0, dtype=torch.float32 if gy2.dtype != torch.float64 else None).to(bdt) if bdt is not None and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
 def linear(x, weight, bias=None):
-    """F.linear; tiny in/out features over many GPU rows go to the HIP row-map kernel."""
+    """F.linear; tiny in/out features over many GPU rows go to the HIP row-map kernel, many rows with a
+    small weight get the split-K weight gradient."""
     out_f, in_f = weight.shape
     if (x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.numel() // max(1, in_f) >= _MIN_ROWS
             and _lib.lib().vmasr_small_linear_supported(in_f, out_f)):
         out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
         if out_dtype == x.dtype or x.dtype == torch.float32:
             return _SmallLinearFn.apply(x, weight, bias, out_dtype)
+    if x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and x.is_floating_point():
+        rows = x.numel() // max(1, in_f)
+        if splitk_plan(rows, out_f, in_f) >= 4:
+            cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+            return _SplitKLinearFn.apply(x, weight, bias, cdt)
     return F.linear(x, weight, bias)
 
 

@@ -33,7 +33,7 @@ import torch.nn.functional as F
 from .stft import spectro2wav, wav2spectro
 from .streams import parallel as _parallel
 from .layernorm import LayerNorm
-from .linear import linear as _linear
+from .linear import Linear as _Linear, linear as _linear
 from .vmamba import PatchMerging2D, Permute, VSSBlock
 
 __all__ = ["PatchMerging2D", "PatchExpanding", "MambaUNet", "DualStreamInteractiveMambaUNet"]
@@ -45,7 +45,7 @@ class PatchExpanding(nn.Module):
     def __init__(self, dim, dim_scale=2, norm_layer=LayerNorm):
         super().__init__()
         self.dim = dim
-        self.expand = nn.Linear(dim, 2 * dim, bias=False) if dim_scale == 2 else nn.Identity()
+        self.expand = _Linear(dim, 2 * dim, bias=False) if dim_scale == 2 else nn.Identity()
         self.norm = norm_layer(dim // dim_scale) if norm_layer is not None else nn.Identity()
 
     def forward(self, x):
@@ -75,7 +75,7 @@ class GemmConv2d(nn.Conv2d):
         cols = F.unfold(x, self.kernel_size, padding=self.padding, stride=self.stride)  # (B, C*kh*kw, Ho*Wo)
         # pixels as the GEMM's M dimension: (B*Ho*Wo, C*kh*kw) @ (C*kh*kw, Cout).  The batched
         # (Cout x K) @ (K x Ho*Wo) form picks a 32x32 hipBLASLt tile and takes 1.5 ms per call.
-        y = F.linear(cols.transpose(1, 2), self.weight.flatten(1), self.bias)            # (B, Ho*Wo, Cout)
+        y = _linear(cols.transpose(1, 2), self.weight.flatten(1), self.bias)            # (B, Ho*Wo, Cout)
         return y.transpose(1, 2).reshape(B, -1, Ho, Wo)
 
 

@@ -372,7 +372,7 @@ class PatchMerging2D(nn.Module):
     def __init__(self, dim, out_dim=-1, norm_layer=LayerNorm, **kwargs):
         super().__init__()
         self.dim = dim
-        self.reduction = nn.Linear(4 * dim, (2 * dim) if out_dim < 0 else out_dim, bias=False)
+        self.reduction = _Linear(4 * dim, (2 * dim) if out_dim < 0 else out_dim, bias=False)
         self.norm = norm_layer(4 * dim)
         if isinstance(self.norm, LayerNorm):
             self.norm.feeds_gemm = True  # -> reduction
