@@ -52,7 +52,7 @@ def run(KD, L, tune, iters=20):
 if __name__ == "__main__":
     print(f"B={B}")
     for KD, L in SHAPES:
-        for tune in ((-1, -1), (1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2)):
+        for tune in [(-1, -1)] + ([(1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2)] if os.environ.get("SWEEP", "1") == "1" else []):
             if tune[0] > 0 and (KD // 4) % tune[0]:
                 continue
             tf, gf, tb, gb = run(KD, L, tune)

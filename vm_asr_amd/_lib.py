@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvmasr_hip.so")
+LIB_PATH = os.environ.get("VMASR_LIB") or os.path.join(_HERE, "libvmasr_hip.so")   # VMASR_LIB: A/B builds (dev)
 
 c_i32, c_i64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
 

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
     __shared__ float2 s_tot[MODE == 3 ? 2 * kMaxBlockWaves * R : 1];
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row pointers live in SGPRs
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
     TaskMap m;
     int W = 1;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
     extern __shared__ __attribute__((aligned(16))) float s_red[];  // dB / dC partials: 2 x W x 256 floats (W > 1 only)
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row pointers live in SGPRs
     const int W = geo.W;
     const int L = p.seqlen, N = DYN ? p.dstate : 1;
     const int ntiles = (L + kTile - 1) / kTile;

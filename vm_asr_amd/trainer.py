@@ -256,7 +256,8 @@ class Trainer(BaseTrainer):
         "ddp" = torch DistributedDataParallel buckets overlapped with backward."""
         super().__init__(models, metric_ftns, optimizers, config, logger)
         self.dp_mode = dp_mode
-        self._flat = {}
+        self._flat, self._flat_params, self._flat_views = {}, {}, {}
+        self._gather = config.TRAIN.ACCUMULATION_STEPS == 1   # fresh grads are packed, not accumulated in place
         self._graphed = None
         self.device = device[0] if isinstance(device, (tuple, list)) else device
         self.data_loader, self.data_loader_val = data_loader_train, data_loader_val
@@ -371,13 +372,38 @@ class Trainer(BaseTrainer):
             p.grad = view
             off += n
         self._flat[key] = flat
+        self._flat_params[key] = used
+        self._flat_views[key] = [p.grad for p in used]
         return flat
 
     def _zero_grads(self, key, optimizer):
+        """Before a backward.  With a flat buffer and no gradient accumulation the parameters' grads are
+        dropped so that autograd hands over each gradient tensor as produced (no `grad += g` kernel per
+        parameter: 640 launches a step); _gather_grads() then packs them into the flat buffer."""
         if key in self._flat:
-            self._flat[key].zero_()
+            if self._gather:
+                for p in self._flat_params[key]:
+                    p.grad = None
+            else:
+                self._flat[key].zero_()
         else:
             optimizer.zero_grad(set_to_none=True)
+
+    def _gather_grads(self, key):
+        """After a backward: multi-tensor copy of the fresh gradients into the flat buffer's views, which
+        become the parameters' .grad again (what the all-reduce and the fused AdamW read)."""
+        if key not in self._flat or not self._gather:
+            return
+        params, views = self._flat_params[key], self._flat_views[key]
+        src, dst = [], []
+        for p, v in zip(params, views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                src.append(p.grad)
+                dst.append(v)
+            p.grad = v
+        torch._foreach_copy_(dst, src)
 
     def _reduce_grads(self, key):
         """ONE all-reduce per model per step over RCCL/xGMI (generator 9 MB, MPD 164 MB fp32)."""
@@ -402,12 +428,14 @@ class Trainer(BaseTrainer):
         total_g = sum(g_losses.values()) / acc
         self._zero_grads("generator", self.optimizer_G)
         total_g.backward()
+        self._gather_grads("generator")
         logs = {"total_loss": total_g.detach()}
         logs.update({f"generator/{k}": v.detach() for k, v in g_losses.items()})
         if self.gan:
             total_d = sum(d_losses.values()) / acc
             self._zero_grads("mpd", self.optimizer_D)
             total_d.backward()
+            self._gather_grads("mpd")
             logs["total_disc_loss"] = total_d.detach()
         return wave_out.detach(), logs
 
