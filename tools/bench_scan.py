@@ -6,6 +6,7 @@ from vm_asr_amd import selective_scan as ss
 
 SHAPES = [(8, 262144), (64, 65536), (128, 16384), (256, 4096), (512, 1024), (1024, 256)]
 B = int(os.environ.get("B", 4))
+SP = os.environ.get("SOFTPLUS", "1") == "1"
 dev = "cuda:0"
 
 
@@ -20,16 +21,16 @@ def run(KD, L, tune, iters=20):
     bias = 0.5 * torch.rand(KD, device=dev, generator=g)
     dout = torch.randn(B, KD, L, device=dev, generator=g)
     ss.tune(*tune)
-    out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
-    ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
+    out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, SP, 1)
+    ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, SP, 1)
     torch.cuda.synchronize()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record()
     for _ in range(iters):
-        out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
+        out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, SP, 1)
     e1.record()
     for _ in range(iters):
-        ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
+        ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, SP, 1)
     e2.record()
     torch.cuda.synchronize()
     tf, tb = e0.elapsed_time(e1) / iters * 1e-3, e1.elapsed_time(e2) / iters * 1e-3
@@ -37,9 +38,9 @@ def run(KD, L, tune, iters=20):
         from vm_asr_amd import _lib
         _lib.prof_reset(); _lib.prof_enable(True)
         for _ in range(iters):
-            out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
+            out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, SP, 1)
         for _ in range(iters):
-            ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
+            ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, SP, 1)
         _lib.prof_enable(False)
         pr = _lib.prof_collect()
         tf = sum(v["ms"] for k, v in pr.items() if k.startswith("sscan_fwd")) / iters * 1e-3

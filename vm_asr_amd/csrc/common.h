@@ -82,6 +82,45 @@ __device__ __forceinline__ void load4(const T *__restrict__ p, int t, int len, f
     }
 }
 
+// Same with a wave-uniform `full` (the whole wave's 256-element tile is in range and the rows are
+// vector-aligned): the choice is a scalar branch, not a per-lane one, so full tiles are straight-line
+// vector loads the scheduler can hoist and keep in flight.
+template <typename T, bool VEC>
+__device__ __forceinline__ void load4u(const T *__restrict__ p, int t, int len, float (&v)[4], bool full) {
+    if (VEC && full) {
+        if constexpr (sizeof(T) == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(p + t);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            union { uint2 raw; T e[4]; } q;
+            q.raw = *reinterpret_cast<const uint2 *>(p + t);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = to_f32(q.e[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (t + i < len) ? to_f32(p[t + i]) : 0.f;
+    }
+}
+
+template <typename T, bool VEC>
+__device__ __forceinline__ void store4u(T *__restrict__ p, int t, int len, const float (&v)[4], bool full) {
+    if (VEC && full) {
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4 *>(p + t) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            union { uint2 raw; T e[4]; } q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q.e[i] = from_f32<T>(v[i]);
+            *reinterpret_cast<uint2 *>(p + t) = q.raw;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t + i < len) p[t + i] = from_f32<T>(v[i]);
+    }
+}
+
 template <typename T, bool VEC>
 __device__ __forceinline__ void store4(T *__restrict__ p, int t, int len, const float (&v)[4]) {
     if (VEC && t + 3 < len) {

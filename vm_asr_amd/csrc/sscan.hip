@@ -42,6 +42,10 @@ constexpr int kMaxDState = 256;
 constexpr int kMaxBlockWaves = 16;
 static_assert(kTile == VMASR_SSCAN_CHUNK, "tile must equal the saved-state chunk");
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, not for its
+// outstanding global loads and stores (__syncthreads() carries a full fence = s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct Pair {
     float a, b;  // h -> a*h + b
 };
@@ -229,11 +233,12 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
     for (int tbase = m.tile0, it = 0; tbase < m.tile1; tbase += step, ++it) {
         const int tile = MODE == 3 ? tbase + wave : tbase;
         const int t0 = tile * kTile + lane * kItems;  // >= L for the idle waves of a ragged block
+        const bool full = (tile + 1) * kTile <= L;    // wave-uniform: straight-line vector loads / stores
         float uv[R][kItems], dl[R][kItems], outv[R][kItems];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            load4<T, VEC>(u_row[r], t0, L, uv[r]);
-            load4<T, VEC>(dl_row[r], t0, L, dl[r]);
+            load4u<T, VEC>(u_row[r], t0, L, uv[r], full);
+            load4u<T, VEC>(dl_row[r], t0, L, dl[r], full);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -243,20 +248,26 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
                 dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
                 outv[r][i] = Dv[r] * uv[r][i];
             }
+        if (!full) {  // ragged tile: steps past the end get delta = 0, i.e. a = 1, b = 0 (identity)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < kItems; ++i)
+                    if (t0 + i >= L) dl[r][i] = 0.f;
+        }
 
         for (int n = 0; n < N; ++n) {
             float Bv[kItems], Cv[kItems];
-            load4<T, VEC>(Bg + n * p.B_dstate_stride, t0, L, Bv);
-            if (MODE != 2) load4<T, VEC>(Cg + n * p.C_dstate_stride, t0, L, Cv);
+            load4u<T, VEC>(Bg + n * p.B_dstate_stride, t0, L, Bv, full);
+            if (MODE != 2) load4u<T, VEC>(Cg + n * p.C_dstate_stride, t0, L, Cv, full);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float An = DYN ? Ap[(m.d0 + r) * p.A_d_stride + n * p.A_dstate_stride] * kLog2e : An1[r];
                 float a[kItems], bb[kItems];
 #pragma unroll
                 for (int i = 0; i < kItems; ++i) {
-                    const bool in = t0 + i < L;
-                    a[i] = in ? __builtin_amdgcn_exp2f(dl[r][i] * An) : 1.f;
-                    bb[i] = in ? dl[r][i] * uv[r][i] * Bv[i] : 0.f;
+                    a[i] = __builtin_amdgcn_exp2f(dl[r][i] * An);
+                    bb[i] = dl[r][i] * uv[r][i] * Bv[i];
                 }
                 Pair agg{a[0], bb[0]};
 #pragma unroll
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
                         // exchange tile totals; carry-in = running state composed with the waves before
                         float2 *slot = s_tot + ((it & 1) * kMaxBlockWaves) * R;
                         if (lane == 0) slot[wave * R + r] = make_float2(tot.a, tot.b);
-                        __syncthreads();
+                        lds_barrier();
                         float hrun = h_in[r];
                         hin = hrun;
                         for (int w = 0; w < W; ++w) {
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
         }
         if constexpr (MODE != 2) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) store4<T, VEC>(out_row[r], t0, L, outv[r]);
+            for (int r = 0; r < R; ++r) store4u<T, VEC>(out_row[r], t0, L, outv[r], full);
         }
     }
 }
@@ -409,11 +420,12 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
 
     const T *u_row[R], *dl_row[R], *do_row[R];
     T *du_row[R], *dd_row[R];
-    float Dv[R], bias[R], g_in[R], a_nx[R], accA[R], accD[R], accBias[R];
+    float Dv[R], bias[R], g_in[R], a_nx[R], accA[R], accD[R], accBias[R], A1[R];
     const size_t xrow0 = ((size_t)b * p.dim + d0) * p.n_chunks;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int d = d0 + r;
+        A1[r] = DYN ? 0.f : Ap[d * p.A_d_stride];  // d_state 1: loop-invariant (no load inside the tile loop)
         u_row[r] = static_cast<const T *>(p.u_ptr) + b * p.u_batch_stride + d * p.u_d_stride;
         dl_row[r] = static_cast<const T *>(p.delta_ptr) + b * p.delta_batch_stride + d * p.delta_d_stride;
         do_row[r] = static_cast<const T *>(q.dout_ptr) + b * q.dout_batch_stride + d * q.dout_d_stride;
@@ -466,12 +478,13 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
 
     for (int tile = tile1 - 1; tile >= tile0; --tile) {
         const int t0 = tile * kTile + lane * kItems;
+        const bool full = (tile + 1) * kTile <= L;  // wave-uniform
         float uv[R][kItems], dl[R][kItems], dov[R][kItems], duv[R][kItems], ddv[R][kItems], sig[R][kItems];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            load4<T, VEC>(dl_row[r], t0, L, dl[r]);
-            load4<T, VEC>(do_row[r], t0, L, dov[r]);
-            if (MODE != 2) load4<T, VEC>(u_row[r], t0, L, uv[r]);
+            load4u<T, VEC>(dl_row[r], t0, L, dl[r], full);
+            load4u<T, VEC>(do_row[r], t0, L, dov[r], full);
+            if (MODE != 2) load4u<T, VEC>(u_row[r], t0, L, uv[r], full);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -479,6 +492,7 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
             for (int i = 0; i < kItems; ++i) {
                 const float v = dl[r][i] + bias[r];
                 dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
+                if (!full && t0 + i >= L) dl[r][i] = 0.f;  // ragged tile: identity steps (a = 1, b = 0)
                 if (MODE != 2) {
                     // d softplus / dv = sigmoid(v) (1 above the threshold)
                     sig[r][i] = (p.delta_softplus && v <= 20.f) ? __fdividef(1.f, 1.f + __expf(-v)) : 1.f;
@@ -490,17 +504,17 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
 
         for (int n = 0; n < N; ++n) {
             float Bv[kItems], Cv[kItems], dBv[kItems], dCv[kItems];
-            load4<T, VEC>(Cg + n * p.C_dstate_stride, t0, L, Cv);
-            if (MODE != 2) load4<T, VEC>(Bg + n * p.B_dstate_stride, t0, L, Bv);
+            load4u<T, VEC>(Cg + n * p.C_dstate_stride, t0, L, Cv, full);
+            if (MODE != 2) load4u<T, VEC>(Bg + n * p.B_dstate_stride, t0, L, Bv, full);
 #pragma unroll
             for (int i = 0; i < kItems; ++i) { dBv[i] = 0.f; dCv[i] = 0.f; }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float Araw = Ap[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride];
+                const float Araw = DYN ? Ap[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride] : A1[r];
                 const float An = Araw * kLog2e;
                 float a[kItems], al[kItems], be[kItems];
 #pragma unroll
-                for (int i = 0; i < kItems; ++i) a[i] = (t0 + i < L) ? __builtin_amdgcn_exp2f(dl[r][i] * An) : 1.f;
+                for (int i = 0; i < kItems; ++i) a[i] = __builtin_amdgcn_exp2f(dl[r][i] * An);
                 float anx, gin;
                 if constexpr (DYN) { anx = s_an[wave * kMaxDState + n]; gin = s_g[wave * kMaxDState + n]; }
                 else { anx = a_nx[r]; gin = g_in[r]; }
@@ -530,7 +544,7 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
                 if (tile > 0) hin = xp[(((xrow0 + (size_t)r * p.n_chunks) + tile - 1) * N + n) * 2 + 1];
                 float bb[kItems];
 #pragma unroll
-                for (int i = 0; i < kItems; ++i) bb[i] = (t0 + i < L) ? dl[r][i] * uv[r][i] * Bv[i] : 0.f;
+                for (int i = 0; i < kItems; ++i) bb[i] = dl[r][i] * uv[r][i] * Bv[i];
                 Pair agg{a[0], bb[0]};
 #pragma unroll
                 for (int i = 1; i < kItems; ++i) agg = then(agg, Pair{a[i], bb[i]});
@@ -589,7 +603,7 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
                     float *redB = s_red, *redC = s_red + W * kTile;
                     *reinterpret_cast<float4 *>(redB + wave * kTile + lane * kItems) = make_float4(dBv[0], dBv[1], dBv[2], dBv[3]);
                     *reinterpret_cast<float4 *>(redC + wave * kTile + lane * kItems) = make_float4(dCv[0], dCv[1], dCv[2], dCv[3]);
-                    __syncthreads();
+                    lds_barrier();
                     for (int e = threadIdx.x; e < 2 * kTile; e += blockDim.x) {
                         const int which = e / kTile, idx = e % kTile;
                         const float *src = which ? redC : redB;
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
                             if (geo.wg_per_group == 1) *dst = s; else atomicAdd(dst, s);
                         }
                     }
-                    __syncthreads();
+                    lds_barrier();
                 }
             }
         }
@@ -611,10 +625,10 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
 #pragma unroll
                 for (int i = 0; i < kItems; ++i) {
                     ddv[r][i] *= sig[r][i];
-                    accBias[r] += (t0 + i < L) ? ddv[r][i] : 0.f;
+                    accBias[r] += (full || t0 + i < L) ? ddv[r][i] : 0.f;
                 }
-                store4<T, VEC>(du_row[r], t0, L, duv[r]);
-                store4<T, VEC>(dd_row[r], t0, L, ddv[r]);
+                store4u<T, VEC>(du_row[r], t0, L, duv[r], full);
+                store4u<T, VEC>(dd_row[r], t0, L, ddv[r], full);
             }
         }
     }
