@@ -163,7 +163,7 @@ def test_splitk_linear_matches_f_linear():
     x = torch.randn(3, 5000, 6, requires_grad=True, dtype=torch.double)
     w = torch.randn(4, 6, requires_grad=True, dtype=torch.double)
     b = torch.randn(4, requires_grad=True, dtype=torch.double)
-    _SplitKLinearFn.apply(x, w, b, torch.double).square().sum().backward()
+    _SplitKLinearFn.apply(x, w, b, torch.double, None, None).square().sum().backward()
     got = [t.grad.clone() for t in (x, w, b)]
     for t in (x, w, b):
         t.grad = None

@@ -127,6 +127,19 @@ def current_stream(device):
 K_COUNT = 27
 
 
+def zeros_f32(device, *shapes):
+    """Zero-initialised fp32 tensors of the given shapes (None passes through) carved from ONE
+    allocation / one fill kernel, each 16-byte aligned (the kernels' accumulators: dA, dB, dC, ...)."""
+    import torch
+    sizes = [0 if sh is None else -(-int(torch.Size(sh).numel()) // 4) * 4 for sh in shapes]
+    flat = torch.zeros(max(1, sum(sizes)), dtype=torch.float32, device=device)
+    out, off = [], 0
+    for sh, n in zip(shapes, sizes):
+        out.append(None if sh is None else flat[off:off + torch.Size(sh).numel()].view(sh))
+        off += n
+    return out
+
+
 def prof_enable(on=True):
     lib().vmasr_prof_enable(int(bool(on)))
 

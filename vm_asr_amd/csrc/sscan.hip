@@ -721,6 +721,7 @@ Plan make_plan(const vmasr_sscan_params &p, bool dyn, bool backward) {
     if (!dyn && !backward && rpg == 2) R = 2;
     if (!dyn && g_tune_rows > 0 && rpg % g_tune_rows == 0 && (g_tune_rows == 1 || g_tune_rows == 2 || g_tune_rows == 4))
         R = g_tune_rows;
+    if (backward && R == 4) R = 2;  // the backward keeps ~25 live values per row and item: 4 rows only spill
     pl.R = R;
     const long row_tasks = (long)p.batch * (p.dim / R);
     int mode = 0;
@@ -838,9 +839,9 @@ int dispatch_fwd(const vmasr_sscan_params &p, const Plan &pl, bool dyn, bool vec
 }
 template <typename T>
 int dispatch_bwd(const vmasr_sscan_bwd_params &q, const Plan &pl, bool dyn, bool vec, hipStream_t st) {
-    if (dyn) { if (vec) VMASR_DISPATCH_R(launch_bwd, T, true, true, q, pl, st); else VMASR_DISPATCH_R(launch_bwd, T, true, false, q, pl, st); }
-    else { if (vec) VMASR_DISPATCH_R(launch_bwd, T, false, true, q, pl, st); else VMASR_DISPATCH_R(launch_bwd, T, false, false, q, pl, st); }
-    return VMASR_EINVAL;
+    if (dyn) return vec ? launch_bwd<T, 1, true, true>(q, pl, st) : launch_bwd<T, 1, true, false>(q, pl, st);
+    if (pl.R == 1) return vec ? launch_bwd<T, 1, false, true>(q, pl, st) : launch_bwd<T, 1, false, false>(q, pl, st);
+    return vec ? launch_bwd<T, 2, false, true>(q, pl, st) : launch_bwd<T, 2, false, false>(q, pl, st);
 }
 
 }  // namespace

@@ -79,8 +79,8 @@ def _conv_kx1_cl(x, weight, bias, stride, pad):
         x = F.pad(x, (0, 0, pad, pad))
     cols = x.unfold(2, k, stride)                      # (B, P, T_out, Cin, k) view
     Bn, P, To, Cin, _ = cols.shape
-    w = weight[:, :, :, 0].reshape(weight.shape[0], Cin * k).to(x.dtype)   # (Cout, Cin*k), (c,k) order
-    y = _linear(cols.reshape(Bn, P, To, Cin * k), w, None if bias is None else bias.to(x.dtype))
+    w = weight[:, :, :, 0].reshape(weight.shape[0], Cin * k)   # (Cout, Cin*k), (c,k) order; cast inside linear()
+    y = _linear(cols.reshape(Bn, P, To, Cin * k), w, bias)
     return y
 
 

@@ -51,8 +51,7 @@ class DWConv3x3SiLU(torch.autograd.Function):
             gy = gy.to(x.dtype)
         with torch.cuda.device(x.device):
             dx = torch.empty_like(x)
-            dw = torch.zeros((C, 1, 3, 3), dtype=torch.float32, device=x.device)
-            db = torch.zeros((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            dw, db = _lib.zeros_f32(x.device, (C, 1, 3, 3), (C,) if ctx.has_bias else None)
             ws = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
             _lib.check(_lib.lib().vmasr_dwconv_silu_bwd(_p(x), _p(w32), _p(b32) if ctx.has_bias else None, _p(gy),
                                                         _p(dx), _p(dw), _p(db), _p(ws), B, C, H, W,

@@ -5,7 +5,7 @@ microseconds), so eager execution is bound by host launch overhead, not by the G
 
     graph A   zero grads -> G forward -> D loss + G losses -> backward(G loss) -> backward(D loss)
     (eager)   one RCCL all-reduce per flat gradient buffer          [world_size > 1 only]
-    graph B   AdamW step for G and for D (capturable optimisers)
+    graph B   AdamW step for G and for D (capturable optimisers) + refresh of the bf16 shadow weights
 
 The library's own kernels are launched on the capturing stream through ctypes, so they are part of
 graph A like any ATen kernel; the in-library event profiler must be off during capture and replay.
@@ -46,9 +46,7 @@ class GraphedTrainStep:
             self.static_out, self.static_logs = tr._forward_backward(*self.static_in)
         self.graph_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool()):
-            tr.optimizer_G.step()
-            if tr.gan:
-                tr.optimizer_D.step()
+            tr._optimizer_steps()
 
     def __call__(self, wave_input, wave_target, highcut):
         for dst, src in zip(self.static_in, (wave_input, wave_target, highcut)):

@@ -76,36 +76,75 @@ def splitk_plan(rows, out_f, in_f):
     return min(rows // 2048, max(1, 512 // tiles))
 
 
+_F32_OUT = None   # does this torch build take out_dtype=float32 on 16-bit mm / bmm (hipBLASLt fp32 output)?
+
+
+def _f32_out_ok(device):
+    global _F32_OUT
+    if _F32_OUT is None:
+        try:
+            a = torch.ones(16, 16, dtype=torch.bfloat16, device=device)
+            ok = torch.mm(a, a, out_dtype=torch.float32).dtype == torch.float32
+            ok = ok and torch.bmm(a[None], a[None], out_dtype=torch.float32).dtype == torch.float32
+            _F32_OUT = bool(ok)
+        except (RuntimeError, NotImplementedError, TypeError):
+            _F32_OUT = False
+    return _F32_OUT
+
+
+def _mm_acc(a, b, acc):
+    """a @ b (2-D or batched) returned in the accumulation dtype `acc` without a separate cast kernel
+    where the GEMM can write fp32 itself."""
+    if a.dtype == acc:
+        return torch.bmm(a, b) if a.dim() == 3 else torch.mm(a, b)
+    if a.is_cuda and acc == torch.float32 and _f32_out_ok(a.device):
+        return torch.bmm(a, b, out_dtype=acc) if a.dim() == 3 else torch.mm(a, b, out_dtype=acc)
+    return (torch.bmm(a, b) if a.dim() == 3 else torch.mm(a, b)).to(acc)
+
+
 def weight_grad(gy2, x2, splits=None):
-    """dW (fp32 for 16-bit inputs) = gy2^T @ x2 for row-major (rows, out_f), (rows, in_f); split over the rows into a
-    batched GEMM + an fp32 sum of the partial products when the output is only a few tiles."""
+    """dW (fp32 for 16-bit inputs) = gy2^T @ x2 for row-major (rows, out_f), (rows, in_f); split over the
+    rows into a batched GEMM + a sum of the partial products when the output is only a few tiles."""
     rows, out_f = gy2.shape
     in_f = x2.shape[1]
     S = splitk_plan(rows, out_f, in_f) if splits is None else splits
     acc = torch.float32 if gy2.dtype in (torch.float16, torch.bfloat16) else gy2.dtype
     if S < 4:
-        return (gy2.t() @ x2).to(acc)
+        return _mm_acc(gy2.t(), x2, acc)
     chunk = rows // S
     main = chunk * S
-    part = torch.bmm(gy2[:main].view(S, chunk, out_f).transpose(1, 2), x2[:main].view(S, chunk, in_f))
-    dw = part.sum(0, dtype=acc)
+    part = _mm_acc(gy2[:main].view(S, chunk, out_f).transpose(1, 2), x2[:main].view(S, chunk, in_f), acc)
+    dw = part.sum(0)
     if main < rows:
-        dw += (gy2[main:].t() @ x2[main:]).to(acc)
+        dw += _mm_acc(gy2[main:].t(), x2[main:], acc)
     return dw
 
 
-class _SplitKLinearFn(torch.autograd.Function):
-    """F.linear whose weight gradient is the split-K GEMM above (inputs are cast to the autocast
-    dtype here, so dW is accumulated across splits in fp32 and returned in the parameter's dtype)."""
+LP_ATTR = "_vmasr_lp"   # parameter attribute: low-precision (autocast dtype) shadow copy kept by the trainer
+
+
+def _shadow(t, like, cdt):
+    """The trainer's low-precision shadow of parameter `t` (viewed like `like`, a view of t), or None."""
+    sh = getattr(t, LP_ATTR, None) if t is not None else None
+    if sh is None or sh.dtype != cdt:
+        return None
+    return sh if like is t else sh.view(like.shape)
+
+
+class _LinearFn(torch.autograd.Function):
+    """F.linear with (a) the operands cast to the compute dtype here - or taken from the trainer's
+    shadow copies, which saves a cast kernel per weight per step -, (b) dW accumulated in fp32 by the
+    GEMM itself and split over the rows where it would otherwise be one tile (weight_grad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cdt):
+    def forward(ctx, x, weight, bias, cdt, w_lp, b_lp):
         out_f, in_f = weight.shape
         x2 = x.reshape(-1, in_f).to(cdt)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        wc = weight.detach().to(cdt)
-        y = F.linear(x2, wc, None if bias is None else bias.detach().to(cdt))
+        wc = w_lp if w_lp is not None else weight.detach().to(cdt)
+        bc = None if bias is None else (b_lp if b_lp is not None else bias.detach().to(cdt))
+        y = F.linear(x2, wc, bc)
         ctx.save_for_backward(x2, wc)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y.view(*x.shape[:-1], out_f)
@@ -119,13 +158,19 @@ class _SplitKLinearFn(torch.autograd.Function):
             gy2 = gy2.contiguous()
         dx = (gy2 @ wc).view(shape).to(xdt) if ctx.needs_input_grad[0] else None
         dw = weight_grad(gy2, x2).to(wdt) if ctx.needs_input_grad[1] else None
-        db = gy2.sum(0, dtype=torch.float32 if gy2.dtype != torch.float64 else None).to(bdt) if bdt is not None and ctx.needs_input_grad[2] else None
-        return dx, dw, db, None
+        db = None
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = gy2.sum(0, dtype=torch.float32 if gy2.dtype != torch.float64 else None).to(bdt)
+        return dx, dw, db, None, None, None
 
 
-def linear(x, weight, bias=None):
-    """F.linear; tiny in/out features over many GPU rows go to the HIP row-map kernel, many rows with a
-    small weight get the split-K weight gradient."""
+_SplitKLinearFn = _LinearFn   # (tests)
+
+
+def linear(x, weight, bias=None, shadow_of=None, bias_shadow_of=None):
+    """F.linear for this path.  Tiny in/out features over many GPU rows go to the HIP row-map kernel; under
+    autocast, or for many rows with a small weight, the GEMM path goes through _LinearFn.  `shadow_of`:
+    the parameter `weight` is a view of (for the shadow lookup)."""
     out_f, in_f = weight.shape
     if (x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.numel() // max(1, in_f) >= _MIN_ROWS
             and _lib.lib().vmasr_small_linear_supported(in_f, out_f)):
@@ -133,10 +178,13 @@ def linear(x, weight, bias=None):
         if out_dtype == x.dtype or x.dtype == torch.float32:
             return _SmallLinearFn.apply(x, weight, bias, out_dtype)
     if x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and x.is_floating_point():
+        amp = torch.is_autocast_enabled("cuda")
         rows = x.numel() // max(1, in_f)
-        if splitk_plan(rows, out_f, in_f) >= 4:
-            cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-            return _SplitKLinearFn.apply(x, weight, bias, cdt)
+        if amp or splitk_plan(rows, out_f, in_f) >= 4:
+            cdt = torch.get_autocast_dtype("cuda") if amp else x.dtype
+            w_lp = _shadow(shadow_of if shadow_of is not None else weight, weight, cdt)
+            b_lp = _shadow(bias_shadow_of if bias_shadow_of is not None else bias, bias, cdt) if bias is not None else None
+            return _LinearFn.apply(x, weight, bias, cdt, w_lp, b_lp)
     return F.linear(x, weight, bias)
 
 

@@ -75,7 +75,7 @@ class GemmConv2d(nn.Conv2d):
         cols = F.unfold(x, self.kernel_size, padding=self.padding, stride=self.stride)  # (B, C*kh*kw, Ho*Wo)
         # pixels as the GEMM's M dimension: (B*Ho*Wo, C*kh*kw) @ (C*kh*kw, Cout).  The batched
         # (Cout x K) @ (K x Ho*Wo) form picks a 32x32 hipBLASLt tile and takes 1.5 ms per call.
-        y = _linear(cols.transpose(1, 2), self.weight.flatten(1), self.bias)            # (B, Ho*Wo, Cout)
+        y = _linear(cols.transpose(1, 2), self.weight.flatten(1), self.bias, shadow_of=self.weight)            # (B, Ho*Wo, Cout)
         return y.transpose(1, 2).reshape(B, -1, Ho, Wo)
 
 
@@ -85,7 +85,7 @@ class PointwiseConvCL(nn.Conv2d):
     862-864) without the two layout copies and without MIOpen's naive 1x1 fallbacks."""
 
     def forward(self, x):
-        return _linear(x, self.weight.flatten(1), self.bias)
+        return _linear(x, self.weight.flatten(1), self.bias, shadow_of=self.weight)
 
 
 _ACT = dict(silu=nn.SiLU, gelu=nn.GELU, relu=nn.ReLU, sigmoid=nn.Sigmoid)

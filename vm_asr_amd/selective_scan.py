@@ -119,11 +119,9 @@ def bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows=1):
         if ddelta.stride(-1) != 1:
             ddelta = torch.empty(u.shape, dtype=u.dtype, device=u.device)
         f32 = dict(dtype=torch.float32, device=u.device)
-        dA = torch.zeros(A.shape, **f32)
-        dB = torch.zeros(B.shape, **f32)
-        dC = torch.zeros(C.shape, **f32)
-        dD = torch.zeros(dim, **f32) if D is not None else None
-        ddelta_bias = torch.zeros(dim, **f32) if delta_bias is not None else None
+        dB, dC, dA, dD, ddelta_bias = _lib.zeros_f32(u.device, B.shape, C.shape, A.shape,
+                                                     (dim,) if D is not None else None,
+                                                     (dim,) if delta_bias is not None else None)
         q = _lib.SScanBwdParams()
         _fill(q.f, u, delta, A, B, C, D, delta_bias, None, x, delta_softplus, n_chunks)
         q.dout_batch_stride, q.dout_d_stride = dout.stride(0), dout.stride(1)

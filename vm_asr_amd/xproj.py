@@ -55,8 +55,7 @@ class _XProjFn(torch.autograd.Function):
         ddts, dBs, dCs = z(ddts, (B, K * D, L)), z(dBs, (B, K, N, L)), z(dCs, (B, K, N, L))
         with torch.cuda.device(xs.device):
             dxs = torch.empty_like(xs)
-            dWx = torch.zeros((K, C, D), **f32)
-            dWdt = torch.zeros((K, D, R), **f32)
+            dWx, dWdt = _lib.zeros_f32(xs.device, (K, C, D), (K, D, R))
             ws = torch.empty((B, K, C, L), **f32)
             _lib.check(_lib.lib().vmasr_xproj_bwd(_p(xs), _p(wx32), _p(wdt32), _p(dtr), _p(ddts), _p(dBs), _p(dCs), None,
                                                   _p(dxs), _p(dWx), _p(dWdt), _p(ws), B, K, D, N, R, L,
