@@ -118,7 +118,12 @@ def load_reference():
     g = dict(torch=torch, F=F, rearrange=rearrange, repeat=repeat)
     exec(code, g)
 
-    ns = types.SimpleNamespace(vmamba=vmamba, model=model, stft=stft, metric=metric,
+    try:
+        disc = _load("refdisc", os.path.join(REF, "model/discriminator.py"))
+    except Exception as e:  # pragma: no cover
+        disc = None
+        print("WARNING: reference discriminator not importable:", e)
+    ns = types.SimpleNamespace(vmamba=vmamba, model=model, stft=stft, metric=metric, discriminator=disc,
                                loss=loss, selective_scan_ref=g["selective_scan_ref"])
     _CACHE["ns"] = ns
     return ns

@@ -14,6 +14,8 @@ Fixture families:
   model_tiny.npz  DualStreamInteractiveMambaUNet dims=8, n_fft=128 fwd + grads + LSD
   metric.npz      LSD / SNR / LSD-HF / LSD-LF on fixed pairs (model/metric.py)
   loss.npz        MultiResolutionSTFTLoss values + d/dx (model/loss.py:137-184)
+  mpd.npz         MultiPeriodDiscriminator hidden=2 scores / feature maps / LSGAN losses / grads
+                  (model/discriminator.py:21-147, model/loss.py:188-235)
 """
 import os
 import sys
@@ -35,7 +37,7 @@ def _np(t):
     t = t.detach()
     if t.dtype == torch.bfloat16 or t.dtype == torch.float16:
         t = t.float()
-    return t.cpu().numpy()
+    return t.cpu().numpy().copy()   # a copy: later in-place updates (power iteration) must not leak into the fixture
 
 
 def save(name, **arrs):
@@ -294,6 +296,48 @@ def gen_loss(ns):
     save("loss.npz", **out)
 
 
+def gen_mpd(ns):
+    """MultiPeriodDiscriminator (model/discriminator.py:21-147) hidden=2 on a 2 x 1 x 1 201 pair (not a
+    multiple of any period -> reflect pad), with the HiFi-GAN LSGAN losses (model/loss.py:188-235).
+    eval mode: spectral norm uses the stored u, v (no power iteration): scores, all 30 feature maps,
+    the three losses and d(gen+feat)/dy_hat, d(disc)/d(two weights).  train mode: forward(y, y_hat) from
+    the same state = one power iteration per call (real, then fake), scores only."""
+    torch.manual_seed(11)
+    D = ns.discriminator.MultiPeriodDiscriminator(hidden=2)
+    g = torch.Generator().manual_seed(12)
+    y = 0.3 * torch.randn(2, 1, 1201, generator=g)
+    y_hat = (0.3 * torch.randn(2, 1, 1201, generator=g)).requires_grad_()
+    out = {f"sd::{k}": _np(v) for k, v in D.state_dict().items()}
+    out.update(y=_np(y), y_hat=_np(y_hat))
+    L = ns.loss.HiFiGANLoss("lsgan")
+    D.eval()
+    rs, gs, fr, fg = D(y, y_hat)
+    for i, (a, b) in enumerate(zip(rs, gs)):
+        out[f"eval_real{i}"], out[f"eval_gen{i}"] = _np(a), _np(b)
+    for i, (a, b) in enumerate(zip(fr, fg)):
+        for j, (u, v) in enumerate(zip(a, b)):
+            out[f"eval_fmap_real{i}_{j}"], out[f"eval_fmap_gen{i}_{j}"] = _np(u), _np(v)
+    d_loss = L.discriminator_loss(rs, gs)
+    g_loss = L.generator_loss(gs)
+    f_loss = L.feature_loss(fr, fg)
+    out.update(d_loss=np.array(d_loss.item()), g_loss=np.array(g_loss.item()), f_loss=np.array(f_loss.item()))
+    (g_loss + f_loss).backward(retain_graph=True)
+    out["d_gf_dyhat"] = _np(y_hat.grad)
+    names = ["discriminators.0.layers.0.parametrizations.weight.original", "discriminators.4.layers.3.parametrizations.weight.original",
+             "discriminators.2.conv_post.bias"]
+    params = dict(D.named_parameters())
+    for p in params.values():
+        p.grad = None
+    d_loss.backward()
+    for n in names:
+        out[f"d_disc::{n}"] = _np(params[n].grad)
+    D.train()
+    rs, gs, _, _ = D(y, y_hat.detach())
+    for i, (a, b) in enumerate(zip(rs, gs)):
+        out[f"train_real{i}"], out[f"train_gen{i}"] = _np(a), _np(b)
+    save("mpd.npz", **out)
+
+
 def gen_metric(ns):
     out = {}
     g = torch.Generator().manual_seed(5)
@@ -308,7 +352,7 @@ def gen_metric(ns):
 
 if __name__ == "__main__":
     ns = load_reference()
-    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss"]
+    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss", "mpd"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"](ns)

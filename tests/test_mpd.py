@@ -1,0 +1,111 @@
+"""MultiPeriodDiscriminator + HiFi-GAN LSGAN losses vs the reference (golden tests/golden/mpd.npz, made by
+model/discriminator.py:21-147 and model/loss.py:188-235 on CPU).  The CPU run exercises the plain-convolution
+host path; the GPU run the GEMM-formulated channel-last path the training step uses, plus the stacked
+real+fake pass (forward_pair) and the HIP power iteration of the spectral norm (train mode)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+N_DISC, N_FMAP = 5, 6
+
+
+def _load(device):
+    from vm_asr_amd.discriminator import MultiPeriodDiscriminator
+    z = np.load(os.path.join(GOLDEN, "mpd.npz"))
+    D = MultiPeriodDiscriminator(hidden=2)
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    D.load_state_dict(sd, strict=True)          # same keys as the reference (checkpoint contract)
+    return z, D.to(device)
+
+
+def _close(got, want, tol, what):
+    got = got.detach().float().cpu().numpy()
+    scale = max(np.abs(want).max(), 1e-6)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = np.abs(got - want).max()
+    assert err <= tol * scale, (what, err, scale)
+
+
+PERIODS = (2, 3, 5, 7, 11)
+
+
+def _score_ref_order(s, i, device):
+    """GPU path flattens the channel-last score (B, P, T') -> reference order is (B, T', P)."""
+    if device == "cpu":
+        return s
+    return s.view(s.shape[0], PERIODS[i], -1).transpose(1, 2).reshape(s.shape[0], -1)
+
+
+def _fmap_ref_layout(t, device):
+    """GPU path returns feature maps channel-last (B, P, T', C); the reference layout is (B, C, T', P)."""
+    return t.permute(0, 3, 2, 1) if device != "cpu" else t
+
+
+def _run_eval(device, tol):
+    from vm_asr_amd.loss import HiFiGANLoss
+    z, D = _load(device)
+    D.eval()
+    y = torch.from_numpy(z["y"]).to(device)
+    y_hat = torch.from_numpy(z["y_hat"]).to(device).requires_grad_()
+    L = HiFiGANLoss("lsgan")
+    rs, gs, fr, fg = D(y, y_hat)
+    for i in range(N_DISC):
+        _close(_score_ref_order(rs[i], i, device), z[f"eval_real{i}"], tol, f"real{i}")
+        _close(_score_ref_order(gs[i], i, device), z[f"eval_gen{i}"], tol, f"gen{i}")
+        for j in range(N_FMAP):
+            _close(_fmap_ref_layout(fr[i][j], device), z[f"eval_fmap_real{i}_{j}"], tol, f"fmap_real{i}_{j}")
+            _close(_fmap_ref_layout(fg[i][j], device), z[f"eval_fmap_gen{i}_{j}"], tol, f"fmap_gen{i}_{j}")
+    d_loss, g_loss, f_loss = L.discriminator_loss(rs, gs), L.generator_loss(gs), L.feature_loss(fr, fg)
+    for name, v in (("d_loss", d_loss), ("g_loss", g_loss), ("f_loss", f_loss)):
+        assert abs(v.item() - float(z[name])) <= tol * max(1.0, abs(float(z[name]))), (name, v.item(), float(z[name]))
+    (g_loss + f_loss).backward(retain_graph=True)
+    _close(y_hat.grad, z["d_gf_dyhat"], 5 * tol, "d(gen+feat)/dy_hat")
+    params = dict(D.named_parameters())
+    for p in params.values():
+        p.grad = None
+    d_loss.backward()
+    for k in z.files:
+        if k.startswith("d_disc::"):
+            _close(params[k[8:]].grad, z[k], 5 * tol, k)
+    return z, D, y, y_hat
+
+
+def test_mpd_eval_cpu():
+    _run_eval("cpu", 2e-5)
+
+
+def test_mpd_train_power_iteration_cpu():
+    """train mode: one power iteration per call, real then fake (model/discriminator.py:129-147)."""
+    z, D = _load("cpu")
+    D.train()
+    rs, gs, _, _ = D(torch.from_numpy(z["y"]), torch.from_numpy(z["y_hat"]))
+    for i in range(N_DISC):
+        _close(rs[i], z[f"train_real{i}"], 2e-5, f"train_real{i}")
+        _close(gs[i], z[f"train_gen{i}"], 2e-5, f"train_gen{i}")
+
+
+@pytest.mark.gpu
+def test_mpd_eval_hip():
+    z, D, y, y_hat = _run_eval("cuda:0", 1e-4)
+    # the stacked real+fake pass the trainer uses gives the same scores and feature maps
+    with torch.no_grad():
+        rs, gs, fr, fg = D(y, y_hat)
+        prs, pgs, pfr, pfg = D.forward_pair(y, y_hat)
+    for i in range(N_DISC):
+        assert torch.allclose(rs[i], prs[i], rtol=1e-4, atol=1e-5) and torch.allclose(gs[i], pgs[i], rtol=1e-4, atol=1e-5)
+        for j in range(N_FMAP):
+            assert torch.allclose(fr[i][j], pfr[i][j], rtol=1e-4, atol=1e-5)
+            assert torch.allclose(fg[i][j], pfg[i][j], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_mpd_train_power_iteration_hip():
+    z, D = _load("cuda:0")
+    D.train()
+    rs, gs, _, _ = D(torch.from_numpy(z["y"]).cuda(), torch.from_numpy(z["y_hat"]).cuda())
+    for i in range(N_DISC):
+        _close(_score_ref_order(rs[i], i, "cuda"), z[f"train_real{i}"], 1e-4, f"train_real{i}")
+        _close(_score_ref_order(gs[i], i, "cuda"), z[f"train_gen{i}"], 1e-4, f"train_gen{i}")
