@@ -199,6 +199,16 @@ int vmasr_small_linear_bwd(const void *x, const float *w, const void *gy, void *
 int vmasr_spectral_power_iter(const float *W, float *u, float *v, float *ws, int32_t R, int32_t C,
                               int32_t n_iter, float eps, vmasr_stream_t stream);
 
+/* Column / scatter operands of the period discriminator's (k,1) convolutions on channel-last sequences
+ * (replaces the MIOpen convolutions behind model/discriminator.py:40-88 together with a GEMM):
+ *   im2col: x (N, H, C) -> cols (N, H1, k, C), cols[n,h1,j,c] = x[n, h1*stride + j - pad, c] (0 outside),
+ *           H1 = (H + 2*pad - k)/stride + 1;   col2im: the adjoint gather, dcols (N, H1, k, C) -> dx (N, H, C).
+ * Contiguous tensors of `dtype` (VMASR_F32/F16/BF16). */
+int vmasr_im2col_kx1(const void *x, void *cols, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
+                     int32_t pad, int32_t dtype, vmasr_stream_t stream);
+int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
+                     int32_t pad, int32_t dtype, vmasr_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents
  * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
@@ -233,6 +243,8 @@ enum {
     VMASR_K_XPROJ_BWD_A,
     VMASR_K_XPROJ_BWD_B,
     VMASR_K_SPECTRAL,
+    VMASR_K_IM2COL,
+    VMASR_K_COL2IM,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

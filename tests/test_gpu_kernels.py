@@ -450,3 +450,26 @@ def test_spectral_power_iteration_vs_torch():
         _close(sn_gpu._u, sn_cpu._u.numpy(), 1e-4, 1e-5, f"u {shape}")
         _close(sn_gpu._v, sn_cpu._v.numpy(), 1e-4, 1e-5, f"v {shape}")
         _close(out_g, out_c.detach().numpy(), 1e-4, 1e-5, f"w/sigma {shape}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,C,k,stride,pad", [(201, 1, 5, 3, 2), (67, 8, 5, 3, 2), (23, 32, 5, 3, 2), (8, 12, 5, 1, 2),
+                                               (8, 5, 3, 1, 1), (1, 4, 3, 1, 1), (40881, 1, 5, 3, 2)])
+def test_im2col_col2im_kx1(dtype, H, C, k, stride, pad):
+    """HIP im2col / col2im of the period discriminator's (k,1) convolutions vs unfold and its autograd adjoint
+    (exact: pure data movement; the adjoint sums at most ceil(k/stride) terms in fp32)."""
+    from vm_asr_amd.discriminator import _Im2ColFn
+    torch.manual_seed(H + C)
+    B, P = 2, 3
+    x = torch.randn(B, P, H, C, device="cuda").to(dtype).requires_grad_()
+    cols = _Im2ColFn.apply(x, k, stride, pad)
+    xr = x.detach().clone().requires_grad_()
+    ref = torch.nn.functional.pad(xr, (0, 0, pad, pad)).unfold(2, k, stride).permute(0, 1, 2, 4, 3)   # (B,P,H1,k,C)
+    ref = ref.reshape(B, P, -1, k * C)
+    assert cols.shape == ref.shape and torch.equal(cols, ref)
+    g = torch.randn_like(ref)
+    cols.backward(g)
+    ref.float().backward(g.float())
+    tol = 0 if dtype == torch.float32 and stride >= k else (1e-6 if dtype == torch.float32 else 2e-2)
+    assert (x.grad.float() - xr.grad.float()).abs().max() <= tol * max(1.0, xr.grad.float().abs().max().item())

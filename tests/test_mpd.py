@@ -109,3 +109,26 @@ def test_mpd_train_power_iteration_hip():
     for i in range(N_DISC):
         _close(_score_ref_order(rs[i], i, "cuda"), z[f"train_real{i}"], 1e-4, f"train_real{i}")
         _close(_score_ref_order(gs[i], i, "cuda"), z[f"train_gen{i}"], 1e-4, f"train_gen{i}")
+
+
+@pytest.mark.parametrize("H,C,Cout,k,stride,pad", [(201, 1, 2, 5, 3, 2), (67, 2, 8, 5, 3, 2), (23, 8, 4, 5, 3, 2), (8, 4, 4, 5, 3, 2),
+                                                   (5, 3, 2, 5, 3, 2), (6, 3, 2, 5, 3, 2), (7, 3, 2, 5, 3, 2), (1, 2, 3, 5, 3, 2),
+                                                   (8, 4, 4, 5, 1, 2), (3, 2, 1, 3, 1, 1), (1, 2, 2, 3, 1, 1)])
+def test_conv_kx1_gemm_form_matches_conv2d(H, C, Cout, k, stride, pad):
+    """The im2col-free GEMM form of the (k,1) convolution (vm_asr_amd/discriminator.py:_ConvKx1Fn) == F.conv2d,
+    forward and all three gradients, for every tail length modulo the stride."""
+    from vm_asr_amd.discriminator import _ConvKx1Fn
+    torch.manual_seed(H * 31 + C)
+    B, P = 2, 3
+    x = torch.randn(B, P, H, C, dtype=torch.double, requires_grad=True)
+    w = torch.randn(Cout, C, k, 1, dtype=torch.double, requires_grad=True)
+    b = torch.randn(Cout, dtype=torch.double, requires_grad=True)
+    y = _ConvKx1Fn.apply(x, w, b, stride, pad, torch.double)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 2, 1), w, b, (stride, 1), (pad, 0)).permute(0, 3, 2, 1)
+    assert y.shape == ref.shape
+    assert torch.allclose(y, ref, rtol=1e-10, atol=1e-10)
+    gy = torch.randn_like(ref)
+    got = torch.autograd.grad(y, (x, w, b), gy)
+    want = torch.autograd.grad(ref, (x, w, b), gy)
+    for g, r in zip(got, want):
+        assert g.shape == r.shape and torch.allclose(g, r, rtol=1e-9, atol=1e-9)

@@ -63,6 +63,8 @@ SYMBOLS = {
     "vmasr_xproj_fwd": (ctypes.c_int, [c_vp] * 7 + [c_i32] * 7 + [c_vp]),
     "vmasr_xproj_bwd": (ctypes.c_int, [c_vp] * 12 + [c_i32] * 7 + [c_vp]),
     "vmasr_spectral_power_iter": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, ctypes.c_float, c_vp]),
+    "vmasr_im2col_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_col2im_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -124,7 +126,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 27
+K_COUNT = 29
 
 
 def zeros_f32(device, *shapes):

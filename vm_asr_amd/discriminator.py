@@ -6,13 +6,16 @@ else spectral_norm`, :37) means the default `use_spectral_norm=False` yields SPE
 that is reproduced so state_dicts (parametrizations.weight.original + power-iteration
 buffers) stay compatible.  MSD (:174-337) is not enabled by any yaml and is not built.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import parametrize
 from torch.nn.utils.parametrizations import weight_norm
 
-from .linear import linear as _linear
+from . import _lib
+from .linear import linear as _linear, weight_grad as _weight_grad
 from .streams import parallel as _parallel
 
 __all__ = ["PeriodDiscriminator", "MultiPeriodDiscriminator", "spectral_norm"]
@@ -69,12 +72,43 @@ def spectral_norm(module, name="weight", n_power_iterations=1, eps=1e-12):
     return module
 
 
+class _Im2ColFn(torch.autograd.Function):
+    """x (B, P, H, C) channel-last -> columns (B, P, H1, k*C), (tap, channel) order, zero padding implicit:
+    the HIP gather / adjoint-gather kernels of vm_asr_amd/csrc/im2col.hip."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        B, P, H, C = x.shape
+        xc = x.contiguous()
+        H1 = (H + 2 * pad - k) // stride + 1
+        with torch.cuda.device(x.device):
+            cols = torch.empty((B, P, H1, k * C), dtype=x.dtype, device=x.device)
+            _lib.check(_lib.lib().vmasr_im2col_kx1(xc.data_ptr(), cols.data_ptr(), B * P, H, C, k, stride, pad,
+                                                   _lib.torch_dtype_code(x.dtype), _lib.current_stream(x.device)), "im2col_kx1")
+        ctx.geom = (B, P, H, C, k, stride, pad)
+        return cols
+
+    @staticmethod
+    def backward(ctx, g):
+        B, P, H, C, k, stride, pad = ctx.geom
+        g = g.contiguous()
+        with torch.cuda.device(g.device):
+            dx = torch.empty((B, P, H, C), dtype=g.dtype, device=g.device)
+            _lib.check(_lib.lib().vmasr_col2im_kx1(g.data_ptr(), dx.data_ptr(), B * P, H, C, k, stride, pad,
+                                                   _lib.torch_dtype_code(g.dtype), _lib.current_stream(g.device)), "col2im_kx1")
+        return dx, None, None, None
+
+
 def _conv_kx1_cl(x, weight, bias, stride, pad):
     """Conv2d with a (k,1) kernel, stride (s,1), zero padding (pad,0) on CHANNEL-LAST input
     x (B, P, T, Cin) -> (B, P, T_out, Cout), evaluated as unfold + GEMM.  MIOpen runs these
     (5,1)/(3,1) bf16 convolutions with its `naive_conv_*` fallback (40+ ms per call on MI355X);
     as GEMMs (K = Cin*k up to 5120) they run on the MFMA pipes through hipBLASLt."""
     k = weight.shape[2]
+    if x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.shape[2] + 2 * pad >= k:
+        cols = _Im2ColFn.apply(x, k, stride, pad)      # (B, P, T_out, k*Cin), (tap, c) order, HIP gather
+        w = weight[:, :, :, 0].permute(0, 2, 1).reshape(weight.shape[0], -1)
+        return _linear(cols, w, bias)
     if pad:
         x = F.pad(x, (0, 0, pad, pad))
     cols = x.unfold(2, k, stride)                      # (B, P, T_out, Cin, k) view
@@ -82,6 +116,110 @@ def _conv_kx1_cl(x, weight, bias, stride, pad):
     w = weight[:, :, :, 0].reshape(weight.shape[0], Cin * k)   # (Cout, Cin*k), (c,k) order; cast inside linear()
     y = _linear(cols.reshape(Bn, P, To, Cin * k), w, bias)
     return y
+
+
+class _ConvKx1Fn(torch.autograd.Function):
+    """The same convolution with NO im2col: on the (B*P sequences, T, C) channel-last layout the taps of a
+    (k,1) kernel are row-shifted views of the zero-padded input, so the convolution is a few GEMMs on views.
+
+      stride 3, k 5:  Xp (N, 3*Hq, C) viewed as V (N*Hq, 3C):   Y = V @ W[taps 0-2]^T ;  Y[:-1] += V[1:, :2C] @ W[taps 3-4]^T
+      stride 1, k:    Xp (N*Hp, C):                              Y[:R] = sum_j Xp[j:j+R] @ W[tap j]^T,   R = N*Hp - (k-1)
+
+    Rows that straddle two sequences are junk and lie exactly in the rows the valid-output view drops.
+    unfold + GEMM reads and writes 5/3x (stride 3) or 5x (stride 1) the input as columns and scatters it back
+    in the backward (`_unfold_backward`: 2.7 ms/step); here the only copy is the zero padding (1x).
+    The backward is the same GEMMs transposed; dW is accumulated in fp32 (split over rows where it is one tile)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, cdt):
+        B, P, H, C = x.shape
+        Cout, _, k, _ = weight.shape
+        N = B * P
+        H1 = (H + 2 * pad - k) // stride + 1
+        w = weight.detach()[:, :, :, 0].to(cdt)                       # (Cout, C, k)
+        bc = None if bias is None else bias.detach().to(cdt)
+        if stride == 3:
+            Hq = H1 + 1
+            Hp = 3 * Hq
+            xp = F.pad(x.detach().reshape(N, H, C).to(cdt), (0, 0, pad, Hp - pad - H))   # negative = crop unused tail
+            V = xp.view(N * Hq, 3 * C)
+            Wa = w[:, :, 0:3].permute(0, 2, 1).reshape(Cout, 3 * C)   # (tap, c) order = V's column order
+            Wb = w[:, :, 3:5].permute(0, 2, 1).reshape(Cout, 2 * C)
+            Y = torch.addmm(bc, V, Wa.t()) if bc is not None else V @ Wa.t()
+            Y[:-1].addmm_(V[1:, :2 * C], Wb.t())
+            ctx.save_for_backward(xp, Wa, Wb)
+            rows = Hq
+        else:
+            Hp = H + 2 * pad
+            xp = F.pad(x.detach().reshape(N, H, C).to(cdt), (0, 0, pad, pad)).view(N * Hp, C)
+            R = N * Hp - (k - 1)
+            Wt = w.permute(2, 0, 1).contiguous()                       # (k, Cout, C)
+            Y = torch.empty((N * Hp, Cout), dtype=cdt, device=x.device)
+            Y[R:].zero_()
+            if bc is not None:
+                torch.addmm(bc, xp[0:R], Wt[0].t(), out=Y[:R])
+            else:
+                torch.mm(xp[0:R], Wt[0].t(), out=Y[:R])
+            for j in range(1, k):
+                Y[:R].addmm_(xp[j:j + R], Wt[j].t())
+            ctx.save_for_backward(xp, Wt)
+            rows = Hp
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, stride, pad, k, H1, rows)
+        return Y.view(B, P, rows, Cout)[:, :, :H1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        (B, P, H, C), xdt, wdt, bdt, stride, pad, k, H1, rows = ctx.meta
+        N = B * P
+        Cout = gy.shape[-1]
+        cdt = ctx.saved_tensors[0].dtype
+        g = F.pad(gy.reshape(N, H1, Cout).to(cdt), (0, 0, 0, rows - H1)).view(N * rows, Cout)   # junk rows: zero gradient
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = dw = db = None
+        if stride == 3:
+            xp, Wa, Wb = ctx.saved_tensors
+            V = xp.view(N * rows, 3 * C)
+            if need_x:
+                dV = g @ Wa
+                dV[1:, :2 * C].addmm_(g[:-1], Wb)
+                dxp = dV.view(N, 3 * rows, C)
+            if need_w:
+                dWa = _weight_grad(g, V).view(Cout, 3, C)
+                dWb = _weight_grad(g[:-1], V[1:, :2 * C]).view(Cout, 2, C)
+                dw = torch.cat((dWa, dWb), dim=1).permute(0, 2, 1).unsqueeze(-1).to(wdt)
+            Hp = 3 * rows
+        else:
+            xp, Wt = ctx.saved_tensors
+            Hp = rows
+            R = N * Hp - (k - 1)
+            if need_x:
+                dX = torch.zeros((N * Hp, C), dtype=cdt, device=gy.device)
+                for j in range(k):
+                    dX[j:j + R].addmm_(g[:R], Wt[j])
+                dxp = dX.view(N, Hp, C)
+            if need_w:
+                dw = torch.stack([_weight_grad(g[:R], xp[j:j + R]) for j in range(k)], dim=2).unsqueeze(-1).to(wdt)
+        if need_x:
+            avail = min(H, Hp - pad)
+            dx = dxp[:, pad:pad + avail]
+            if avail < H:
+                dx = F.pad(dx, (0, 0, 0, H - avail))
+            dx = dx.reshape(B, P, H, C).to(xdt)
+        if need_b and bdt is not None:
+            db = g.sum(0, dtype=torch.float32 if cdt in (torch.float16, torch.bfloat16) else None).to(bdt)
+        return dx, dw, db, None, None, None
+
+
+def conv_kx1(x, weight, bias, stride, pad):
+    """(k,1) convolution of channel-last x (B, P, T, Cin) -> (B, P, T_out, Cout): the im2col-free GEMM form
+    for the discriminator's two shapes (k 5 / stride 3, and stride 1), unfold + GEMM otherwise."""
+    k = weight.shape[2]
+    mode = os.environ.get("VMASR_MPD_CONV", "unfold")    # gemm | s3 (stride-3 layers only) | unfold (default: measured fastest)
+    ok = (stride == 3 and k == 5 and mode in ("gemm", "s3")) or (stride == 1 and mode == "gemm")
+    if x.is_cuda and ok and x.shape[2] + 2 * pad >= k:
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        return _ConvKx1Fn.apply(x, weight, bias, stride, pad, cdt)
+    return _conv_kx1_cl(x, weight, bias, stride, pad)
 
 
 class PeriodDiscriminator(nn.Module):
@@ -122,10 +260,10 @@ class PeriodDiscriminator(nn.Module):
         x = x.view(b, c, t // self.period, self.period).permute(0, 3, 2, 1)  # (B, P, T', C=1)
         for layer in self.layers:
             w, bias = wb(layer)
-            x = F.gelu(_conv_kx1_cl(x, w, bias, layer.stride[0], layer.padding[0]))
+            x = F.gelu(conv_kx1(x, w, bias, layer.stride[0], layer.padding[0]))
             fmap.append(x)
         w, bias = wb(self.conv_post)
-        x = _conv_kx1_cl(x, w, bias, 1, self.conv_post.padding[0])
+        x = conv_kx1(x, w, bias, 1, self.conv_post.padding[0])
         fmap.append(x)
         return torch.flatten(x, 1, -1), fmap
 

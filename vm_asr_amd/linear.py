@@ -113,7 +113,8 @@ def weight_grad(gy2, x2, splits=None):
         return _mm_acc(gy2.t(), x2, acc)
     chunk = rows // S
     main = chunk * S
-    part = _mm_acc(gy2[:main].view(S, chunk, out_f).transpose(1, 2), x2[:main].view(S, chunk, in_f), acc)
+    # unflatten, not view: x2 may be a column slice of a wider matrix (row stride > in_f)
+    part = _mm_acc(gy2[:main].unflatten(0, (S, chunk)).transpose(1, 2), x2[:main].unflatten(0, (S, chunk)), acc)
     dw = part.sum(0)
     if main < rows:
         dw += _mm_acc(gy2[main:].t(), x2[main:], acc)
