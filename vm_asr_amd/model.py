@@ -34,7 +34,7 @@ from .stft import spectro2wav, wav2spectro
 from .streams import parallel as _parallel
 from .layernorm import LayerNorm
 from .linear import Linear as _Linear, linear as _linear
-from .vmamba import PatchMerging2D, Permute, VSSBlock
+from .vmamba import PatchMerging2D, Permute, VSSBlock, attach_drop_path_pool
 
 __all__ = ["PatchMerging2D", "PatchExpanding", "MambaUNet", "DualStreamInteractiveMambaUNet"]
 
@@ -220,6 +220,7 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
             self.output_layer_phase = deepcopy(self.output_layer)
         del self.patch_embed, self.layers_encoder, self.layers_latent, self.layers_decoder, self.output_layer
         self.apply(self._init_weights)  # the reference re-draws every Linear after the copy
+        self._dp_pool = attach_drop_path_pool(self)   # one stochastic-depth draw per forward for all blocks
 
     def _interact(self, mag, phase):
         if self.interact in ("dual", "p2m"):
@@ -237,6 +238,8 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
         single = self.interact == "single"
 
         dev = x.device
+        if self.training and self._dp_pool is not None:
+            self._dp_pool.refresh(2 * x.shape[0], dev)     # 2B: the shared decoders run both streams stacked
         if not single:
             # the two streams are independent between interaction points: fork them onto two HIP streams
             mag, phase = _parallel([lambda: self.patch_embed_mag(mag), lambda: self.patch_embed_phase(phase)], dev, "g")

@@ -39,6 +39,24 @@ from .selective_scan import SelectiveScanCore
 __all__ = ["SS2D", "VSSBlock", "VSSM", "Mlp", "DropPath", "LayerNorm2d", "Linear2d", "Permute"]
 
 
+class DropPathPool:
+    """One Bernoulli draw per forward for ALL stochastic-depth layers of a model (instead of a
+    bernoulli_ + div_ pair per layer: 140 tiny launches per step).  `masks[i, b]` is layer i's keep mask
+    for sample b, already scaled by 1/keep (timm's scale_by_keep).  Plain object: no parameters/buffers."""
+
+    def __init__(self, drop_probs):
+        self.keep = 1.0 - torch.tensor(drop_probs, dtype=torch.float32).view(-1, 1)
+        self.masks = None
+
+    def refresh(self, batch, device):
+        if self.keep.device != device:
+            self.keep = self.keep.to(device)
+        self.masks = torch.bernoulli(self.keep.expand(-1, batch)) / self.keep
+
+    def get(self, index, batch, ndim):
+        return self.masks[index, :batch].view((batch,) + (1,) * (ndim - 1))
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm semantics: identity in eval or at p=0)."""
 
@@ -46,18 +64,45 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
         self.scale_by_keep = scale_by_keep
+        self._pool, self._index = None, -1          # set by attach_drop_path_pool()
 
-    def forward(self, x):
-        if self.drop_prob == 0.0 or not self.training:
-            return x
+    def active(self):
+        return self.drop_prob != 0.0 and self.training
+
+    def _mask(self, x):
+        pool = self._pool
+        if pool is not None and pool.masks is not None and pool.masks.shape[1] >= x.shape[0] and pool.masks.device == x.device:
+            return pool.get(self._index, x.shape[0], x.ndim)
         keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        mask = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), dtype=torch.float32, device=x.device).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
-        return x * mask
+        return mask
+
+    def forward(self, x):
+        if not self.active():
+            return x
+        return x * self._mask(x).to(x.dtype)
+
+    def residual(self, x, y):
+        """x + drop_path(y) as ONE kernel (addcmul with the per-sample mask)."""
+        if not self.active():
+            return x + y
+        return torch.addcmul(x, y, self._mask(y).to(torch.promote_types(x.dtype, y.dtype)))
 
     def extra_repr(self):
         return f"drop_prob={self.drop_prob:0.3f}"
+
+
+def attach_drop_path_pool(model):
+    """Give every active DropPath of `model` a slot in one shared DropPathPool; returns the pool (or None)."""
+    layers = [m for m in model.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0 and m.scale_by_keep and m.drop_prob < 1.0]
+    if not layers:
+        return None
+    pool = DropPathPool([m.drop_prob for m in layers])
+    for i, m in enumerate(layers):
+        m._pool, m._index = pool, i
+    return pool
 
 
 class Linear2d(nn.Linear):
@@ -352,12 +397,12 @@ class VSSBlock(nn.Module):
             if self.post_norm:
                 x = input + self.drop_path(self.norm(self.op(input)))
             else:
-                x = input + self.drop_path(self.op(self.norm(input)))
+                x = self.drop_path.residual(input, self.op(self.norm(input)))
         if self.mlp_branch:
             if self.post_norm:
                 x = x + self.drop_path(self.norm2(self.mlp(x)))
             else:
-                x = x + self.drop_path(self.mlp(self.norm2(x)))
+                x = self.drop_path.residual(x, self.mlp(self.norm2(x)))
         return x
 
     def forward(self, input: torch.Tensor):
