@@ -473,3 +473,28 @@ def test_im2col_col2im_kx1(dtype, H, C, k, stride, pad):
     ref.float().backward(g.float())
     tol = 0 if dtype == torch.float32 and stride >= k else (1e-6 if dtype == torch.float32 else 2e-2)
     assert (x.grad.float() - xr.grad.float()).abs().max() <= tol * max(1.0, xr.grad.float().abs().max().item())
+
+
+@pytest.mark.gpu
+def test_spectral_power_iteration_batched_matches_single():
+    """All 30 weights of a MultiPeriodDiscriminator in one launch per phase == one matrix at a time, and both
+    == torch's power iteration (CPU)."""
+    import copy
+    from vm_asr_amd.discriminator import MultiPeriodDiscriminator
+    torch.manual_seed(3)
+    ref = MultiPeriodDiscriminator(hidden=4)           # CPU: torch ops
+    a, b = copy.deepcopy(ref).to(DEV), copy.deepcopy(ref).to(DEV)
+    for m in a.spectral_norms():
+        m.train()
+    assert b.power_iterate_all(3)                      # batched HIP
+    assert b._sn_batch.n == 30
+    for mod_r, mod_a, mod_b in zip(ref.modules(), a.modules(), b.modules()):
+        if isinstance(mod_r, torch.nn.Conv2d):
+            w = mod_r.parametrizations.weight.original.detach().flatten(1)
+            sr, sa, sb = (m.parametrizations.weight[0] for m in (mod_r, mod_a, mod_b))
+            sr._power_method(w, 3)                     # torch (CPU)
+            sa._power_method(w.to(DEV), 3)             # single-matrix HIP
+            for got, what in ((sa, "single"), (sb, "batched")):
+                _close(got._u, sr._u.numpy(), 1e-4, 1e-5, f"u {what} {tuple(w.shape)}")
+                _close(got._v, sr._v.numpy(), 1e-4, 1e-5, f"v {what} {tuple(w.shape)}")
+    assert b.power_iterate_all(1) and float(b._sn_batch.ws.abs().max()) >= 0   # table reused, scratch sane

@@ -77,10 +77,114 @@ __global__ __launch_bounds__(1024) void l2_normalize_kernel(const float *__restr
     for (int i = threadIdx.x; i < n_clear; i += blockDim.x) clear[i] = 0.f;
 }
 
+// ---- all matrices of a model in one launch per phase -------------------------------------------
+// 30 spectrally normalised weights x 3 iterations x 4 phases = 360 launches of ~6 us per training
+// step when run one matrix at a time; here the four phases each cover every matrix (12 launches).
+// A workgroup finds its matrix by scanning the (<= 64 entry) prefix table in the descriptor array.
+
+__device__ __forceinline__ int find_item(const vmasr_spectral_item *__restrict__ it, const int n, const int bid,
+                                         const bool cols) {
+    int m = 0;
+    for (int i = 1; i < n; ++i) m = (bid >= (cols ? it[i].col_tile_start : it[i].row_block_start)) ? i : m;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void gemv_rows_multi_kernel(const vmasr_spectral_item *__restrict__ items, const int n) {
+    const int m = find_item(items, n, blockIdx.x, false);
+    const vmasr_spectral_item it = items[m];
+    const int lane = threadIdx.x & 63;
+    const int r = (blockIdx.x - it.row_block_start) * 4 + (threadIdx.x >> 6);
+    if (r >= it.R) return;
+    const float *row = it.W + (size_t)r * it.C;
+    const float *v = it.v;
+    float acc = 0.f;
+    if ((it.C & 3) == 0) {
+        for (int c = lane * 4; c < it.C; c += 256) {
+            const float4 a = *reinterpret_cast<const float4 *>(row + c);
+            const float4 b = *reinterpret_cast<const float4 *>(v + c);
+            acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+        }
+    } else {
+        for (int c = lane; c < it.C; c += 64) acc = fmaf(row[c], v[c], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) it.t[r] = acc;
+}
+
+__global__ __launch_bounds__(256) void gemv_cols_multi_kernel(const vmasr_spectral_item *__restrict__ items, const int n) {
+    const int m = find_item(items, n, blockIdx.x, true);
+    const vmasr_spectral_item it = items[m];
+    const int local = blockIdx.x - it.col_tile_start;
+    const int ctiles = (it.C + 1023) / 1024;
+    const int c0 = ((local % ctiles) * 256 + threadIdx.x) * 4;
+    const int r0 = (local / ctiles) * kRowChunk, r1 = min(it.R, r0 + kRowChunk);
+    if (c0 >= it.C) return;
+    const float *W = it.W, *u = it.u;
+    const int C = it.C;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((C & 3) == 0) {
+        for (int r = r0; r < r1; ++r) {
+            const float4 w = *reinterpret_cast<const float4 *>(W + (size_t)r * C + c0);
+            const float ur = u[r];
+            a[0] = fmaf(w.x, ur, a[0]); a[1] = fmaf(w.y, ur, a[1]); a[2] = fmaf(w.z, ur, a[2]); a[3] = fmaf(w.w, ur, a[3]);
+        }
+    } else {
+        for (int r = r0; r < r1; ++r) {
+            const float ur = u[r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c0 + i < C) a[i] = fmaf(W[(size_t)r * C + c0 + i], ur, a[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (c0 + i < C) atomicAdd(it.s + c0 + i, a[i]);
+}
+
+// one workgroup per matrix: COLS ? (v = normalize(s), s = 0) : (u = normalize(t))
+template <bool COLS>
+__global__ __launch_bounds__(1024) void l2_normalize_multi_kernel(const vmasr_spectral_item *__restrict__ items, const float eps) {
+    const vmasr_spectral_item it = items[blockIdx.x];
+    float *x = COLS ? it.s : it.t;
+    float *y = COLS ? it.v : it.u;
+    const int len = COLS ? it.C : it.R;
+    __shared__ float s_part[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) acc = fmaf(x[i], x[i], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_part[w];
+    const float inv = 1.f / fmaxf(sqrtf(tot), eps);
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        y[i] = x[i] * inv;
+        if (COLS) x[i] = 0.f;
+    }
+}
+
 }  // namespace
 }  // namespace vmasr
 
 using namespace vmasr;
+
+// `items`: n descriptors in DEVICE memory (W, u, v, scratch t (R floats) and s (C floats, zero on entry and
+// on exit), prefix sums of 4-row blocks and of (1024-column x 32-row) tiles); total_* = the two grid sizes;
+// weight_bytes = sum of R*C*4 (the algorithmic bytes of one matrix-vector phase, for the profiler).
+VMASR_EXPORT int vmasr_spectral_power_iter_batched(const vmasr_spectral_item *items, int32_t n, int32_t total_row_blocks,
+                                                   int32_t total_col_tiles, int64_t weight_bytes, int32_t n_iter,
+                                                   float eps, vmasr_stream_t stream) {
+    VMASR_REQUIRE(items && n > 0 && n <= 64, VMASR_EINVAL, "spectral_power_iter_batched: 1..64 matrices");
+    VMASR_REQUIRE(total_row_blocks > 0 && total_col_tiles > 0 && n_iter >= 0, VMASR_EINVAL, "spectral_power_iter_batched: bad size");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int it = 0; it < n_iter; ++it) {
+        VMASR_LAUNCH(VMASR_K_SPECTRAL, (double)weight_bytes, gemv_rows_multi_kernel, dim3(total_row_blocks), dim3(256), 0, st, items, n);
+        VMASR_LAUNCH(VMASR_K_SPECTRAL, 0.0, (l2_normalize_multi_kernel<false>), dim3(n), dim3(1024), 0, st, items, eps);
+        VMASR_LAUNCH(VMASR_K_SPECTRAL, (double)weight_bytes, gemv_cols_multi_kernel, dim3(total_col_tiles), dim3(256), 0, st, items, n);
+        VMASR_LAUNCH(VMASR_K_SPECTRAL, 0.0, (l2_normalize_multi_kernel<true>), dim3(n), dim3(1024), 0, st, items, eps);
+    }
+    return check_launch("spectral_power_iter_batched");
+}
 
 // n_iter rounds of  u <- normalize(W v);  v <- normalize(W^T u)  in place.  W (R,C) fp32 row-major,
 // u (R), v (C); ws: (R + C) floats of scratch.

@@ -67,6 +67,49 @@ class _SpectralNorm(nn.Module):
             return weight / sigma
 
 
+class SpectralBatch:
+    """Power iteration of MANY _SpectralNorm modules in one launch per phase
+    (vmasr_spectral_power_iter_batched): the descriptor table (pointers to the fp32 weights, u, v and
+    scratch) is built once on the device; the pointers are those of parameters and buffers, which live
+    at fixed addresses for the life of the model on its device."""
+
+    def __init__(self, modules, weights):
+        import numpy as np
+        assert 0 < len(modules) <= 64
+        dev = weights[0].device
+        self.modules, self.eps = list(modules), float(modules[0].eps)
+        mats = [w.detach() for w in weights]
+        assert all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in mats)
+        shapes = [(w.shape[0], w[0].numel()) for w in mats]
+        self.ws = torch.zeros(sum(r + c for r, c in shapes), dtype=torch.float32, device=dev)
+        item = np.dtype([("W", "u8"), ("u", "u8"), ("v", "u8"), ("t", "u8"), ("s", "u8"),
+                         ("R", "i4"), ("C", "i4"), ("rb", "i4"), ("ct", "i4")])
+        tab = np.zeros(len(mats), dtype=item)
+        off = rb = ct = 0
+        for i, (m, w, (r, c)) in enumerate(zip(self.modules, mats, shapes)):
+            tab[i] = (w.data_ptr(), m._u.data_ptr(), m._v.data_ptr(), self.ws.data_ptr() + 4 * off,
+                      self.ws.data_ptr() + 4 * (off + r), r, c, rb, ct)
+            off += r + c
+            rb += -(-r // 4)
+            ct += -(-c // 1024) * -(-r // 32)
+        self.n, self.row_blocks, self.col_tiles = len(mats), rb, ct
+        self.weight_bytes = sum(4 * r * c for r, c in shapes)
+        self.ptrs = [(w.data_ptr(), m._u.data_ptr(), m._v.data_ptr()) for m, w in zip(self.modules, mats)]
+        self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+
+    def matches(self, weights):
+        return len(weights) == self.n and all(
+            (w.data_ptr(), m._u.data_ptr(), m._v.data_ptr()) == p for m, w, p in zip(self.modules, weights, self.ptrs))
+
+    @torch.no_grad()
+    def run(self, n_iter):
+        dev = self.table.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().vmasr_spectral_power_iter_batched(
+                self.table.data_ptr(), self.n, self.row_blocks, self.col_tiles, self.weight_bytes, int(n_iter), self.eps,
+                _lib.current_stream(dev)), "spectral_power_iter_batched")
+
+
 def spectral_norm(module, name="weight", n_power_iterations=1, eps=1e-12):
     parametrize.register_parametrization(module, name, _SpectralNorm(getattr(module, name), n_power_iterations, eps))
     return module
@@ -292,6 +335,22 @@ class MultiPeriodDiscriminator(nn.Module):
 
     def spectral_norms(self):
         return [m for m in self.modules() if isinstance(m, _SpectralNorm)]
+
+    def power_iterate_all(self, n_iter):
+        """n_iter power iterations of every spectrally normalised weight, batched into one launch per phase.
+        Returns False (nothing done) when the model is not on the GPU in fp32."""
+        pairs = [(mod.parametrizations.weight[0], mod.parametrizations.weight.original)
+                 for mod in self.modules() if isinstance(mod, nn.Conv2d) and parametrize.is_parametrized(mod, "weight")
+                 and isinstance(mod.parametrizations.weight[0], _SpectralNorm)]
+        if not pairs or not all(w.is_cuda and w.dtype == torch.float32 for _, w in pairs) or len(pairs) > 64:
+            return False
+        weights = [w.detach() for _, w in pairs]
+        batch = getattr(self, "_sn_batch", None)
+        if batch is None or not batch.matches(weights):
+            batch = SpectralBatch([m for m, _ in pairs], weights)
+            object.__setattr__(self, "_sn_batch", batch)
+        batch.run(n_iter)
+        return True
 
     def forward(self, y, y_hat):
         y_real, y_gen, fmap_real, fmap_gen = [], [], [], []

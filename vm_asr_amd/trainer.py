@@ -459,8 +459,10 @@ class Trainer(BaseTrainer):
         @contextlib.contextmanager
         def ctx():
             saved = [m.n_power_iterations for m in sns]
+            n3 = 3 * saved[0] if saved else 3
+            batched = hasattr(mpd, "power_iterate_all") and mpd.power_iterate_all(n3)   # 12 launches for all 30 weights
             for m in sns:
-                m.n_power_iterations = 3 * saved[0] if saved else 3
+                m.n_power_iterations = 0 if batched else n3
             try:
                 with parametrize.cached():
                     yield
