@@ -14,6 +14,7 @@ Fixture families:
   model_tiny.npz  DualStreamInteractiveMambaUNet dims=8, n_fft=128 fwd + grads + LSD
   metric.npz      LSD / SNR / LSD-HF / LSD-LF on fixed pairs (model/metric.py)
   loss.npz        MultiResolutionSTFTLoss values + d/dx (model/loss.py:137-184)
+  model_variants.npz  the m2p / p2m / single ablation forwards on model_tiny's weights: output, LSD, grad norms
   mpd.npz         MultiPeriodDiscriminator hidden=2 scores / feature maps / LSGAN losses / grads
                   (model/discriminator.py:21-147, model/loss.py:188-235)
 """
@@ -280,6 +281,46 @@ def gen_model(ns):
     save("model_tiny.npz", **out)
 
 
+def gen_variants(ns):
+    """The ablation forwards (configs/vm_asr_48k_MPD_{M2P,P2M,SINGLE}.yaml -> interact = m2p / p2m / single,
+    model/model.py:1229-1552) on the weights, inputs and injected spectrogram of model_tiny.npz: output,
+    LSD and the L2 norm of every parameter gradient (small fixture: no second copy of the weights)."""
+    z = np.load(os.path.join(HERE, "model_tiny.npz"))
+    kw = dict(in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=8, ssm_d_state=1, ssm_ratio=2.0,
+              ssm_dt_rank="auto", ssm_act_layer="silu", ssm_conv=3, ssm_conv_bias=True,
+              ssm_drop_rate=0.0, ssm_init="v0", forward_type="v5", mlp_ratio=4.0,
+              mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False, drop_path_rate=0.1,
+              patch_norm=True, norm_layer="LN", patchembed_version="v2", downsample_version="v1",
+              upsample_version="v1", output_version="v3", concat_skip=True,
+              n_fft=128, hop_length=32, win_length=128, spectro_scale="log2", low_freq_replacement=True)
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    wave, target, hf, gy = (torch.from_numpy(z[k]) for k in ("wave", "target", "hf", "gy"))
+    mag_in, phase_in = torch.from_numpy(z["mag_in"]), torch.from_numpy(z["phase_in"])
+    out = {}
+    for variant in ("m2p", "p2m", "single"):
+        torch.manual_seed(123)
+        m = ns.model.DualStreamInteractiveMambaUNet(interact=variant, **kw)
+        patch_ss2d_to_cpu(ns, m)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not missing, missing
+        m.eval()
+        m._mag_phase = lambda x, _a=mag_in, _b=phase_in: (_a.clone(), _b.clone())   # the spectrogram of model_tiny.npz
+        y = m(wave, hf)
+        y.backward(gy)
+        out[f"{variant}_y"] = _np(y)
+        out[f"{variant}_lsd"] = np.array(ns.metric.lsd(y.detach().squeeze(1), target.squeeze(1)))
+        out[f"{variant}_n_unexpected"] = np.array(len(unexpected))
+        n_unused = 0
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                n_unused += 1
+            else:
+                out[f"{variant}_gradnorm::{k}"] = np.array(p.grad.double().norm().item())
+        out[f"{variant}_n_unused"] = np.array(n_unused)
+        print(f"  {variant}: {n_unused} tensors without grad, {len(unexpected)} unexpected keys")
+    save("model_variants.npz", **out)
+
+
 def gen_loss(ns):
     """MultiResolutionSTFTLoss (model/loss.py:137-184) values and d/dx on a fixed pair."""
     g = torch.Generator().manual_seed(6)
@@ -352,7 +393,7 @@ def gen_metric(ns):
 
 if __name__ == "__main__":
     ns = load_reference()
-    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss", "mpd"]
+    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss", "mpd", "variants"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"](ns)

@@ -74,15 +74,64 @@ def test_ss2d_vssblock_hip(tag):
     _run_block(tag, "cuda:0")
 
 
-def _tiny_model():
+def _tiny_model(interact="dual"):
     from vm_asr_amd.model import DualStreamInteractiveMambaUNet
     return DualStreamInteractiveMambaUNet(
         in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=8, ssm_d_state=1, ssm_ratio=2.0, ssm_dt_rank="auto",
         ssm_act_layer="silu", ssm_conv=3, ssm_conv_bias=True, ssm_drop_rate=0.0, ssm_init="v0", forward_type="v5",
         mlp_ratio=4.0, mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False, drop_path_rate=0.1, patch_norm=True,
         norm_layer="LN", patchembed_version="v2", downsample_version="v1", upsample_version="v1",
-        output_version="v3", concat_skip=True, interact="dual", n_fft=128, hop_length=32, win_length=128,
+        output_version="v3", concat_skip=True, interact=interact, n_fft=128, hop_length=32, win_length=128,
         spectro_scale="log2", low_freq_replacement=True)
+
+
+def _run_variant(device, variant):
+    """Ablation forwards m2p / p2m / single (model/model.py:1229-1552) on model_tiny's weights and inputs:
+    output, LSD and every parameter-gradient norm vs the reference (tests/golden/model_variants.npz)."""
+    import oracle
+    import vm_asr_amd.model as M
+    z, v = np.load(os.path.join(GOLDEN, "model_tiny.npz")), np.load(os.path.join(GOLDEN, "model_variants.npz"))
+    m = _tiny_model(variant)
+    missing, unexpected = m.load_state_dict(_sd(z, "sd::"), strict=False)
+    assert not missing and len(unexpected) == int(v[f"{variant}_n_unexpected"])   # same parameter set as the reference variant
+    m.eval()
+    if device == "cpu":
+        use_oracle(m)
+    m = m.to(device)
+    wave, hf = torch.from_numpy(z["wave"]).to(device), torch.from_numpy(z["hf"]).to(device)
+    mag_in, phase_in = torch.from_numpy(z["mag_in"]).to(device), torch.from_numpy(z["phase_in"]).to(device)
+    saved = M.wav2spectro
+    M.wav2spectro = lambda *a, **k: (mag_in.clone(), phase_in.clone())
+    try:
+        y = m(wave, hf)
+    finally:
+        M.wav2spectro = saved
+    _close(y, v[f"{variant}_y"], what=f"{variant} wave out")
+    y.backward(torch.from_numpy(z["gy"]).to(device))
+    n_none = 0
+    for k, p in m.named_parameters():
+        key = f"{variant}_gradnorm::{k}"
+        if p.grad is None:
+            n_none += 1
+            assert key not in v.files, k
+        else:
+            want = float(v[key])
+            assert abs(p.grad.double().norm().item() - want) <= 2e-3 * max(want, 1e-3), (k, want)
+    assert n_none == int(v[f"{variant}_n_unused"])
+    lsd = oracle.lsd(y.detach().cpu().numpy()[:, 0], z["target"][:, 0])
+    assert abs(lsd - float(v[f"{variant}_lsd"])) < 1e-4
+
+
+@pytest.mark.parametrize("variant", ["m2p", "p2m", "single"])
+def test_ablation_variants_cpu_oracle_backend(variant):
+    with oracle_stft_patch():
+        _run_variant("cpu", variant)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["m2p", "p2m", "single"])
+def test_ablation_variants_hip(variant):
+    _run_variant("cuda:0", variant)
 
 
 def _run_tiny(device):
