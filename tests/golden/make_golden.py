@@ -15,6 +15,7 @@ Fixture families:
   metric.npz      LSD / SNR / LSD-HF / LSD-LF on fixed pairs (model/metric.py)
   loss.npz        MultiResolutionSTFTLoss values + d/dx (model/loss.py:137-184)
   model_variants.npz  the m2p / p2m / single ablation forwards on model_tiny's weights: output, LSD, grad norms
+  fullsize.npz    full-size generator forward (dims 16, n_fft 1024) at 16 kHz and 48 kHz: clip, output, LSD
   mpd.npz         MultiPeriodDiscriminator hidden=2 scores / feature maps / LSGAN losses / grads
                   (model/discriminator.py:21-147, model/loss.py:188-235)
 """
@@ -321,6 +322,45 @@ def gen_variants(ns):
     save("model_variants.npz", **out)
 
 
+def gen_fullsize(ns):
+    """BASELINE.json configs[0] / configs[1]: the full-size generator (dims 16, n_fft 1024) forward on one
+    synthetic clip, 16 kHz (hop 80, T 40 880) and 48 kHz (hop 240, T 122 640), through the reference's CPU
+    selective_scan_ref path; weights from synth.synth_state (not stored), phase indeterminacies pinned
+    (synth.canonical_phase).  Stored: the clip, the output wave and its LSD against a second clip."""
+    from synth import canonical_phase, synth_state
+    out = {}
+    for tag, hop, T in (("16k", 80, 40880), ("48k", 240, 122640)):
+        torch.manual_seed(123)
+        m = ns.model.DualStreamInteractiveMambaUNet(
+            in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=16, ssm_d_state=1, ssm_ratio=2.0,
+            ssm_dt_rank="auto", ssm_act_layer="silu", ssm_conv=3, ssm_conv_bias=True, ssm_drop_rate=0.0,
+            ssm_init="v0", forward_type="v5", mlp_ratio=4.0, mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False,
+            drop_path_rate=0.1, patch_norm=True, norm_layer="LN", patchembed_version="v2", downsample_version="v1",
+            upsample_version="v1", output_version="v3", concat_skip=True, interact="dual",
+            n_fft=1024, hop_length=hop, win_length=1024, spectro_scale="log2", low_freq_replacement=True)
+        patch_ss2d_to_cpu(ns, m)
+        synth_state(m)
+        m.eval()
+        g = torch.Generator().manual_seed(31)
+        wave = 0.1 * torch.randn(1, 1, T, generator=g)
+        target = 0.1 * torch.randn(1, 1, T, generator=g)
+        hf = torch.full((1,), 171, dtype=torch.int64)
+        orig = m._mag_phase
+
+        def pinned(x, _f=orig):
+            mag, phase = _f(x)
+            return mag, canonical_phase(phase)
+        m._mag_phase = pinned
+        import time
+        t0 = time.time()
+        with torch.no_grad():
+            y = m(wave, hf)
+        print(f"  {tag}: reference forward {time.time() - t0:.1f} s, |y|max {y.abs().max().item():.4f}")
+        out.update({f"{tag}_wave": _np(wave), f"{tag}_target": _np(target), f"{tag}_hf": _np(hf), f"{tag}_y": _np(y),
+                    f"{tag}_lsd": np.array(ns.metric.lsd(y.squeeze(1), target.squeeze(1)))})
+    save("fullsize.npz", **out)
+
+
 def gen_loss(ns):
     """MultiResolutionSTFTLoss (model/loss.py:137-184) values and d/dx on a fixed pair."""
     g = torch.Generator().manual_seed(6)
@@ -393,7 +433,7 @@ def gen_metric(ns):
 
 if __name__ == "__main__":
     ns = load_reference()
-    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss", "mpd", "variants"]
+    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss", "mpd", "variants", "fullsize"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"](ns)

@@ -129,6 +129,30 @@ def test_scan_vs_oracle(shape):
             _close(got, w, 1e-4, _scaled(w), f"{name} tune={tune}")
 
 
+def test_scan_long_sequence_dstate32_stress():
+    """BASELINE.json configs[4]: d_state 32 with the n_fft 2048 geometry — the 1024x512 output block, L = 524 288,
+    8 rows, 32 states per row (the general-N path, 2 049 saved chunks).  Forward and every gradient vs the
+    oracle, walk and split plans agreeing with each other."""
+    from vm_asr_amd import selective_scan as ss
+    shape = (1, 8, 4, 32, 524288)
+    cpu = _scan_inputs(*shape, seed=5)
+    u, delta, A, Bm, Cm, D, bias, dout = [t.to(DEV) for t in cpu]
+    want = oracle.sscan_fwd(*[t.numpy() for t in cpu[:7]], True)
+    wants = oracle.sscan_bwd(*[t.numpy() for t in cpu[:7]], cpu[7].numpy(), True)
+    outs = []
+    for tune in ((-1, -1), (1, 0), (1, 1)):
+        ss.tune(*tune)
+        out, x = ss.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
+        assert x.shape == (1, 8, 2048, 64)
+        _close(out, want, 1e-4, _scaled(want), f"out tune={tune}")
+        got = ss.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
+        for name, g, w in zip(("du", "ddelta", "dA", "dB", "dC", "dD", "dbias"), got, wants):
+            _close(g, w, 2e-4, 2 * _scaled(w), f"{name} tune={tune}")       # dA/dbias sum 524 288 terms per entry
+        outs.append(out)
+    ss.tune(-1, -1)
+    assert torch.allclose(outs[1], outs[2], rtol=1e-4, atol=1e-4 * outs[1].abs().max().item())
+
+
 def test_scan_strided_inputs():
     """Non-contiguous batch/dim strides and unaligned bases are part of the operator contract
     (cus/selective_scan.cpp:80-95)."""
