@@ -113,10 +113,23 @@ __device__ __forceinline__ float shift_from_next_lane(float v, int lane, float l
 __device__ __forceinline__ float softplus_f(float x) {
     const float e = __expf(fminf(x, 20.f));
     const float u = 1.f + e;
-    const float big = __logf(u) * __fdividef(e, u - 1.f);
+    // e / (u - 1) as e * rcp(u - 1): one v_rcp_f32 instead of the ~12-instruction IEEE division sequence
+    // (the kernels are VALU-issue bound); u == 1 gives inf/NaN here, discarded by the select below
+    const float big = __logf(u) * (e * __builtin_amdgcn_rcpf(u - 1.f));
     const float small = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.33333334f), -0.5f), 1.f);
     const float sp = e < 0.015625f ? small : big;
     return x <= 20.f ? sp : x;
+}
+
+// softplus and its derivative sigmoid(x) = e / (1 + e) from ONE exponential (backward pass)
+__device__ __forceinline__ void softplus_sigmoid_f(float x, float &sp, float &sig) {
+    const float e = __expf(fminf(x, 20.f));
+    const float u = 1.f + e;
+    const float big = __logf(u) * (e * __builtin_amdgcn_rcpf(u - 1.f));
+    const float small = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.33333334f), -0.5f), 1.f);
+    const float s = e < 0.015625f ? small : big;
+    sp = x <= 20.f ? s : x;
+    sig = x <= 20.f ? e * __builtin_amdgcn_rcpf(u) : 1.f;
 }
 
 // ---- task geometry ----------------------------------------------------------------------
@@ -491,11 +504,16 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
 #pragma unroll
             for (int i = 0; i < kItems; ++i) {
                 const float v = dl[r][i] + bias[r];
-                dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
+                if (MODE == 2) {
+                    dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
+                } else if (p.delta_softplus) {
+                    softplus_sigmoid_f(v, dl[r][i], sig[r][i]);   // d softplus / dv = sigmoid(v) (1 above the threshold)
+                } else {
+                    dl[r][i] = v;
+                    sig[r][i] = 1.f;
+                }
                 if (!full && t0 + i >= L) dl[r][i] = 0.f;  // ragged tile: identity steps (a = 1, b = 0)
                 if (MODE != 2) {
-                    // d softplus / dv = sigmoid(v) (1 above the threshold)
-                    sig[r][i] = (p.delta_softplus && v <= 20.f) ? __fdividef(1.f, 1.f + __expf(-v)) : 1.f;
                     duv[r][i] = Dv[r] * dov[r][i];
                     ddv[r][i] = 0.f;
                     accD[r] = fmaf(dov[r][i], uv[r][i], accD[r]);
