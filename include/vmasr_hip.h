@@ -202,7 +202,8 @@ int vmasr_spectral_power_iter(const float *W, float *u, float *v, float *ws, int
 /* The same for n matrices at once (one launch per phase instead of per matrix and phase).  `items`: n
  * descriptors in DEVICE memory; t (R floats) and s (C floats; zero on entry, left zero) are per-matrix scratch;
  * row_block_start / col_tile_start: exclusive prefix sums of ceil(R/4) and ceil(C/1024)*ceil(R/32);
- * total_row_blocks / total_col_tiles: their totals; weight_bytes = sum of R*C*4.  n <= 64. */
+ * total_row_blocks / total_col_tiles: their totals; weight_bytes = sum of R*C*4; sigma: null or n floats
+ * receiving u^T W v of the final vectors.  n <= 64. */
 typedef struct vmasr_spectral_item {
     const float *W;
     float *u, *v, *t, *s;
@@ -210,7 +211,7 @@ typedef struct vmasr_spectral_item {
 } vmasr_spectral_item;
 int vmasr_spectral_power_iter_batched(const vmasr_spectral_item *items, int32_t n, int32_t total_row_blocks,
                                       int32_t total_col_tiles, int64_t weight_bytes, int32_t n_iter, float eps,
-                                      vmasr_stream_t stream);
+                                      float *sigma, vmasr_stream_t stream);
 
 /* Column / scatter operands of the period discriminator's (k,1) convolutions on channel-last sequences
  * (replaces the MIOpen convolutions behind model/discriminator.py:40-88 together with a GEMM):

@@ -132,3 +132,34 @@ def test_conv_kx1_gemm_form_matches_conv2d(H, C, Cout, k, stride, pad):
     want = torch.autograd.grad(ref, (x, w, b), gy)
     for g, r in zip(got, want):
         assert g.shape == r.shape and torch.allclose(g, r, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_mpd_batched_sigma_matches_module_path():
+    """The trainer's per-step scheme (all power iterations + sigmas in one batched launch set, W / sigma through
+    _SNDivFn) gives the same scores and the same gradients of the original weights as each module running its own
+    three power iterations and autograd's expression for sigma."""
+    import copy
+    from torch.nn.utils import parametrize
+    z, D = _load("cuda:0")
+    D.train()
+    E = copy.deepcopy(D)
+    y = torch.from_numpy(z["y"]).cuda()
+    for m in D.spectral_norms():
+        m.n_power_iterations = 3
+    with parametrize.cached():
+        sa, _ = D.forward_single(y)
+    assert E.power_iterate_all(3, with_sigma=True)
+    for m in E.spectral_norms():
+        m.n_power_iterations = 0
+    with parametrize.cached():
+        sb, _ = E.forward_single(y)
+    E.clear_sigmas()
+    la, lb = sum((s ** 2).mean() for s in sa), sum((s ** 2).mean() for s in sb)
+    la.backward(); lb.backward()
+    for a, b in zip(sa, sb):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    for (n, p), (_, q) in zip(D.named_parameters(), E.named_parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=2e-3, atol=1e-5 * max(1.0, p.grad.abs().max().item())), n
+    for ma, mb in zip(D.spectral_norms(), E.spectral_norms()):
+        assert torch.allclose(ma._u, mb._u, atol=1e-5) and torch.allclose(ma._v, mb._v, atol=1e-5)

@@ -163,6 +163,18 @@ __global__ __launch_bounds__(1024) void l2_normalize_multi_kernel(const vmasr_sp
     }
 }
 
+// sigma_m = u_m . t_m  (t = W v just computed): one workgroup per matrix
+__global__ __launch_bounds__(256) void sigma_multi_kernel(const vmasr_spectral_item *__restrict__ items, float *__restrict__ sigma) {
+    const vmasr_spectral_item it = items[blockIdx.x];
+    __shared__ float s_part[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < it.R; i += blockDim.x) acc = fmaf(it.u[i], it.t[i], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sigma[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
 }  // namespace
 }  // namespace vmasr
 
@@ -170,10 +182,11 @@ using namespace vmasr;
 
 // `items`: n descriptors in DEVICE memory (W, u, v, scratch t (R floats) and s (C floats, zero on entry and
 // on exit), prefix sums of 4-row blocks and of (1024-column x 32-row) tiles); total_* = the two grid sizes;
-// weight_bytes = sum of R*C*4 (the algorithmic bytes of one matrix-vector phase, for the profiler).
+// weight_bytes = sum of R*C*4 (the algorithmic bytes of one matrix-vector phase, for the profiler);
+// sigma: null, or n floats that receive u^T W v of the final vectors.
 VMASR_EXPORT int vmasr_spectral_power_iter_batched(const vmasr_spectral_item *items, int32_t n, int32_t total_row_blocks,
                                                    int32_t total_col_tiles, int64_t weight_bytes, int32_t n_iter,
-                                                   float eps, vmasr_stream_t stream) {
+                                                   float eps, float *sigma, vmasr_stream_t stream) {
     VMASR_REQUIRE(items && n > 0 && n <= 64, VMASR_EINVAL, "spectral_power_iter_batched: 1..64 matrices");
     VMASR_REQUIRE(total_row_blocks > 0 && total_col_tiles > 0 && n_iter >= 0, VMASR_EINVAL, "spectral_power_iter_batched: bad size");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -182,6 +195,10 @@ VMASR_EXPORT int vmasr_spectral_power_iter_batched(const vmasr_spectral_item *it
         VMASR_LAUNCH(VMASR_K_SPECTRAL, 0.0, (l2_normalize_multi_kernel<false>), dim3(n), dim3(1024), 0, st, items, eps);
         VMASR_LAUNCH(VMASR_K_SPECTRAL, (double)weight_bytes, gemv_cols_multi_kernel, dim3(total_col_tiles), dim3(256), 0, st, items, n);
         VMASR_LAUNCH(VMASR_K_SPECTRAL, 0.0, (l2_normalize_multi_kernel<true>), dim3(n), dim3(1024), 0, st, items, eps);
+    }
+    if (sigma) {  // sigma_m = u^T W v with the final u, v (what spectral_norm divides the weight by)
+        VMASR_LAUNCH(VMASR_K_SPECTRAL, (double)weight_bytes, gemv_rows_multi_kernel, dim3(total_row_blocks), dim3(256), 0, st, items, n);
+        VMASR_LAUNCH(VMASR_K_SPECTRAL, 0.0, sigma_multi_kernel, dim3(n), dim3(256), 0, st, items, sigma);
     }
     return check_launch("spectral_power_iter_batched");
 }

@@ -59,12 +59,36 @@ class _SpectralNorm(nn.Module):
 
     def forward(self, weight):
         with torch.autocast(device_type=weight.device.type, enabled=False):
+            pre = getattr(self, "_sigma_pre", None)
+            if pre is not None and self.training and self.n_power_iterations == 0 and weight.dtype == torch.float32:
+                # u, v and sigma = u^T W v of this step come from the batched launch (SpectralBatch.run)
+                return _SNDivFn.apply(weight, self._u, self._v, pre)
             w = weight.float().flatten(1)
             if self.training:
                 self._power_method(w, self.n_power_iterations)
             u, v = self._u.clone(), self._v.clone()
             sigma = (u * (w @ v.unsqueeze(1)).squeeze(1)).sum()
             return weight / sigma
+
+
+class _SNDivFn(torch.autograd.Function):
+    """W / sigma with sigma = u^T W v precomputed (u, v constants, as in torch's spectral_norm):
+    dL/dW = (g - <g, W/sigma> u v^T) / sigma  — two passes over the weight instead of the GEMV + outer-product
+    GEMM + five elementwise kernels autograd needs for the same expression."""
+
+    @staticmethod
+    def forward(ctx, weight, u, v, sigma):
+        out = weight / sigma
+        ctx.save_for_backward(out, u, v, sigma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, u, v, sigma = ctx.saved_tensors
+        g2, o2 = g.reshape(u.numel(), -1), out.reshape(u.numel(), -1)
+        s = torch.dot(g2.reshape(-1), o2.reshape(-1))
+        gw = torch.addcmul(g2, (u * (-s)).unsqueeze(1), v.unsqueeze(0)) / sigma
+        return gw.view_as(out), None, None, None
 
 
 class SpectralBatch:
@@ -95,6 +119,7 @@ class SpectralBatch:
         self.n, self.row_blocks, self.col_tiles = len(mats), rb, ct
         self.weight_bytes = sum(4 * r * c for r, c in shapes)
         self.ptrs = [(w.data_ptr(), m._u.data_ptr(), m._v.data_ptr()) for m, w in zip(self.modules, mats)]
+        self.sigma = torch.ones(len(mats), dtype=torch.float32, device=dev)
         self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
 
     def matches(self, weights):
@@ -102,12 +127,21 @@ class SpectralBatch:
             (w.data_ptr(), m._u.data_ptr(), m._v.data_ptr()) == p for m, w, p in zip(self.modules, weights, self.ptrs))
 
     @torch.no_grad()
-    def run(self, n_iter):
+    def run(self, n_iter, with_sigma=False):
+        """n_iter power iterations of every matrix; with_sigma: also sigma_m = u^T W v, handed to the modules
+        (`_sigma_pre`, a view of self.sigma) until clear_sigma()."""
         dev = self.table.device
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().vmasr_spectral_power_iter_batched(
                 self.table.data_ptr(), self.n, self.row_blocks, self.col_tiles, self.weight_bytes, int(n_iter), self.eps,
-                _lib.current_stream(dev)), "spectral_power_iter_batched")
+                self.sigma.data_ptr() if with_sigma else None, _lib.current_stream(dev)), "spectral_power_iter_batched")
+        if with_sigma:
+            for i, m in enumerate(self.modules):
+                object.__setattr__(m, "_sigma_pre", self.sigma[i])
+
+    def clear_sigma(self):
+        for m in self.modules:
+            object.__setattr__(m, "_sigma_pre", None)
 
 
 def spectral_norm(module, name="weight", n_power_iterations=1, eps=1e-12):
@@ -336,8 +370,9 @@ class MultiPeriodDiscriminator(nn.Module):
     def spectral_norms(self):
         return [m for m in self.modules() if isinstance(m, _SpectralNorm)]
 
-    def power_iterate_all(self, n_iter):
-        """n_iter power iterations of every spectrally normalised weight, batched into one launch per phase.
+    def power_iterate_all(self, n_iter, with_sigma=False):
+        """n_iter power iterations of every spectrally normalised weight, batched into one launch per phase
+        (with_sigma: the normalising sigmas too; call clear_sigmas() when the weights may change).
         Returns False (nothing done) when the model is not on the GPU in fp32."""
         pairs = [(mod.parametrizations.weight[0], mod.parametrizations.weight.original)
                  for mod in self.modules() if isinstance(mod, nn.Conv2d) and parametrize.is_parametrized(mod, "weight")
@@ -349,8 +384,13 @@ class MultiPeriodDiscriminator(nn.Module):
         if batch is None or not batch.matches(weights):
             batch = SpectralBatch([m for m, _ in pairs], weights)
             object.__setattr__(self, "_sn_batch", batch)
-        batch.run(n_iter)
+        batch.run(n_iter, with_sigma)
         return True
+
+    def clear_sigmas(self):
+        batch = getattr(self, "_sn_batch", None)
+        if batch is not None:
+            batch.clear_sigma()
 
     def forward(self, y, y_hat):
         y_real, y_gen, fmap_real, fmap_gen = [], [], [], []

@@ -460,7 +460,7 @@ class Trainer(BaseTrainer):
         def ctx():
             saved = [m.n_power_iterations for m in sns]
             n3 = 3 * saved[0] if saved else 3
-            batched = hasattr(mpd, "power_iterate_all") and mpd.power_iterate_all(n3)   # 12 launches for all 30 weights
+            batched = hasattr(mpd, "power_iterate_all") and mpd.power_iterate_all(n3, with_sigma=True)   # 14 launches for all 30 weights
             for m in sns:
                 m.n_power_iterations = 0 if batched else n3
             try:
@@ -469,6 +469,8 @@ class Trainer(BaseTrainer):
             finally:
                 for m, n in zip(sns, saved):
                     m.n_power_iterations = n
+                if batched:
+                    mpd.clear_sigmas()
         return ctx()
 
     def _optimizer_steps(self):
