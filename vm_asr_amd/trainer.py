@@ -6,11 +6,15 @@ file names and dict layout), re-designed for MI355X data parallelism, which the 
 not have (README.md:31):
 
   * one process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI); the clip batch
-    is sharded across ranks, gradients are all-reduced by DistributedDataParallel buckets
-    overlapped with backward; no data-path collective (SURVEY.md §8e);
+    is sharded across ranks; every model's gradients are packed into ONE flat fp32 buffer and
+    all-reduced by one call per model per step (dp_mode "flat": few large messages suit the
+    point-to-point xGMI links, and the step stays HIP-graph capturable); torch DDP buckets
+    overlapped with backward are the alternative dp_mode "ddp".  No data-path collective (SURVEY.md §8e);
   * the 129 `layers_decoder_phase` tensors never receive a gradient in the reference either
-    (model/model.py:1187) — they are excluded from the DDP reducer statically instead of paying
-    `find_unused_parameters` every step;
+    (model/model.py:1187) — they are left out of the flat buffer / the DDP reducer statically
+    instead of paying `find_unused_parameters` every step;
+  * the step is replayed as two HIP graphs (graph_step.py): forward + losses + both backwards +
+    gradient packing, then the fused AdamW steps + bf16 shadow-weight refresh;
   * the generator's adversarial/feature losses run through the discriminator with its
     parameters frozen, so the 164 MB MPD gradient is produced and all-reduced once per step
     (the reference fills and discards it during the G update, trainer/trainer.py:428-438);
