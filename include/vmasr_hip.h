@@ -217,9 +217,10 @@ int vmasr_spectral_power_iter_batched(const vmasr_spectral_item *items, int32_t 
  * (replaces the MIOpen convolutions behind model/discriminator.py:40-88 together with a GEMM):
  *   im2col: x (N, H, C) -> cols (N, H1, k, C), cols[n,h1,j,c] = x[n, h1*stride + j - pad, c] (0 outside),
  *           H1 = (H + 2*pad - k)/stride + 1;   col2im: the adjoint gather, dcols (N, H1, k, C) -> dx (N, H, C).
- * Contiguous tensors of `dtype` (VMASR_F32/F16/BF16). */
+ * rows_out: 0, or the number of column rows to write (>= N*H1): the surplus rows are zero-filled (padding of a
+ * stacked GEMM operand).  Contiguous tensors of `dtype` (VMASR_F32/F16/BF16). */
 int vmasr_im2col_kx1(const void *x, void *cols, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
-                     int32_t pad, int32_t dtype, vmasr_stream_t stream);
+                     int32_t pad, int64_t rows_out, int32_t dtype, vmasr_stream_t stream);
 int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                      int32_t pad, int32_t dtype, vmasr_stream_t stream);
 

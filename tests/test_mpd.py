@@ -163,3 +163,38 @@ def test_mpd_batched_sigma_matches_module_path():
         assert torch.allclose(p.grad, q.grad, rtol=2e-3, atol=1e-5 * max(1.0, p.grad.abs().max().item())), n
     for ma, mb in zip(D.spectral_norms(), E.spectral_norms()):
         assert torch.allclose(ma._u, mb._u, atol=1e-5) and torch.allclose(ma._v, mb._v, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", [False, True])
+def test_mpd_batched_layers_match_per_discriminator_path(amp, monkeypatch):
+    """Layer-synchronous MPD (stacked im2col + one batched GEMM per layer for all five discriminators) ==
+    the discriminators one by one: scores, feature maps, input gradient and every parameter gradient."""
+    import copy
+    z, D = _load("cuda:0")
+    D.eval()
+    E = copy.deepcopy(D)
+    y = torch.from_numpy(z["y"]).cuda()
+    res = {}
+    for tag, mod, flag in (("batched", D, "1"), ("single", E, "0")):
+        monkeypatch.setenv("VMASR_MPD_BATCHED", flag)
+        x = torch.from_numpy(z["y_hat"]).cuda().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            scores, fmaps = mod.forward_single(x)
+            loss = sum((s.float() ** 2).mean() for s in scores) + sum(f.float().abs().mean() for fm in fmaps for f in fm)
+        loss.backward()
+        res[tag] = (scores, fmaps, x.grad, {n: p.grad for n, p in mod.named_parameters()})
+    tol = 1e-1 if amp else 1e-4        # amp: two different bf16 evaluation orders through six layers (d/dx worst: ~7 %)
+    (sa, fa, ga, pa), (sb, fb, gb, pb) = res["batched"], res["single"]
+
+    def close(a, b, what):
+        a, b = a.float(), b.float()
+        assert a.shape == b.shape, what
+        assert (a - b).abs().max() <= tol * max(b.abs().max().item(), 1e-6), (what, (a - b).abs().max().item(), b.abs().max().item())
+    for i in range(N_DISC):
+        close(sa[i], sb[i], f"score {i}")
+        for j in range(N_FMAP):
+            close(fa[i][j], fb[i][j], f"fmap {i},{j}")
+    close(ga, gb, "d/dx")
+    for n in pa:
+        close(pa[n], pb[n], f"grad {n}")

@@ -64,7 +64,7 @@ SYMBOLS = {
     "vmasr_xproj_bwd": (ctypes.c_int, [c_vp] * 12 + [c_i32] * 7 + [c_vp]),
     "vmasr_spectral_power_iter": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, ctypes.c_float, c_vp]),
     "vmasr_spectral_power_iter_batched": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i32, ctypes.c_float, c_vp, c_vp]),
-    "vmasr_im2col_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_im2col_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_col2im_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),

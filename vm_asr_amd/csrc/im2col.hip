@@ -22,13 +22,14 @@ namespace {
 
 struct ColGeom {
     int N, H, C, k, stride, pad, H1;
+    long rows_out;  // im2col: rows written (>= N*H1; the surplus is zero-filled: padding of a stacked operand)
 };
 
 // V = elements per 16-byte vector (4 fp32 / 8 bf16); C % V == 0 on the vector path
 template <typename T, int V>
 __global__ __launch_bounds__(256) void im2col_kernel(const T *__restrict__ x, T *__restrict__ cols, const ColGeom g) {
     const int cv = g.C / V;                                   // vectors per tap
-    const long total = (long)g.N * g.H1 * g.k * cv;
+    const long total = g.rows_out * g.k * cv;
     using Vec = typename std::conditional<V == 1, T, uint4>::type;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % cv);
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T *__restrict__ x, T 
         const int n = (int)(r / g.H1);
         const int h = h1 * g.stride + j - g.pad;
         Vec v{};
-        if (h >= 0 && h < g.H) v = reinterpret_cast<const Vec *>(x + ((size_t)n * g.H + h) * g.C)[c];
+        if (n < g.N && h >= 0 && h < g.H) v = reinterpret_cast<const Vec *>(x + ((size_t)n * g.H + h) * g.C)[c];
         reinterpret_cast<Vec *>(cols)[i] = v;
     }
 }
@@ -88,7 +89,7 @@ int launch(bool fwd, const void *src, void *dst, const ColGeom &g, hipStream_t s
     constexpr int V = 16 / sizeof(T);
     const bool vec = (g.C % V == 0) && aligned_to(src, 16) && aligned_to(dst, 16);
     const long cvn = vec ? g.C / V : g.C;
-    const long total = fwd ? (long)g.N * g.H1 * g.k * cvn : (long)g.N * g.H * cvn;
+    const long total = fwd ? g.rows_out * g.k * cvn : (long)g.N * g.H * cvn;
     const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 64);   // grid-stride: ~64 workgroups per CU at most
     const double bytes = ((double)g.N * g.H * g.C + (double)g.N * g.H1 * g.k * g.C) * sizeof(T);
     if (fwd) {
@@ -102,12 +103,14 @@ int launch(bool fwd, const void *src, void *dst, const ColGeom &g, hipStream_t s
 }
 
 int run(bool fwd, const void *src, void *dst, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride, int32_t pad,
-        int32_t dtype, hipStream_t st) {
+        int64_t rows_out, int32_t dtype, hipStream_t st) {
     VMASR_REQUIRE(src && dst, VMASR_EINVAL, "im2col_kx1: null tensor");
     VMASR_REQUIRE(N > 0 && H > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && H + 2 * pad >= k, VMASR_EINVAL,
                   "im2col_kx1: bad geometry (N=%ld H=%d C=%d k=%d stride=%d pad=%d)", (long)N, H, C, k, stride, pad);
     VMASR_REQUIRE(N <= 0x7fffffff, VMASR_EINVAL, "im2col_kx1: too many sequences");
-    const ColGeom g{(int)N, H, C, k, stride, pad, (H + 2 * pad - k) / stride + 1};
+    const int H1 = (H + 2 * pad - k) / stride + 1;
+    VMASR_REQUIRE(rows_out == 0 || rows_out >= N * H1, VMASR_EINVAL, "im2col_kx1: rows_out smaller than N*H1");
+    const ColGeom g{(int)N, H, C, k, stride, pad, H1, rows_out ? (long)rows_out : (long)N * H1};
     switch (dtype) {
         case VMASR_F32: return launch<float>(fwd, src, dst, g, st);
         case VMASR_F16: return launch<f16_t>(fwd, src, dst, g, st);
@@ -123,11 +126,11 @@ int run(bool fwd, const void *src, void *dst, int64_t N, int32_t H, int32_t C, i
 using namespace vmasr;
 
 VMASR_EXPORT int vmasr_im2col_kx1(const void *x, void *cols, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
-                                  int32_t pad, int32_t dtype, vmasr_stream_t stream) {
-    return run(true, x, cols, N, H, C, k, stride, pad, dtype, static_cast<hipStream_t>(stream));
+                                  int32_t pad, int64_t rows_out, int32_t dtype, vmasr_stream_t stream) {
+    return run(true, x, cols, N, H, C, k, stride, pad, rows_out, dtype, static_cast<hipStream_t>(stream));
 }
 
 VMASR_EXPORT int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                                   int32_t pad, int32_t dtype, vmasr_stream_t stream) {
-    return run(false, dcols, dx, N, H, C, k, stride, pad, dtype, static_cast<hipStream_t>(stream));
+    return run(false, dcols, dx, N, H, C, k, stride, pad, 0, dtype, static_cast<hipStream_t>(stream));
 }

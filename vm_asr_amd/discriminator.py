@@ -15,7 +15,7 @@ from torch.nn.utils import parametrize
 from torch.nn.utils.parametrizations import weight_norm
 
 from . import _lib
-from .linear import linear as _linear, weight_grad as _weight_grad
+from .linear import _mm_acc, linear as _linear, weight_grad as _weight_grad
 from .streams import parallel as _parallel
 
 __all__ = ["PeriodDiscriminator", "MultiPeriodDiscriminator", "spectral_norm"]
@@ -160,7 +160,7 @@ class _Im2ColFn(torch.autograd.Function):
         H1 = (H + 2 * pad - k) // stride + 1
         with torch.cuda.device(x.device):
             cols = torch.empty((B, P, H1, k * C), dtype=x.dtype, device=x.device)
-            _lib.check(_lib.lib().vmasr_im2col_kx1(xc.data_ptr(), cols.data_ptr(), B * P, H, C, k, stride, pad,
+            _lib.check(_lib.lib().vmasr_im2col_kx1(xc.data_ptr(), cols.data_ptr(), B * P, H, C, k, stride, pad, 0,
                                                    _lib.torch_dtype_code(x.dtype), _lib.current_stream(x.device)), "im2col_kx1")
         ctx.geom = (B, P, H, C, k, stride, pad)
         return cols
@@ -299,6 +299,113 @@ def conv_kx1(x, weight, bias, stride, pad):
     return _conv_kx1_cl(x, weight, bias, stride, pad)
 
 
+# ---- all period discriminators, layer by layer (stacked GEMM operands) ---------------------------
+# The five period discriminators have the same layer shapes and nearly the same number of GEMM rows
+# (B*p*T'_p ~ B*T/3^l for every p), but run one after the other each of their GEMMs fills a fraction of the
+# 256 CUs (M ~ 4.7 k rows x N = 1024: 76 tiles of 256x256).  Stacked into one batched GEMM per layer they
+# fill the chip, and GELU / bias / weight casts run once per layer instead of once per discriminator.
+
+def _round_up(v, m):
+    return -(-v // m) * m
+
+
+class _StackedIm2ColFn(torch.autograd.Function):
+    """n channel-last inputs (B, P_i, H_i, C) -> one (n, rows, k*C) column tensor, slot i holding the im2col
+    of input i in its first B*P_i*H1_i rows and zeros below (vmasr_im2col_kx1 with rows_out)."""
+
+    @staticmethod
+    def forward(ctx, k, stride, pad, rows, *xs):
+        C, dt, dev = xs[0].shape[3], xs[0].dtype, xs[0].device
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            cols = torch.empty((len(xs), rows, k * C), dtype=dt, device=dev)
+            for i, x in enumerate(xs):
+                B, P, H, _ = x.shape
+                xc = x.contiguous()
+                _lib.check(lib.vmasr_im2col_kx1(xc.data_ptr(), cols[i].data_ptr(), B * P, H, C, k, stride, pad, rows,
+                                                _lib.torch_dtype_code(dt), _lib.current_stream(dev)), "im2col_kx1")
+        ctx.geom = (k, stride, pad, [tuple(x.shape) for x in xs])
+        return cols
+
+    @staticmethod
+    def backward(ctx, g):
+        k, stride, pad, shapes = ctx.geom
+        g = g.contiguous()
+        lib = _lib.lib()
+        dxs = []
+        with torch.cuda.device(g.device):
+            for i, (B, P, H, C) in enumerate(shapes):
+                dx = torch.empty((B, P, H, C), dtype=g.dtype, device=g.device)
+                _lib.check(lib.vmasr_col2im_kx1(g[i].data_ptr(), dx.data_ptr(), B * P, H, C, k, stride, pad,
+                                                _lib.torch_dtype_code(g.dtype), _lib.current_stream(g.device)), "col2im_kx1")
+                dxs.append(dx)
+        return (None, None, None, None, *dxs)
+
+
+class _BatchedLinearFn(torch.autograd.Function):
+    """y[i] = cols[i] @ W[i]^T + b[i] for the n stacked discriminators (one batched GEMM); backward: one batched
+    GEMM for the column gradient, the weight gradient split over the rows into a larger batch (fp32 sum)."""
+
+    @staticmethod
+    def forward(ctx, cols, weight, bias, cdt):
+        wc = weight.detach().to(cdt)                                   # (n, N, K): the operand of dcols = gy @ W
+        # The forward operand is a CONTIGUOUS (n, K, N) copy: batched bf16 GEMMs with a transposed-view B operand
+        # fault the GPU on ROCm 7.2 / hipBLASLt for e.g. (5, 36608, 640) x (5, 640, 512)^T (tools/bmm_probe.py);
+        # contiguous-B ("NN") and transposed-A ("TN", the weight gradient) forms are fine at every MPD shape.
+        y = torch.bmm(cols, wc.transpose(1, 2).contiguous()).add_(bias.detach().to(cdt).unsqueeze(1))
+        ctx.save_for_backward(cols, wc)
+        ctx.meta = (weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        cols, wc = ctx.saved_tensors
+        wdt, bdt = ctx.meta
+        gy = gy.contiguous()
+        n, M, N = gy.shape
+        K = cols.shape[2]
+        dcols = torch.bmm(gy, wc) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            acc = torch.float32 if gy.dtype in (torch.float16, torch.bfloat16) else gy.dtype
+            tiles = n * -(-N // 64) * -(-K // 64)
+            want = min(M // 2048, max(1, 512 // tiles))
+            S = max(d for d in range(1, max(1, want) + 1) if (M // 256) % d == 0) if M % 256 == 0 else 1
+            if S > 1:   # (n, S, M/S, .) -> batch n*S: the row split is a free view because S divides M
+                part = _mm_acc(gy.view(n * S, M // S, N).transpose(1, 2), cols.view(n * S, M // S, K), acc)
+                dw = part.view(n, S, N, K).sum(1)
+            else:
+                dw = _mm_acc(gy.transpose(1, 2), cols, acc)
+            dw = dw.to(wdt)
+        if ctx.needs_input_grad[2]:
+            db = gy.sum(1, dtype=torch.float32 if gy.dtype in (torch.float16, torch.bfloat16) else None).to(bdt)
+        return dcols, dw, db, None
+
+
+class _UnstackRowsFn(torch.autograd.Function):
+    """(n, rows, N) -> n views y[i, :M_i]; the backward assembles the stacked gradient with one copy per slot
+    (autograd's own select/slice backward would zero-fill a full-size tensor per slot)."""
+
+    @staticmethod
+    def forward(ctx, y, *Ms):
+        ctx.shape = tuple(y.shape)
+        ctx.Ms = Ms
+        return tuple(y[i, :m] for i, m in enumerate(Ms))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        full = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        for i, (g, m) in enumerate(zip(gs, ctx.Ms)):
+            if g is None:
+                full[i].zero_()
+            else:
+                full[i, :m].copy_(g)
+                if m < ctx.shape[1]:
+                    full[i, m:].zero_()
+        return (full, *([None] * len(ctx.Ms)))
+
+
 class PeriodDiscriminator(nn.Module):
     def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False, hidden=32):
         super().__init__()
@@ -350,9 +457,46 @@ class MultiPeriodDiscriminator(nn.Module):
         super().__init__()
         self.discriminators = nn.ModuleList([PeriodDiscriminator(p, hidden=hidden) for p in periods])
 
+    def _forward_batched(self, x, detach_weights=False):
+        """All discriminators layer by layer on stacked GEMM operands (GPU path).  Same scores and feature maps
+        (channel-last (B, p, T', C) views) as running the PeriodDiscriminators one by one."""
+        discs = list(self.discriminators)
+        n, (B, _, T) = len(discs), x.shape
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        cur = []
+        for d in discs:
+            xp, p = x, d.period
+            if T % p:
+                xp = F.pad(xp, (0, p - T % p), "reflect")
+            cur.append(xp.view(B, 1, -1, p).permute(0, 3, 2, 1).to(cdt))          # (B, p, T/p, 1)
+        fmaps = [[] for _ in discs]
+        for li in range(len(discs[0].layers) + 1):
+            layers = [d.layers[li] if li < len(d.layers) else d.conv_post for d in discs]
+            k, stride, pad = layers[0].kernel_size[0], layers[0].stride[0], layers[0].padding[0]
+            P = [c.shape[1] for c in cur]
+            H1 = [(c.shape[2] + 2 * pad - k) // stride + 1 for c in cur]
+            Ms = [B * p * h for p, h in zip(P, H1)]
+            cols = _StackedIm2ColFn.apply(k, stride, pad, _round_up(max(Ms), 256), *cur)
+            ws = [(l.weight.detach(), l.bias.detach()) if detach_weights else (l.weight, l.bias) for l in layers]
+            W = torch.stack([w[:, :, :, 0] for w, _ in ws])                         # (n, Cout, Cin, k)
+            W = W.permute(0, 1, 3, 2).reshape(n, W.shape[1], -1)                     # (tap, c) column order
+            y = _BatchedLinearFn.apply(cols, W, torch.stack([b for _, b in ws]), cdt)
+            if li < len(discs[0].layers):
+                y = F.gelu(y)
+            outs = _UnstackRowsFn.apply(y, *Ms)
+            cur = [o.view(B, p, h, -1) for o, p, h in zip(outs, P, H1)]
+            for f, c in zip(fmaps, cur):
+                f.append(c)
+        return [torch.flatten(c, 1, -1) for c in cur], fmaps
+
+    def _use_batched(self, x):
+        return x.is_cuda and os.environ.get("VMASR_MPD_BATCHED", "1") == "1" and len(self.discriminators) > 1
+
     def forward_single(self, x, detach_weights=False):
         """scores and feature maps of ONE signal batch (used for the generator pass, where the
         real-signal features of the discriminator pass are reused instead of recomputed)."""
+        if self._use_batched(x):
+            return self._forward_batched(x, detach_weights)
         res = _parallel([(lambda d=d: d(x, detach_weights)) for d in self.discriminators], x.device, "d")
         return [r[0] for r in res], [r[1] for r in res]
 
@@ -362,7 +506,11 @@ class MultiPeriodDiscriminator(nn.Module):
         n = y.shape[0]
         y_real, y_gen, fmap_real, fmap_gen = [], [], [], []
         both = torch.cat((y, y_hat), dim=0)
-        for s, f in _parallel([(lambda d=d: d(both)) for d in self.discriminators], y.device, "d"):
+        if self._use_batched(both):
+            res = list(zip(*self._forward_batched(both)))
+        else:
+            res = _parallel([(lambda d=d: d(both)) for d in self.discriminators], y.device, "d")
+        for s, f in res:
             y_real.append(s[:n]); y_gen.append(s[n:])
             fmap_real.append([t[:n] for t in f]); fmap_gen.append([t[n:] for t in f])
         return y_real, y_gen, fmap_real, fmap_gen
