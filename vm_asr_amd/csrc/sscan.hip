@@ -68,13 +68,24 @@ __device__ __forceinline__ Pair dpp_pair(Pair v) {  // lanes without a source in
 
 __device__ __forceinline__ Pair lane_pair(Pair v, int lane) { return {readlane_f(v.a, lane), readlane_f(v.b, lane)}; }
 
+// One Hillis-Steele stage inside the 16-lane rows, v <- then(v shifted by SH lanes, v), as TWO DPP-modified
+// VALU instructions: lanes without a source lane in their row are disabled by the DPP control (bound_ctrl 0),
+// i.e. keep v — exactly the identity the scan needs.  The compiler's own form of this (update_dpp + mul + fma)
+// is 7 instructions per stage: two identity moves, a nop, two DPP moves, mul, fmac; the kernels are
+// VALU-issue bound.  `s_nop 1`: the two wait states a DPP read needs after a VALU write of its source.
+#define VMASR_SCAN_STAGE(CTRL, SH)                                                                              \
+    asm volatile("s_nop 1\n\t"                                                                                  \
+                 "v_fmac_f32_dpp %0, %0, %1 " CTRL ":" #SH " row_mask:0xf bank_mask:0xf\n\t"                      \
+                 "v_mul_f32_dpp %1, %1, %1 " CTRL ":" #SH " row_mask:0xf bank_mask:0xf"                           \
+                 : "+v"(v.b), "+v"(v.a))
+
 // Forward scan of the 64 lane aggregates: `excl` = composition of lanes [0, lane), `total` =
 // composition of all lanes (wave-uniform).
 __device__ __forceinline__ void wave_scan_fwd(Pair v, int lane, Pair &excl, Pair &total) {
-    v = then(dpp_pair<kRowShr + 1>(v), v);
-    v = then(dpp_pair<kRowShr + 2>(v), v);
-    v = then(dpp_pair<kRowShr + 4>(v), v);
-    v = then(dpp_pair<kRowShr + 8>(v), v);  // inclusive inside each 16-lane row
+    VMASR_SCAN_STAGE("row_shr", 1);   // b <- a*b_prev + b first (uses the old a), then a <- a*a_prev
+    VMASR_SCAN_STAGE("row_shr", 2);
+    VMASR_SCAN_STAGE("row_shr", 4);
+    VMASR_SCAN_STAGE("row_shr", 8);   // inclusive inside each 16-lane row
     const Pair t0 = lane_pair(v, 15), t1 = lane_pair(v, 31), t2 = lane_pair(v, 47), t3 = lane_pair(v, 63);
     const Pair p2 = then(t0, t1), p3 = then(p2, t2);
     total = then(p3, t3);
@@ -86,10 +97,10 @@ __device__ __forceinline__ void wave_scan_fwd(Pair v, int lane, Pair &excl, Pair
 // Reverse scan (g_i = b_i + a_i g_{i+1}): `excl` = composition of lanes (lane, 63] applied from the
 // right, `total` = all lanes.
 __device__ __forceinline__ void wave_scan_rev(Pair v, int lane, Pair &excl, Pair &total) {
-    v = then(dpp_pair<kRowShl + 1>(v), v);
-    v = then(dpp_pair<kRowShl + 2>(v), v);
-    v = then(dpp_pair<kRowShl + 4>(v), v);
-    v = then(dpp_pair<kRowShl + 8>(v), v);  // suffix-inclusive inside each row
+    VMASR_SCAN_STAGE("row_shl", 1);
+    VMASR_SCAN_STAGE("row_shl", 2);
+    VMASR_SCAN_STAGE("row_shl", 4);
+    VMASR_SCAN_STAGE("row_shl", 8);   // suffix-inclusive inside each row
     const Pair t0 = lane_pair(v, 0), t1 = lane_pair(v, 16), t2 = lane_pair(v, 32), t3 = lane_pair(v, 48);
     const Pair s1 = then(t3, t2), s0 = then(s1, t1);  // rows to the right of row 1 / row 0
     total = then(s0, t0);
