@@ -5,7 +5,6 @@ state_dict layout, autograd plumbing) be checked on a machine without a GPU, and
 bench.py its `cpu_baseline` leg.  Never imported by the product."""
 from functools import partial
 
-import numpy as np
 import torch
 
 from . import oracle as oracle

@@ -1,5 +1,5 @@
 """Micro-benchmark of the selective-scan kernels on the SS2D call shapes (dev tool)."""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vm_asr_amd import selective_scan as ss
