@@ -86,7 +86,8 @@ __device__ __forceinline__ void load4(const T *__restrict__ p, int t, int len, f
 // vector-aligned): the choice is a scalar branch, not a per-lane one, so full tiles are straight-line
 // vector loads the scheduler can hoist and keep in flight.
 template <typename T, bool VEC>
-__device__ __forceinline__ void load4u(const T *__restrict__ p, int t, int len, float (&v)[4], bool full) {
+__device__ __forceinline__ void load4u(const T *__restrict__ p, int t, int len, float (&v)[4], bool full,
+                                       float fill = 0.f) {
     if (VEC && full) {
         if constexpr (sizeof(T) == 4) {
             const float4 q = *reinterpret_cast<const float4 *>(p + t);
@@ -99,7 +100,7 @@ __device__ __forceinline__ void load4u(const T *__restrict__ p, int t, int len, 
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (t + i < len) ? to_f32(p[t + i]) : 0.f;
+        for (int i = 0; i < 4; ++i) v[i] = (t + i < len) ? to_f32(p[t + i]) : fill;
     }
 }
 

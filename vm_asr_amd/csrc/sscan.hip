@@ -121,12 +121,17 @@ __device__ __forceinline__ float shift_from_next_lane(float v, int lane, float l
 
 // softplus with the reference's threshold (cus/selective_scan_fwd_kernel.cuh:115-118).
 // log1p(e) without the libm call: a 4-term series below 2^-6, Kahan's log(u)*e/(u-1) above.
+// ln(u) for u in [1, 2^29]: v_log_f32 (log2, 1 ulp) times ln 2.  HIP's __logf expands to the denormal-safe
+// OCML sequence (range check, ldexp, v_log_f32, a 4-instruction split multiply by ln 2, inf fix-up: 12
+// instructions) — none of which this argument range needs.
+__device__ __forceinline__ float ln_fast(float u) { return __builtin_amdgcn_logf(u) * 0.6931471805599453f; }
+
 __device__ __forceinline__ float softplus_f(float x) {
     const float e = __expf(fminf(x, 20.f));
     const float u = 1.f + e;
     // e / (u - 1) as e * rcp(u - 1): one v_rcp_f32 instead of the ~12-instruction IEEE division sequence
     // (the kernels are VALU-issue bound); u == 1 gives inf/NaN here, discarded by the select below
-    const float big = __logf(u) * (e * __builtin_amdgcn_rcpf(u - 1.f));
+    const float big = ln_fast(u) * (e * __builtin_amdgcn_rcpf(u - 1.f));
     const float small = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.33333334f), -0.5f), 1.f);
     const float sp = e < 0.015625f ? small : big;
     return x <= 20.f ? sp : x;
@@ -136,7 +141,7 @@ __device__ __forceinline__ float softplus_f(float x) {
 __device__ __forceinline__ void softplus_sigmoid_f(float x, float &sp, float &sig) {
     const float e = __expf(fminf(x, 20.f));
     const float u = 1.f + e;
-    const float big = __logf(u) * (e * __builtin_amdgcn_rcpf(u - 1.f));
+    const float big = ln_fast(u) * (e * __builtin_amdgcn_rcpf(u - 1.f));
     const float small = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.33333334f), -0.5f), 1.f);
     const float s = e < 0.015625f ? small : big;
     sp = x <= 20.f ? s : x;
@@ -262,7 +267,9 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             load4u<T, VEC>(u_row[r], t0, L, uv[r], full);
-            load4u<T, VEC>(dl_row[r], t0, L, dl[r], full);
+            // steps past the end of a ragged tile must be identity steps (delta = 0: a = 1, b = 0): they load
+            // the value that softplus / the bias add below maps to exactly 0, so no per-item masking is needed
+            load4u<T, VEC>(dl_row[r], t0, L, dl[r], full, p.delta_softplus ? -INFINITY : -bias[r]);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -272,13 +279,6 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
                 dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
                 outv[r][i] = Dv[r] * uv[r][i];
             }
-        if (!full) {  // ragged tile: steps past the end get delta = 0, i.e. a = 1, b = 0 (identity)
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int i = 0; i < kItems; ++i)
-                    if (t0 + i >= L) dl[r][i] = 0.f;
-        }
 
         for (int n = 0; n < N; ++n) {
             float Bv[kItems], Cv[kItems];
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
         float uv[R][kItems], dl[R][kItems], dov[R][kItems], duv[R][kItems], ddv[R][kItems], sig[R][kItems];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            load4u<T, VEC>(dl_row[r], t0, L, dl[r], full);
+            load4u<T, VEC>(dl_row[r], t0, L, dl[r], full, p.delta_softplus ? -INFINITY : -bias[r]);   // identity steps past the end
             load4u<T, VEC>(do_row[r], t0, L, dov[r], full);
             if (MODE != 2) load4u<T, VEC>(u_row[r], t0, L, uv[r], full);
         }
@@ -523,7 +523,6 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
                     dl[r][i] = v;
                     sig[r][i] = 1.f;
                 }
-                if (!full && t0 + i >= L) dl[r][i] = 0.f;  // ragged tile: identity steps (a = 1, b = 0)
                 if (MODE != 2) {
                     duv[r][i] = Dv[r] * dov[r][i];
                     ddv[r][i] = 0.f;
