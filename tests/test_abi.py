@@ -40,9 +40,10 @@ def test_struct_layout_matches_header():
 #include <stddef.h>
 #include "vmasr_hip.h"
 int main(void){
-  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(vmasr_sscan_params), offsetof(vmasr_sscan_params, A_d_stride),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(vmasr_sscan_params), offsetof(vmasr_sscan_params, A_d_stride),
          offsetof(vmasr_sscan_params, A_ptr), offsetof(vmasr_sscan_params, x_ptr),
-         sizeof(vmasr_sscan_bwd_params), offsetof(vmasr_sscan_bwd_params, ws_bytes));
+         sizeof(vmasr_sscan_bwd_params), offsetof(vmasr_sscan_bwd_params, ws_bytes),
+         sizeof(vmasr_spectral_item), offsetof(vmasr_spectral_item, R), offsetof(vmasr_spectral_item, col_tile_start));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -52,7 +53,9 @@ int main(void){
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     P, Q = _lib.SScanParams, _lib.SScanBwdParams
-    want = [ctypes.sizeof(P), P.A_d_stride.offset, P.A_ptr.offset, P.x_ptr.offset, ctypes.sizeof(Q), Q.ws_bytes.offset]
+    # vmasr_spectral_item is written from numpy (vm_asr_amd/discriminator.py:SpectralBatch): 5 pointers + 4 int32
+    want = [ctypes.sizeof(P), P.A_d_stride.offset, P.A_ptr.offset, P.x_ptr.offset, ctypes.sizeof(Q), Q.ws_bytes.offset,
+            56, 40, 52]
     assert got == want
 
 
