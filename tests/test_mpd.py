@@ -198,3 +198,30 @@ def test_mpd_batched_layers_match_per_discriminator_path(amp, monkeypatch):
     close(ga, gb, "d/dx")
     for n in pa:
         close(pa[n], pb[n], f"grad {n}")
+
+
+@pytest.mark.gpu
+def test_feature_loss_stacked_matches_per_map_loss():
+    """Feature-matching loss over the stacked per-layer tensors of the batched discriminator pass == the
+    reference's per-feature-map form (model/loss.py:227-235), value and gradient wrt the generated signal."""
+    from vm_asr_amd.discriminator import StackedFeatures
+    from vm_asr_amd.loss import HiFiGANLoss
+    z, D = _load("cuda:0")
+    D.eval()
+    y = torch.from_numpy(z["y"]).cuda()
+    L = HiFiGANLoss("lsgan")
+    grads, vals = [], []
+    for stacked in (True, False):
+        y_hat = torch.from_numpy(z["y_hat"]).cuda().requires_grad_()
+        _, _, fr, _ = D.forward_pair(y, y_hat.detach())
+        real = fr.detach()
+        _, gen = D.forward_single(y_hat, detach_weights=True)
+        assert isinstance(real, StackedFeatures) and isinstance(gen, StackedFeatures) and real.valid == gen.valid
+        if not stacked:
+            real, gen = [list(f) for f in real], [list(f) for f in gen]       # plain lists: the per-map path
+        loss = L.feature_loss(real, gen)
+        loss.backward()
+        vals.append(loss.item()); grads.append(y_hat.grad.clone())
+    assert abs(vals[0] - vals[1]) <= 1e-5 * abs(vals[1])
+    assert abs(vals[1] - float(z["f_loss"])) <= 1e-4 * abs(float(z["f_loss"]))          # and == the reference's value
+    assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-6 * grads[1].abs().max().item() + 1e-9)

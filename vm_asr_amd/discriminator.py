@@ -406,6 +406,46 @@ class _UnstackRowsFn(torch.autograd.Function):
         return (full, *([None] * len(ctx.Ms)))
 
 
+class StackedFeatures(list):
+    """Feature maps of the batched discriminator pass: the usual list (per discriminator) of lists (per layer) of
+    channel-last views, plus the stacked per-layer tensors they are views of — `stacks[l]` is (n, rows_l, N_l)
+    and `valid[l][i]` says how many leading rows of slot i belong to this signal — so that losses over ALL
+    discriminators can run as one kernel per layer (feature_loss_stacked) instead of one per feature map."""
+
+    def __init__(self, per_disc, stacks, valid):
+        super().__init__(per_disc)
+        self.stacks, self.valid = stacks, valid
+
+    def detach(self):
+        return StackedFeatures([[f.detach() for f in fs] for fs in self], [y.detach() for y in self.stacks], self.valid)
+
+
+_FEAT_MASKS = {}
+
+
+def feature_loss_stacked(real, gen):
+    """HiFi-GAN feature-matching loss (model/loss.py:227-235: mean over feature maps of mean |r - g|) from two
+    StackedFeatures with the same per-slot row counts; None if the inputs do not qualify."""
+    if not (isinstance(real, StackedFeatures) and isinstance(gen, StackedFeatures)) or real.valid != gen.valid:
+        return None
+    n_maps = sum(len(fs) for fs in gen)
+    total = None
+    for yr, yg, valid in zip(real.stacks, gen.stacks, real.valid):
+        R, N = min(yr.shape[1], yg.shape[1]), yg.shape[2]
+        if max(valid) > R:
+            return None
+        key = (yg.device, valid, R, N, n_maps)
+        mask = _FEAT_MASKS.get(key)
+        if mask is None:       # 1 / (elements of the feature map * number of maps) on its rows, 0 on padding rows
+            rows = torch.arange(R, device=yg.device).unsqueeze(0)
+            m = torch.tensor(valid, device=yg.device).unsqueeze(1)
+            mask = ((rows < m).float() / (m.float() * N * n_maps)).unsqueeze(2)
+            _FEAT_MASKS[key] = mask
+        term = ((yg[:, :R] - yr[:, :R]).abs() * mask).sum()
+        total = term if total is None else total + term
+    return total
+
+
 class PeriodDiscriminator(nn.Module):
     def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False, hidden=32):
         super().__init__()
@@ -469,7 +509,7 @@ class MultiPeriodDiscriminator(nn.Module):
             if T % p:
                 xp = F.pad(xp, (0, p - T % p), "reflect")
             cur.append(xp.view(B, 1, -1, p).permute(0, 3, 2, 1).to(cdt))          # (B, p, T/p, 1)
-        fmaps = [[] for _ in discs]
+        fmaps, stacks, valid = [[] for _ in discs], [], []
         for li in range(len(discs[0].layers) + 1):
             layers = [d.layers[li] if li < len(d.layers) else d.conv_post for d in discs]
             k, stride, pad = layers[0].kernel_size[0], layers[0].stride[0], layers[0].padding[0]
@@ -487,7 +527,9 @@ class MultiPeriodDiscriminator(nn.Module):
             cur = [o.view(B, p, h, -1) for o, p, h in zip(outs, P, H1)]
             for f, c in zip(fmaps, cur):
                 f.append(c)
-        return [torch.flatten(c, 1, -1) for c in cur], fmaps
+            stacks.append(y)
+            valid.append(tuple(Ms))
+        return [torch.flatten(c, 1, -1) for c in cur], StackedFeatures(fmaps, stacks, valid)
 
     def _use_batched(self, x):
         return x.is_cuda and os.environ.get("VMASR_MPD_BATCHED", "1") == "1" and len(self.discriminators) > 1
@@ -507,7 +549,11 @@ class MultiPeriodDiscriminator(nn.Module):
         y_real, y_gen, fmap_real, fmap_gen = [], [], [], []
         both = torch.cat((y, y_hat), dim=0)
         if self._use_batched(both):
-            res = list(zip(*self._forward_batched(both)))
+            scores, feats = self._forward_batched(both)
+            y_real, y_gen = [s[:n] for s in scores], [s[n:] for s in scores]
+            # the real half of every slot is its leading rows (batch-major row order)
+            fmap_real = StackedFeatures([[t[:n] for t in f] for f in feats], feats.stacks, [tuple(m // 2 for m in v) for v in feats.valid])
+            return y_real, y_gen, fmap_real, [[t[n:] for t in f] for f in feats]
         else:
             res = _parallel([(lambda d=d: d(both)) for d in self.discriminators], y.device, "d")
         for s, f in res:

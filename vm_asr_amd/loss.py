@@ -94,6 +94,10 @@ class HiFiGANLoss:
         return loss
 
     def feature_loss(self, fmap_r, fmap_g):
+        from .discriminator import feature_loss_stacked
+        fast = feature_loss_stacked(fmap_r, fmap_g)     # batched discriminator pass: one kernel chain per layer
+        if fast is not None:
+            return fast
         loss, n = 0, 0
         for dr, dg in zip(fmap_r, fmap_g):
             for rl, gl in zip(dr, dg):

@@ -349,7 +349,7 @@ class Trainer(BaseTrainer):
             fake = wave_out.detach().float()
             mpd = self.models["mpd"]
             y_real, y_gen, fr, _ = (mpd(wave_target, fake) if isinstance(mpd, DDP) else mpd.forward_pair(wave_target, fake))
-            fmap_real = [[f.detach() for f in fs] for fs in fr]
+            fmap_real = fr.detach() if hasattr(fr, "stacks") else [[f.detach() for f in fs] for fs in fr]
             d = self.higi_gan_loss.discriminator_loss(y_real, y_gen)
             if self.config.TRAIN.ADVERSARIAL.GAN_LOSS_TYPE == "wgan-gp":
                 d = d + self.higi_gan_loss.gradient_penalty(wave_target, fake, unwrap(self.models["mpd"]))
