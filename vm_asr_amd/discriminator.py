@@ -1,10 +1,22 @@
-"""Multi-period discriminator (PyTorch / MIOpen convs): the adversary of the MPD configs.
+"""Multi-period discriminator: the adversary of the MPD configs.
 
 Re-statement of model/discriminator.py:21-147 (HiFi-GAN style, periods 2,3,5,7,11, hidden 32
 -> 41.09 M parameters).  The reference's inverted ternary (`weight_norm if use_spectral_norm
 else spectral_norm`, :37) means the default `use_spectral_norm=False` yields SPECTRAL norm;
 that is reproduced so state_dicts (parametrizations.weight.original + power-iteration
 buffers) stay compatible.  MSD (:174-337) is not enabled by any yaml and is not built.
+
+How it runs on the GPU (MIOpen has only `naive_conv_*` fallbacks for these (k,1) convolutions):
+
+  * signals folded to channel-last sequences (B, period, T/period, C); every convolution is
+    `vmasr_im2col_kx1` (HIP gather) + a hipBLASLt GEMM + `vmasr_col2im_kx1` in the backward;
+  * the five period discriminators run layer by layer on stacked operands — one batched GEMM per
+    layer (`_forward_batched`); the one-by-one path (`PeriodDiscriminator.forward`) is the same
+    arithmetic and is what `forward(y, y_hat)` (the reference's call) and the CPU use;
+  * spectral norm: power iteration and sigma for all 30 weights in one launch per phase
+    (`SpectralBatch` -> `vmasr_spectral_power_iter_batched`), W / sigma as one autograd function;
+  * `_ConvKx1Fn` (GEMMs on shifted views, no im2col) is an exact alternative kept opt-in
+    (`VMASR_MPD_CONV=gemm`): measured slower than im2col + one GEMM.
 """
 import os
 
@@ -543,8 +555,9 @@ class MultiPeriodDiscriminator(nn.Module):
         return [r[0] for r in res], [r[1] for r in res]
 
     def forward_pair(self, y, y_hat):
-        """Same results as forward(y, y_hat) with ONE pass per discriminator over the stacked batch
-        [y; y_hat] (same weights, identical per-sample arithmetic, half the kernel launches)."""
+        """Same results as forward(y, y_hat) from ONE pass over the stacked batch [y; y_hat] (same weights,
+        identical per-sample arithmetic); on the GPU all discriminators advance layer by layer together
+        (_forward_batched) and the real-signal features come back as StackedFeatures."""
         n = y.shape[0]
         y_real, y_gen, fmap_real, fmap_gen = [], [], [], []
         both = torch.cat((y, y_hat), dim=0)
