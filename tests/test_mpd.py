@@ -225,3 +225,47 @@ def test_feature_loss_stacked_matches_per_map_loss():
     assert abs(vals[0] - vals[1]) <= 1e-5 * abs(vals[1])
     assert abs(vals[1] - float(z["f_loss"])) <= 1e-4 * abs(float(z["f_loss"]))          # and == the reference's value
     assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-6 * grads[1].abs().max().item() + 1e-9)
+
+
+def test_batched_linear_and_unstack_host_logic():
+    """Torch-level pieces of the batched discriminator pass, on CPU in fp64: the batched GEMM function (row-split
+    weight gradient included) == einsum; the slot-unstacking function routes gradients to the right rows."""
+    from vm_asr_amd.discriminator import _BatchedLinearFn, _UnstackRowsFn
+    torch.manual_seed(4)
+    n, M, K, N = 3, 4096, 6, 5                        # M = 16 * 256: the row split picks S > 1
+    cols = torch.randn(n, M, K, dtype=torch.double, requires_grad=True)
+    W = torch.randn(n, N, K, dtype=torch.double, requires_grad=True)
+    b = torch.randn(n, N, dtype=torch.double, requires_grad=True)
+    Ms = (4096, 3000, 17)
+    outs = _UnstackRowsFn.apply(_BatchedLinearFn.apply(cols, W, b, torch.double), *Ms)
+    ref = torch.einsum("nmk,nok->nmo", cols, W) + b.unsqueeze(1)
+    loss = sum((o ** 2).sum() * (i + 1) for i, o in enumerate(outs))
+    loss_ref = sum((ref[i, :m] ** 2).sum() * (i + 1) for i, m in enumerate(Ms))
+    assert all(torch.allclose(o, ref[i, :m]) for i, (o, m) in enumerate(zip(outs, Ms)))
+    got = torch.autograd.grad(loss, (cols, W, b))
+    want = torch.autograd.grad(loss_ref, (cols, W, b))
+    for g, w in zip(got, want):
+        assert torch.allclose(g, w, rtol=1e-9, atol=1e-9)
+
+
+def test_feature_loss_stacked_host_logic():
+    """feature_loss_stacked on synthetic stacks == the per-feature-map loss of model/loss.py:227-235 (CPU)."""
+    from vm_asr_amd.discriminator import StackedFeatures
+    from vm_asr_amd.loss import HiFiGANLoss
+    torch.manual_seed(5)
+    n, layers = 3, [(512, 4, (300, 256, 77)), (256, 2, (100, 90, 31))]
+    gen_stacks, real_stacks, gen_maps, real_maps = [], [], [[] for _ in range(n)], [[] for _ in range(n)]
+    for rows, N, valid in layers:
+        yg = torch.randn(n, rows, N, dtype=torch.double, requires_grad=True)
+        yr = torch.randn(n, 2 * rows, N, dtype=torch.double)       # the real stack of the D pass is longer (real + fake rows)
+        gen_stacks.append(yg); real_stacks.append(yr)
+        for i, m in enumerate(valid):
+            gen_maps[i].append(yg[i, :m]); real_maps[i].append(yr[i, :m])
+    valid = [v for _, _, v in layers]
+    fast = HiFiGANLoss("lsgan").feature_loss(StackedFeatures(real_maps, real_stacks, valid), StackedFeatures(gen_maps, gen_stacks, valid))
+    slow = HiFiGANLoss("lsgan").feature_loss([list(f) for f in real_maps], [list(f) for f in gen_maps])
+    assert torch.allclose(fast.double(), slow, rtol=1e-6)
+    g_fast = torch.autograd.grad(fast, gen_stacks)
+    g_slow = torch.autograd.grad(slow, gen_stacks)
+    for a, b in zip(g_fast, g_slow):
+        assert torch.allclose(a.double(), b, rtol=1e-5, atol=1e-9)
