@@ -447,12 +447,13 @@ class Trainer(BaseTrainer):
         return wave_out.detach(), logs
 
     def _mpd_weights_once(self):
-        """The reference evaluates every spectrally-normalised MPD weight three times per step (real
-        and fake in the D pass, fake in the G pass), one power iteration each, although the weights do
-        not change in between.  Here the three power iterations run back to back at the first use
-        (same u/v state after the step) and the normalised weight is computed once and reused
-        (torch.nn.utils.parametrize.cached): the three passes see the sigma of the third iteration
-        instead of the first / second / third — a difference that vanishes as u, v converge."""
+        """The reference evaluates every spectrally-normalised MPD weight four times per step (real and
+        fake in the D pass, real and fake again in the G pass: trainer/trainer.py:376-384, each
+        model/discriminator.py:129-147 call running every discriminator on both signals), one power
+        iteration each, although the weights do not change in between.  Here the four power iterations run
+        back to back at the first use (same u/v state after the step) and the normalised weight is computed
+        once and reused (torch.nn.utils.parametrize.cached): all passes see the sigma of the fourth
+        iteration instead of the first ... fourth — a difference that vanishes as u, v converge."""
         import contextlib
         from torch.nn.utils import parametrize
         mpd = unwrap(self.models.get("mpd")) if self.gan else None
@@ -463,10 +464,10 @@ class Trainer(BaseTrainer):
         @contextlib.contextmanager
         def ctx():
             saved = [m.n_power_iterations for m in sns]
-            n3 = 3 * saved[0] if saved else 3
-            batched = hasattr(mpd, "power_iterate_all") and mpd.power_iterate_all(n3, with_sigma=True)   # 14 launches for all 30 weights
+            n_it = 4 * saved[0] if saved else 4     # the reference's four D forwards per step
+            batched = hasattr(mpd, "power_iterate_all") and mpd.power_iterate_all(n_it, with_sigma=True)   # 18 launches for all 30 weights
             for m in sns:
-                m.n_power_iterations = 0 if batched else n3
+                m.n_power_iterations = 0 if batched else n_it
             try:
                 with parametrize.cached():
                     yield
