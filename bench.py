@@ -51,7 +51,7 @@ def make_config(workload, batch):
     return update_config(c)
 
 
-def build_trainer(config, device, amp=True, capturable=False):
+def build_trainer(config, device, amp=True, capturable=False, amp_scope="generator"):
     import vm_asr_amd
     from vm_asr_amd.trainer import Trainer, build_optimizer
     torch.manual_seed(config.SEED)
@@ -62,7 +62,8 @@ def build_trainer(config, device, amp=True, capturable=False):
     opts = {"generator": build_optimizer(config, models["generator"], capturable)}
     if gan:
         opts["discriminator"] = build_optimizer(config, [models["mpd"]], capturable)
-    return Trainer(models, [], opts, config, device, None, None, {}, amp=amp, gan=gan, len_epoch=0, dp_mode="flat")
+    return Trainer(models, [], opts, config, device, None, None, {}, amp=amp, gan=gan, len_epoch=0, dp_mode="flat",
+                   amp_scope=amp_scope)
 
 
 def synth_batch(config, device, rank):
@@ -106,6 +107,9 @@ def main():
     ap.add_argument("--workload", default="vm_asr_48k_MPD", choices=["vm_asr_48k_MPD", "vm_asr_48k"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the yaml's)")
     ap.add_argument("--no-amp", action="store_true")
+    ap.add_argument("--amp-scope", default="generator", choices=["generator", "step"],
+                    help="what bf16 autocast covers: 'generator' = the reference's scope (trainer/trainer.py:138-139: the "
+                         "generator forward; losses and discriminator in fp32), 'step' = losses and discriminator too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
@@ -123,7 +127,7 @@ def main():
     torch.cuda.set_device(device)
 
     config = make_config(args.workload, args.batch)
-    trainer = build_trainer(config, device, amp=not args.no_amp, capturable=not args.no_graphs)
+    trainer = build_trainer(config, device, amp=not args.no_amp, capturable=not args.no_graphs, amp_scope=args.amp_scope)
     for m in trainer.models.values():
         m.train()
     torch.manual_seed(config.SEED + 1 + rank)  # per-rank DropPath streams
@@ -168,7 +172,10 @@ def main():
         "metric": "audio clips/sec (train step) 48kHz n_fft=1024", "value": world * B * args.steps / dt,
         "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 autocast (selective scan / STFT fp32)" if not args.no_amp else "f32", "data": "synthetic",
+        "dtype": ("f32" if args.no_amp else
+                  "bf16 autocast over the generator forward as in the reference (selective scan / STFT fp32; losses and "
+                  "discriminator fp32)" if args.amp_scope == "generator" else
+                  "bf16 autocast over generator, losses and discriminator (selective scan / STFT fp32)"), "data": "synthetic",
         "config": {"workload": f"{args.workload}.yaml full train step (G fwd+bwd, "
                                f"{'MR-STFT+LSGAN+feature losses, MPD fwd+bwd, ' if config.TRAIN.ADVERSARIAL.ENABLE else 'MR-STFT loss, '}"
                                f"AdamW); DIMS 16, d_state 1, clip 122640 @48 kHz, n_fft 1024 hop 240",

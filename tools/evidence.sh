@@ -2,6 +2,7 @@ export VMASR_BENCH_WATCHDOG=500
 R=$PWD
 python -m pytest tests -m gpu -q 2>&1 | tail -2
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_v5.json 2> gpurun_out/bench_v5.err
+timeout 600 python bench.py --amp-scope step --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_v5_step.json 2>> gpurun_out/bench_v5.err
 cut -c1-300 gpurun_out/bench_v5.json
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o e -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/bench_v5_prof.json 2> /tmp/prof.err

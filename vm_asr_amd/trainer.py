@@ -256,12 +256,19 @@ class BaseTrainer:
 
 class Trainer(BaseTrainer):
     def __init__(self, models, metric_ftns, optimizers, config, device, data_loader_train, data_loader_val=None,
-                 lr_schedulers=None, amp=False, gan=False, logger=None, len_epoch=None, dp_mode="flat"):
+                 lr_schedulers=None, amp=False, gan=False, logger=None, len_epoch=None, dp_mode="flat",
+                 amp_scope="generator"):
         """dp_mode: "flat" = gradients live in one flat buffer per model and are all-reduced with ONE
         RCCL call per optimiser per step (also what makes the step HIP-graph capturable);
-        "ddp" = torch DistributedDataParallel buckets overlapped with backward."""
+        "ddp" = torch DistributedDataParallel buckets overlapped with backward.
+        amp_scope: what autocast covers when `amp` is on.  "generator" = the reference's scope
+        (trainer/trainer.py:138-139: only the generator forward; the losses and the discriminator run
+        outside autocast, i.e. in fp32); "step" = generator, losses and discriminator (bf16 MPD)."""
         super().__init__(models, metric_ftns, optimizers, config, logger)
         self.dp_mode = dp_mode
+        if amp_scope not in ("generator", "step"):
+            raise ValueError(f"amp_scope='{amp_scope}'")
+        self.amp_scope = amp_scope
         self._flat, self._flat_params, self._flat_views = {}, {}, {}
         self._gather = config.TRAIN.ACCUMULATION_STEPS == 1   # fresh grads are packed, not accumulated in place
         self._graphed = None
@@ -428,6 +435,7 @@ class Trainer(BaseTrainer):
         acc = self.config.TRAIN.ACCUMULATION_STEPS
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
             wave_out = self.models["generator"](wave_input, highcut)
+        with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp and self.amp_scope == "step"):
             # D loss first, with the same D weights the G pass sees (reference order, trainer/trainer.py:369-399)
             with self._mpd_weights_once():
                 d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
