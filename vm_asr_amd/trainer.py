@@ -18,8 +18,10 @@ not have (README.md:31):
   * the generator's adversarial/feature losses run through the discriminator with its
     parameters frozen, so the 164 MB MPD gradient is produced and all-reduced once per step
     (the reference fills and discards it during the G update, trainer/trainer.py:428-438);
-  * bf16 autocast without GradScaler (the reference: fp16 + GradScaler, :106-107); the scan
-    still runs fp32 (forward type v5, model/vmamba.py:842-848);
+  * bf16 autocast without GradScaler (the reference: fp16 + GradScaler, :106-107) over the SAME
+    scope as the reference by default — the generator forward only (:138-139); losses and the
+    discriminator run in fp32 (`amp_scope="step"` widens it); the scan still runs fp32 (forward
+    type v5, model/vmamba.py:842-848);
   * no anomaly mode (:320) and no per-loss `.item()` syncs (:158-176): scalars are read every
     PRINT_FREQ steps.
 """
