@@ -197,3 +197,30 @@ def test_train_step_gpu_graph_matches_eager():
         for k, v in a.items():
             assert abs(v - b[k]) <= 0.02 * abs(v) + 1e-4, (k, v, b[k])
     assert hist[0][-1]["total_loss"] < hist[0][0]["total_loss"]     # and it is learning
+
+
+@pytest.mark.gpu
+def test_shared_fake_pass_gives_the_same_gradients(monkeypatch):
+    """One discriminator pass over the generated signal serving both losses (phase-restricted backwards) ==
+    the reference's two passes (detached for the D loss, attached for the G loss): same losses, same gradients
+    of every generator and discriminator parameter."""
+    cfg = _tiny_config()
+    batch = [t.cuda() for t in _batch(cfg, 2)]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VMASR_SHARE_FAKE_PASS", flag)
+        tr = _gpu_trainer(cfg, amp=False)
+        for m in tr.models.values():
+            m.train()
+        assert tr._share_fake_pass() == (flag == "1")
+        _, logs = tr._forward_backward(*batch)
+        grads = {f"{k}.{n}": p.grad.detach().clone() for k in ("generator", "mpd")
+                 for n, p in tr.models[k].named_parameters() if p.grad is not None}
+        out[flag] = ({k: float(v) for k, v in logs.items()}, grads)
+    (la, ga), (lb, gb) = out["1"], out["0"]
+    for k in lb:
+        assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-7, (k, la[k], lb[k])
+    assert ga.keys() == gb.keys()
+    for k in gb:
+        scale = max(gb[k].abs().max().item(), 1e-8)
+        assert (ga[k] - gb[k]).abs().max().item() <= 2e-3 * scale + 1e-7, (k, (ga[k] - gb[k]).abs().max().item(), scale)

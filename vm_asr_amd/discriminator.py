@@ -354,6 +354,20 @@ class _StackedIm2ColFn(torch.autograd.Function):
         return (None, None, None, None, *dxs)
 
 
+# Backward-phase switch of the trainer's shared fake pass: while the GENERATOR loss is back-propagated through
+# the discriminator's graph only the column / input gradients are wanted; the weight gradients belong to the
+# discriminator loss' own backward through the same graph.
+_PHASE = {"skip_weight_grads": False}
+
+
+class skip_weight_grads:
+    def __enter__(self):
+        _PHASE["skip_weight_grads"] = True
+
+    def __exit__(self, *exc):
+        _PHASE["skip_weight_grads"] = False
+
+
 class _BatchedLinearFn(torch.autograd.Function):
     """y[i] = cols[i] @ W[i]^T + b[i] for the n stacked discriminators (one batched GEMM); backward: one batched
     GEMM for the column gradient, the weight gradient split over the rows into a larger batch (fp32 sum)."""
@@ -378,6 +392,8 @@ class _BatchedLinearFn(torch.autograd.Function):
         K = cols.shape[2]
         dcols = torch.bmm(gy, wc) if ctx.needs_input_grad[0] else None
         dw = db = None
+        if _PHASE["skip_weight_grads"]:
+            return dcols, None, None, None
         if ctx.needs_input_grad[1]:
             acc = torch.float32 if gy.dtype in (torch.float16, torch.bfloat16) else gy.dtype
             tiles = n * -(-N // 64) * -(-K // 64)

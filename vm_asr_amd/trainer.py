@@ -329,7 +329,7 @@ class Trainer(BaseTrainer):
         sc, mag = self.multi_resolution_stft(wave_out.squeeze(1), wave_target.squeeze(1))
         return sc + mag
 
-    def _generator_losses(self, wave_out, wave_target, fmap_real=None):
+    def _generator_losses(self, wave_out, wave_target, fmap_real=None, fake_pass=None):
         cfg, out = self.config.TRAIN, {}
         wave_out = wave_out.float()
         if "l1" in cfg.LOSSES.GEN:
@@ -340,10 +340,13 @@ class Trainer(BaseTrainer):
             out["multi_resolution_stft"] = self._get_stft_loss(wave_out, wave_target)
         if self.gan and "mpd" in cfg.ADVERSARIAL.DISCRIMINATORS:
             mpd = unwrap(self.models["mpd"])  # weights used as constants: no MPD gradients, no DDP hooks
-            if fmap_real is None:  # the reference recomputes the real-signal features here
-                with torch.no_grad():
-                    _, fmap_real = mpd.forward_single(wave_target, detach_weights=True)
-            y_gen, fmap_gen = mpd.forward_single(wave_out, detach_weights=True)
+            if fake_pass is not None:      # shared fake pass (see _forward_backward): scores / features already there
+                y_gen, fmap_gen = fake_pass
+            else:
+                if fmap_real is None:  # the reference recomputes the real-signal features here
+                    with torch.no_grad():
+                        _, fmap_real = mpd.forward_single(wave_target, detach_weights=True)
+                y_gen, fmap_gen = mpd.forward_single(wave_out, detach_weights=True)
             if not cfg.ADVERSARIAL.ONLY_FEATURE_LOSS:
                 out["adversarial_mpd"] = self.higi_gan_loss.generator_loss(y_gen)
             if not cfg.ADVERSARIAL.ONLY_ADVERSARIAL_LOSS:
@@ -437,24 +440,59 @@ class Trainer(BaseTrainer):
         acc = self.config.TRAIN.ACCUMULATION_STEPS
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
             wave_out = self.models["generator"](wave_input, highcut)
+        shared = self._share_fake_pass()
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp and self.amp_scope == "step"):
             # D loss first, with the same D weights the G pass sees (reference order, trainer/trainer.py:369-399)
             with self._mpd_weights_once():
-                d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
-                g_losses = self._generator_losses(wave_out, wave_target, fmap_real)
+                if shared:
+                    # The reference runs D(fake) twice per step on identical values (detached for the D loss, attached
+                    # for the G loss: trainer/trainer.py:376-384).  Here ONE pass over the fake signal carries both:
+                    # the G loss is back-propagated through it for input gradients only, the D loss for weight
+                    # gradients only (`backward(inputs=...)` + skip_weight_grads) — 1/8 fewer discriminator FLOPs.
+                    mpd = unwrap(self.models["mpd"])
+                    y_real, f_real = mpd.forward_single(wave_target)
+                    y_fake, f_fake = mpd.forward_single(wave_out.float())
+                    d_losses = {"mpd": self.higi_gan_loss.discriminator_loss(y_real, y_fake)}
+                    f_real = f_real.detach() if hasattr(f_real, "stacks") else [[f.detach() for f in fs] for fs in f_real]
+                    g_losses = self._generator_losses(wave_out, wave_target, f_real, fake_pass=(y_fake, f_fake))
+                else:
+                    d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
+                    g_losses = self._generator_losses(wave_out, wave_target, fmap_real)
         total_g = sum(g_losses.values()) / acc
         self._zero_grads("generator", self.optimizer_G)
-        total_g.backward()
+        if shared:
+            from .discriminator import skip_weight_grads
+            with skip_weight_grads():
+                total_g.backward(inputs=self._grad_targets("generator"), retain_graph=True)
+        else:
+            total_g.backward()
         self._gather_grads("generator")
         logs = {"total_loss": total_g.detach()}
         logs.update({f"generator/{k}": v.detach() for k, v in g_losses.items()})
         if self.gan:
             total_d = sum(d_losses.values()) / acc
             self._zero_grads("mpd", self.optimizer_D)
-            total_d.backward()
+            if shared:
+                total_d.backward(inputs=self._grad_targets("mpd"))
+            else:
+                total_d.backward()
             self._gather_grads("mpd")
             logs["total_disc_loss"] = total_d.detach()
         return wave_out.detach(), logs
+
+    def _share_fake_pass(self):
+        """One discriminator pass over the generated signal for both losses: GPU, flat gradient buffers (no DDP
+        hooks), LSGAN / WGAN without gradient penalty, and the layer-synchronous discriminator path."""
+        if not (self.gan and self.device.type == "cuda" and self.dp_mode == "flat"):
+            return False
+        if self.config.TRAIN.ADVERSARIAL.GAN_LOSS_TYPE == "wgan-gp" or "mpd" not in self.config.TRAIN.ADVERSARIAL.DISCRIMINATORS:
+            return False
+        return os.environ.get("VMASR_SHARE_FAKE_PASS", "1") == "1" and hasattr(unwrap(self.models["mpd"]), "_forward_batched")
+
+    def _grad_targets(self, key):
+        if key in self._flat_params:
+            return self._flat_params[key]
+        return [p for p in unwrap(self.models[key]).parameters() if p.requires_grad]
 
     def _mpd_weights_once(self):
         """The reference evaluates every spectrally-normalised MPD weight four times per step (real and
