@@ -132,12 +132,16 @@ class oracle_stft_patch:
     """Context manager: route vm_asr_amd.model's STFT front-end to the oracle."""
 
     def __enter__(self):
+        import vm_asr_amd.metric as Q
         import vm_asr_amd.model as M
         import vm_asr_amd.stft as S
-        self._M, self._S, self._saved = M, S, (M.wav2spectro, M.spectro2wav, S.stft_reim)
+        self._M, self._S, self._Q = M, S, Q
+        self._saved = (M.wav2spectro, M.spectro2wav, S.stft_reim, Q.stft_complex)
         M.wav2spectro, M.spectro2wav, S.stft_reim = oracle_wav2spectro, oracle_spectro2wav, oracle_stft_reim
+        Q.stft_complex = lambda w, n_fft, hop, win, normalized=False: tuple(
+            torch.from_numpy(t) for t in oracle.stft(_n(w), n_fft, hop, win, normalized=normalized, logmag=False))
         return self
 
     def __exit__(self, *exc):
-        self._M.wav2spectro, self._M.spectro2wav, self._S.stft_reim = self._saved
+        self._M.wav2spectro, self._M.spectro2wav, self._S.stft_reim, self._Q.stft_complex = self._saved
         return False

@@ -118,13 +118,26 @@ def load_reference():
     g = dict(torch=torch, F=F, rearrange=rearrange, repeat=repeat)
     exec(code, g)
 
+    # float64 evaluation of the SAME function: every `.float()` in its body becomes `.double()` (AST
+    # rewrite, nothing else touched) -> the adjudicator for "which fp32 result is closer to exact"
+    class _ToDouble(ast.NodeTransformer):
+        def visit_Attribute(self, node):
+            self.generic_visit(node)
+            if node.attr == "float":
+                node.attr = "double"
+            return node
+    tree64 = ast.fix_missing_locations(_ToDouble().visit(ast.Module(body=fn_nodes, type_ignores=[])))
+    g64 = dict(torch=torch, F=F, rearrange=rearrange, repeat=repeat)
+    exec(compile(tree64, "selective_scan_ref64", "exec"), g64)
+
     try:
         disc = _load("refdisc", os.path.join(REF, "model/discriminator.py"))
     except Exception as e:  # pragma: no cover
         disc = None
         print("WARNING: reference discriminator not importable:", e)
     ns = types.SimpleNamespace(vmamba=vmamba, model=model, stft=stft, metric=metric, discriminator=disc,
-                               loss=loss, selective_scan_ref=g["selective_scan_ref"])
+                               loss=loss, selective_scan_ref=g["selective_scan_ref"],
+                               selective_scan_ref64=g64["selective_scan_ref"])
     _CACHE["ns"] = ns
     return ns
 
@@ -153,6 +166,46 @@ def patch_ss2d_to_cpu(ns, module):
                                      CrossScan=ns.vmamba.CrossScan,
                                      CrossMerge=ns.vmamba.CrossMerge)
     return module
+
+
+class _RefScan64:
+    """`.apply` adapter for one SS2D evaluated in float64: forward_corev2 hands over As / Ds / delta_bias
+    after a `.to(torch.float)` (model/vmamba.py:1481-1485); the adapter rebuilds them in double from the
+    module's own parameters so that no fp32 arithmetic is left on the path."""
+
+    def __init__(self, ref64, module):
+        self.ref64, self.m = ref64, module
+
+    def apply(self, u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1, backnrows=1,
+              oflex=True):
+        m = self.m
+        return self.ref64(u.double(), delta.double(), -torch.exp(m.A_logs.double()), B.double(), C.double(),
+                          m.Ds.double(), None, m.dt_projs_bias.view(-1).double(), delta_softplus)
+
+
+def patch_ss2d_to_cpu64(ns, module):
+    """float64 evaluation: module.double() + every SS2D on selective_scan_ref64 with force_fp32 off."""
+    from functools import partial
+    module.double()
+    for m in module.modules():
+        if isinstance(m, ns.vmamba.SS2D):
+            m.forward_core = partial(m.forward_corev2, force_fp32=False, SelectiveScan=_RefScan64(ns.selective_scan_ref64, m),
+                                     CrossScan=ns.vmamba.CrossScan, CrossMerge=ns.vmamba.CrossMerge)
+    return module
+
+
+class hann_in_double:
+    """utils/stft.py builds `torch.hann_window(win_length)` in fp32 (:36,:83); inside this context the window
+    is float64 so the float64 evaluation carries no fp32-rounded constant."""
+
+    def __enter__(self):
+        self._orig = torch.hann_window
+        torch.hann_window = lambda n, *a, **k: self._orig(n, *a, **{**k, "dtype": torch.float64})
+        return self
+
+    def __exit__(self, *exc):
+        torch.hann_window = self._orig
+        return False
 
 
 if __name__ == "__main__":

@@ -16,6 +16,9 @@ Fixture families:
   loss.npz        MultiResolutionSTFTLoss values + d/dx (model/loss.py:137-184)
   model_variants.npz  the m2p / p2m / single ablation forwards on model_tiny's weights: output, LSD, grad norms
   fullsize.npz    full-size generator forward (dims 16, n_fft 1024) at 16 kHz and 48 kHz: clip, output, LSD
+  fullsize2.npz   float64 evaluation of the full-size forwards (the adjudicator for fp32 differences) and the
+                  dims-32 / n_fft-2048 full-size forwards (configs/vm_asr_48k_16k_MPD_VSSM32.yaml, ..._nfft2048.yaml)
+  trainstep.npz   one reference `_get_losses` evaluation (trainer/trainer.py:318-399) with the MPD in train mode
   mpd.npz         MultiPeriodDiscriminator hidden=2 scores / feature maps / LSGAN losses / grads
                   (model/discriminator.py:21-147, model/loss.py:188-235)
 """
@@ -28,7 +31,7 @@ import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from _refload import load_reference, patch_ss2d_to_cpu  # noqa: E402
+from _refload import hann_in_double, load_reference, patch_ss2d_to_cpu, patch_ss2d_to_cpu64  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -361,6 +364,72 @@ def gen_fullsize(ns):
     save("fullsize.npz", **out)
 
 
+FULLSIZE_CASES = {
+    # tag: (dims, n_fft, win, hop, T, input seed)   — 16k / 48k reuse the inputs of fullsize.npz (seed 31)
+    "16k": (16, 1024, 1024, 80, 40880, 31),
+    "48k": (16, 1024, 1024, 240, 122640, 31),
+    "d32": (32, 1024, 1024, 240, 122640, 32),      # configs/vm_asr_48k_16k_MPD_VSSM32.yaml:4-5
+    "n2048": (16, 2048, 1024, 240, 122640, 33),    # configs/vm_asr_48k_16k_nfft2048.yaml:17-19 (WIN_LENGTH stays 1024)
+}
+
+
+def _fullsize_model(ns, dims, n_fft, win, hop):
+    torch.manual_seed(123)
+    return ns.model.DualStreamInteractiveMambaUNet(
+        in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=dims, ssm_d_state=1, ssm_ratio=2.0,
+        ssm_dt_rank="auto", ssm_act_layer="silu", ssm_conv=3, ssm_conv_bias=True, ssm_drop_rate=0.0,
+        ssm_init="v0", forward_type="v5", mlp_ratio=4.0, mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False,
+        drop_path_rate=0.1, patch_norm=True, norm_layer="LN", patchembed_version="v2", downsample_version="v1",
+        upsample_version="v1", output_version="v3", concat_skip=True, interact="dual",
+        n_fft=n_fft, hop_length=hop, win_length=win, spectro_scale="log2", low_freq_replacement=True)
+
+
+def gen_fullsize2(ns):
+    """(1) float64 evaluation of the reference's full-size forward for every case (module.double(),
+    selective_scan_ref with its `.float()` casts turned into `.double()`, float64 hann window): stored as
+    d64 = y64 - y32 in fp32, so tests can ask "is the HIP result as close to the exact answer as the reference's
+    own fp32 run".  (2) the dims-32 and n_fft-2048 full-size fp32 forwards + LSD (BASELINE configs[4]).
+    Inputs are regenerated from their seed in the tests; a checksum of the clip is stored."""
+    from synth import canonical_phase, synth_state
+    import time
+    old = np.load(os.path.join(HERE, "fullsize.npz"))
+    out = {}
+    for tag, (dims, n_fft, win, hop, T, seed) in FULLSIZE_CASES.items():
+        g = torch.Generator().manual_seed(seed)
+        wave = 0.1 * torch.randn(1, 1, T, generator=g)
+        target = 0.1 * torch.randn(1, 1, T, generator=g)
+        hf = torch.full((1,), int((n_fft // 2 + 1) * 16000 / 48000), dtype=torch.int64)
+        if f"{tag}_y" in old.files:
+            assert np.array_equal(old[f"{tag}_wave"], wave.numpy())
+            y32 = torch.from_numpy(old[f"{tag}_y"])
+        else:
+            m = synth_state(patch_ss2d_to_cpu(ns, _fullsize_model(ns, dims, n_fft, win, hop))).eval()
+            f32 = m._mag_phase
+            m._mag_phase = lambda x, _f=f32: (lambda mp: (mp[0], canonical_phase(mp[1])))(_f(x))
+            t0 = time.time()
+            with torch.no_grad():
+                y32 = m(wave, hf)
+            print(f"  {tag}: reference fp32 forward {time.time() - t0:.1f} s, |y|max {y32.abs().max().item():.4f}")
+            out[f"{tag}_y"] = _np(y32)
+            out[f"{tag}_lsd"] = np.array(ns.metric.lsd(y32.squeeze(1), target.squeeze(1)))
+        # float64: weights are the SAME fp32 values (synth_state before .double())
+        m = synth_state(_fullsize_model(ns, dims, n_fft, win, hop))
+        patch_ss2d_to_cpu64(ns, m).eval()
+        f64 = m._mag_phase
+        m._mag_phase = lambda x, _f=f64: (lambda mp: (mp[0], canonical_phase(mp[1])))(_f(x))
+        t0 = time.time()
+        with torch.no_grad(), hann_in_double():
+            y64 = m(wave.double(), hf)
+        assert y64.dtype == torch.float64
+        d = y64 - y32.double()
+        print(f"  {tag}: reference fp64 forward {time.time() - t0:.1f} s; |y32 - y64| max {d.abs().max().item():.3e} "
+              f"rms {d.pow(2).mean().sqrt().item():.3e} (peak {y64.abs().max().item():.4f})")
+        out[f"{tag}_d64"] = d.float().numpy()
+        out[f"{tag}_wave_sum"] = np.array(wave.double().sum().item())
+        out[f"{tag}_cfg"] = np.array([dims, n_fft, win, hop, T, seed])
+    save("fullsize2.npz", **out)
+
+
 def gen_loss(ns):
     """MultiResolutionSTFTLoss (model/loss.py:137-184) values and d/dx on a fixed pair."""
     g = torch.Generator().manual_seed(6)
@@ -419,6 +488,83 @@ def gen_mpd(ns):
     save("mpd.npz", **out)
 
 
+def _reference_get_losses():
+    """`Trainer._get_losses`, `_get_mpd_loss`, `_get_stft_loss` taken from trainer/trainer.py by AST (the module
+    itself imports tensorboard / tqdm / the data pipeline) and bound to a bare object."""
+    import ast
+    import types
+    from _refload import REF
+    src = open(os.path.join(REF, "trainer/trainer.py")).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "Trainer"][0]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("_get_losses", "_get_mpd_loss", "_get_stft_loss")]
+    assert len(fns) == 3
+    return fns
+
+
+def gen_trainstep(ns):
+    """One evaluation of the reference's loss function for a train step, trainer/trainer.py:318-399
+    (`_get_losses` -> `_get_stft_loss`, `_get_mpd_loss`), MPD (hidden 2) in TRAIN mode: two discriminator
+    calls = four spectral-norm power iterations per weight (real, fake, real, fake).  `wave_out` is a leaf
+    that requires grad, so d(total generator loss)/d(wave_out) is exactly what flows back into the generator.
+    Two states: "cold" (freshly initialised u, v — the sigma of each of the four passes differs) and "warm"
+    (the same weights after 2000 train-mode power iterations: u, v converged, the four sigmas agree to rounding).
+    Stored per state: MPD state_dict before, the five losses, d total_g / d wave_out, the gradient of the
+    discriminator loss wrt three weights, and u/v after the step."""
+    import ast
+    import types
+    fns = _reference_get_losses()
+    g = dict(torch=torch, mae_loss=ns.loss.mae_loss, mse_loss=ns.loss.mse_loss)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "reference_trainer_losses", "exec"), g)
+    NS = types.SimpleNamespace
+    cfg = NS(TRAIN=NS(LOSSES=NS(GEN=["multi_resolution_stft"]),
+                      ADVERSARIAL=NS(DISCRIMINATORS=["mpd"], ONLY_FEATURE_LOSS=False, ONLY_ADVERSARIAL_LOSS=False,
+                                     FEATURE_LOSS_LAMBDA=100, GAN_LOSS_TYPE="lsgan")))
+    gen = torch.Generator().manual_seed(21)
+    T = 6000
+    wave_target = 0.1 * torch.randn(2, 1, T, generator=gen)
+    wave_out0 = wave_target + 0.03 * torch.randn(2, 1, T, generator=gen)
+    out = dict(wave_target=_np(wave_target), wave_out=_np(wave_out0))
+    names = ["discriminators.0.layers.0.parametrizations.weight.original",
+             "discriminators.4.layers.3.parametrizations.weight.original", "discriminators.2.conv_post.bias"]
+    for state in ("cold", "warm"):
+        torch.manual_seed(11)
+        D = ns.discriminator.MultiPeriodDiscriminator(hidden=2)
+        D.train()
+        if state == "warm":
+            with torch.no_grad():
+                for _ in range(1000):   # 1000 calls x (real, fake) = 2000 power iterations per weight
+                    D(wave_target, wave_out0)
+        for k, v in D.state_dict().items():
+            out[f"{state}_sd::{k}"] = _np(v)
+        me = NS(config=cfg, gan=True, models={"mpd": D},
+                multi_resolution_stft=ns.loss.MultiResolutionSTFTLoss(factor_sc=0.5, factor_mag=0.5, emphasize_high_freq=False),
+                higi_gan_loss=ns.loss.HiFiGANLoss("lsgan"))
+        for f in ("_get_losses", "_get_mpd_loss", "_get_stft_loss"):
+            setattr(me, f, types.MethodType(g[f], me))
+        wave_out = wave_out0.clone().requires_grad_()
+        losses = me._get_losses(wave_out, wave_target)
+        for k, v in losses["generator"].items():
+            out[f"{state}_g::{k}"] = np.array(v.item())
+        for k, v in losses["discriminator"].items():
+            out[f"{state}_d::{k}"] = np.array(v.item())
+        total_g = sum(losses["generator"].values())
+        total_d = sum(losses["discriminator"].values())
+        params = dict(D.named_parameters())
+        total_g.backward(retain_graph=True)          # reference order: _optimize(G) then _optimize_adversarial(D)
+        out[f"{state}_dwave"] = _np(wave_out.grad)
+        for p in params.values():
+            p.grad = None                            # optimizer_D.zero_grad() (trainer/trainer.py:435)
+        total_d.backward()
+        for n in names:
+            out[f"{state}_dD::{n}"] = _np(params[n].grad)
+        out[f"{state}_gradnorm_D"] = np.array(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None)).item())
+        for k, v in D.state_dict().items():
+            if k.endswith("._u") or k.endswith("._v"):
+                out[f"{state}_after::{k}"] = _np(v)
+        print(f"  {state}: " + " ".join(f"{k}={v.item():.5f}" for k, v in {**losses['generator'], **losses['discriminator']}.items()))
+    save("trainstep.npz", **out)
+
+
 def gen_metric(ns):
     out = {}
     g = torch.Generator().manual_seed(5)
@@ -433,7 +579,7 @@ def gen_metric(ns):
 
 if __name__ == "__main__":
     ns = load_reference()
-    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss", "mpd", "variants", "fullsize"]
+    which = sys.argv[1:] or ["scan", "csm", "dwconv", "ss2d", "stft", "model", "metric", "loss", "mpd", "variants", "fullsize", "fullsize2", "trainstep"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"](ns)

@@ -15,16 +15,16 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 sys.path.insert(0, GOLDEN)
 
 
-def _model(hop):
+def _model(hop, dims=16, n_fft=1024, win=1024):
     from synth import synth_state
     from vm_asr_amd.model import DualStreamInteractiveMambaUNet
     torch.manual_seed(123)
     m = DualStreamInteractiveMambaUNet(
-        in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=16, ssm_d_state=1, ssm_ratio=2.0, ssm_dt_rank="auto",
+        in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=dims, ssm_d_state=1, ssm_ratio=2.0, ssm_dt_rank="auto",
         ssm_act_layer="silu", ssm_conv=3, ssm_conv_bias=True, ssm_drop_rate=0.0, ssm_init="v0", forward_type="v5",
         mlp_ratio=4.0, mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False, drop_path_rate=0.1, patch_norm=True,
         norm_layer="LN", patchembed_version="v2", downsample_version="v1", upsample_version="v1",
-        output_version="v3", concat_skip=True, interact="dual", n_fft=1024, hop_length=hop, win_length=1024,
+        output_version="v3", concat_skip=True, interact="dual", n_fft=n_fft, hop_length=hop, win_length=win,
         spectro_scale="log2", low_freq_replacement=True)
     return synth_state(m).eval()
 
@@ -108,3 +108,118 @@ def test_fullsize_forward_hip(tag, hop):
         assert np.sqrt((d.astype(np.float64) ** 2).mean()) <= 5e-4 * scale, (tag, what)
     lsd = oracle.lsd(y_gpu.numpy()[:, 0], z[f"{tag}_target"][:, 0])
     assert abs(lsd - float(z[f"{tag}_lsd"])) < 2e-3, (lsd, float(z[f"{tag}_lsd"]))
+
+
+# ---- float64-adjudicated accuracy, dims-32 and n_fft-2048 configurations ---------------------------------------
+def _case(tag):
+    """Inputs of tests/golden/fullsize2.npz regenerated from their seed (make_golden.py::gen_fullsize2)."""
+    z = np.load(os.path.join(GOLDEN, "fullsize2.npz"))
+    dims, n_fft, win, hop, T, seed = (int(v) for v in z[f"{tag}_cfg"])
+    g = torch.Generator().manual_seed(seed)
+    wave = 0.1 * torch.randn(1, 1, T, generator=g)
+    target = 0.1 * torch.randn(1, 1, T, generator=g)
+    assert abs(wave.double().sum().item() - float(z[f"{tag}_wave_sum"])) < 1e-9, "RNG stream differs from the golden's"
+    hf = torch.full((1,), int((n_fft // 2 + 1) * 16000 / 48000), dtype=torch.int64)
+    old = np.load(os.path.join(GOLDEN, "fullsize.npz"))
+    y32 = z[f"{tag}_y"] if f"{tag}_y" in z.files else old[f"{tag}_y"]
+    lsd = float(z[f"{tag}_lsd"]) if f"{tag}_lsd" in z.files else float(old[f"{tag}_lsd"])
+    return (dims, n_fft, win, hop), wave, target, hf, y32, y32.astype(np.float64) + z[f"{tag}_d64"].astype(np.float64), lsd
+
+
+def _rms(a):
+    return float(np.sqrt((np.asarray(a, np.float64) ** 2).mean()))
+
+
+@pytest.mark.parametrize("tag", ["16k", "48k", "d32", "n2048"])
+def test_fullsize_forward_cpu_oracle_fp64_adjudicated(tag):
+    """CPU plumbing leg of the test below (oracle kernels): same bounds."""
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
+    (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case(tag)
+    m = use_oracle(_model(hop, dims, n_fft, win))
+    with oracle_stft_patch(), torch.no_grad():
+        y = m(wave, hf).float().numpy()
+    _adjudicate(tag, "cpu-oracle", y, y32, y64, target, lsd_ref)
+
+
+K_MAX, K_RMS = 8.0, 4.0
+
+
+def _adjudicate(tag, who, y, y32, y64, target, lsd_ref):
+    """The exact output is y64 (the reference evaluated in float64, make_golden.py::gen_fullsize2).  The reference's
+    own fp32 run sits e_ref = |y32 - y64| from it; ours must sit within a constant factor of that — the factor,
+    not a prose tolerance, is the claim: K_MAX on the worst sample, K_RMS in RMS.  (A different fp32 evaluation
+    order of the same 34-block network cannot be expected to have the SAME error as the reference's, only the same
+    order of magnitude; both are dominated by the final LayerNorm over two channels, see test_fullsize_forward_hip.)"""
+    import oracle
+    e_ref, e = np.abs(y32.astype(np.float64) - y64), np.abs(y.astype(np.float64) - y64)
+    peak = np.abs(y64).max()
+    print(f"[{tag}] {who}: max |y-y64| {e.max() / peak:.2e} of peak (reference fp32: {e_ref.max() / peak:.2e}), "
+          f"rms {_rms(e) / peak:.2e} (reference fp32: {_rms(e_ref) / peak:.2e})")
+    assert e.max() <= K_MAX * e_ref.max(), (tag, who, e.max(), e_ref.max())
+    assert _rms(e) <= K_RMS * _rms(e_ref), (tag, who, _rms(e), _rms(e_ref))
+    lsd = oracle.lsd(y[:, 0], target.numpy()[:, 0])
+    assert abs(lsd - lsd_ref) < 1e-3, (tag, who, lsd, lsd_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["16k", "48k", "d32", "n2048"])
+def test_fullsize_forward_hip_fp64_adjudicated(tag):
+    """BASELINE configs[0], [1], [4] (dims 32; n_fft 2048) at full size through the HIP path in fp32, adjudicated by
+    the float64 evaluation of the reference."""
+    (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case(tag)
+    m = _model(hop, dims, n_fft, win).to("cuda:0")
+    with torch.no_grad():
+        y = m(wave.cuda(), hf.cuda()).float().cpu().numpy()
+    _adjudicate(tag, "hip fp32", y, y32, y64, target, lsd_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["48k", "d32"])
+def test_fullsize_forward_hip_bf16_autocast(tag):
+    """north_star: 1e-2 for bf16.  The generator under bf16 autocast exactly as the trainer runs it (scan, LayerNorm,
+    STFT in fp32; Linear / conv GEMMs in bf16) against the float64 output: RMS error <= 1e-2 of the peak and LSD
+    within 1e-2 of the reference's.  (The worst single sample is reported, not bounded at 1e-2: the final
+    two-channel LayerNorm turns a bf16-level input difference into an O(1) change of its +-1 output at isolated
+    time-frequency bins, see test_fullsize_forward_hip.)"""
+    import oracle
+    (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case(tag)
+    m = _model(hop, dims, n_fft, win).to("cuda:0")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(wave.cuda(), hf.cuda()).float().cpu().numpy()
+    e, peak = np.abs(y.astype(np.float64) - y64), np.abs(y64).max()
+    lsd = oracle.lsd(y[:, 0], target.numpy()[:, 0])
+    print(f"[{tag}] hip bf16 autocast: rms {_rms(e) / peak:.2e}, max {e.max() / peak:.2e} of peak; LSD {lsd:.4f} vs {lsd_ref:.4f}")
+    assert _rms(e) <= 1e-2 * peak, (tag, _rms(e), peak)
+    assert abs(lsd - lsd_ref) <= 1e-2, (tag, lsd, lsd_ref)
+
+
+@pytest.mark.gpu
+def test_fullsize_backward_hip_vs_cpu_oracle():
+    """Full-size GRADIENTS (BASELINE configs[1]/[2] shape: dims 16, 513x512 spectrogram, one 48 kHz clip): every
+    parameter gradient of the HIP fp32 forward+backward against the same module on the CPU oracle kernels
+    (`SelectiveScanCore.backward` at L = 262 144 inside the real graph, model/vmamba.py:347-356).
+    Bounds: relative L2 error per tensor <= 2e-3 against max(|g_ref|, 1e-4 of the largest tensor norm), and the
+    whole gradient vector within 5e-4; the 129 `layers_decoder_phase` tensors have no gradient on either side."""
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
+    (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case("48k")
+    gy = torch.randn(1, 1, wave.shape[-1], generator=torch.Generator().manual_seed(77))
+    m_cpu = use_oracle(_model(hop, dims, n_fft, win))
+    with oracle_stft_patch():
+        (m_cpu(wave, hf) * gy).sum().backward()
+    m_gpu = _model(hop, dims, n_fft, win).to("cuda:0")
+    (m_gpu(wave.cuda(), hf.cuda()).float() * gy.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    ref = {n: p.grad for n, p in m_cpu.named_parameters()}
+    got = {n: p.grad for n, p in m_gpu.named_parameters()}
+    assert sum(g is None for g in ref.values()) == 129 and all((got[n] is None) == (ref[n] is None) for n in ref)
+    names = [n for n in ref if ref[n] is not None]
+    norms = {n: ref[n].double().norm().item() for n in names}
+    floor = 1e-4 * max(norms.values())
+    rel = {n: (got[n].cpu().double() - ref[n].double()).norm().item() / max(norms[n], floor) for n in names}
+    worst = sorted(rel, key=rel.get)[-5:]
+    tot = (sum((got[n].cpu().double() - ref[n].double()).pow(2).sum() for n in names).sqrt()
+           / sum(ref[n].double().pow(2).sum() for n in names).sqrt()).item()
+    print(f"full-size backward: whole-vector rel L2 {tot:.2e}; worst tensors " + ", ".join(f"{n} {rel[n]:.2e}" for n in worst))
+    assert all(torch.isfinite(got[n]).all() for n in names)
+    assert tot <= 5e-4, tot
+    assert rel[worst[-1]] <= 2e-3, (worst[-1], rel[worst[-1]])

@@ -12,7 +12,7 @@ import os
 
 import yaml
 
-__all__ = ["CfgNode", "get_default_config", "get_config", "update_config"]
+__all__ = ["CfgNode", "get_default_config", "get_config", "update_config", "to_yacs", "from_yacs", "yacs_pickle_compat"]
 
 
 class CfgNode(dict):
@@ -97,6 +97,92 @@ class CfgNode(dict):
             return {k: plain(v) if isinstance(v, CfgNode) else (list(v) if isinstance(v, tuple) else v)
                     for k, v in n.items()}
         return yaml.safe_dump(plain(self))
+
+
+# ---- checkpoint interchange with the reference (base/base_trainer.py:146-153, utils/utils.py:141-145) ------------
+# The reference stores its yacs CfgNode OBJECT under checkpoint["config"] and calls `.defrost()` on what it loads.
+# yacs is not a dependency here, so checkpoints are written with a stand-in that pickles BY REFERENCE as
+# `yacs.config.CfgNode` with yacs's own instance state (a dict subclass whose __dict__ holds __immutable__,
+# __deprecated_keys__, __renamed_keys__, __new_allowed__): the reference unpickles it into a real yacs node, and
+# reference checkpoints unpickle here into the stand-in, which `from_yacs` turns into this module's CfgNode.
+class _YacsNode(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def is_frozen(self):
+        return self.__dict__.get("__immutable__", False)
+
+    def _imm(self, flag):
+        self.__dict__["__immutable__"] = flag
+        for v in self.values():
+            if isinstance(v, _YacsNode):
+                v._imm(flag)
+
+    def defrost(self):
+        self._imm(False)
+
+    def freeze(self):
+        self._imm(True)
+
+
+_YacsNode.__module__, _YacsNode.__qualname__, _YacsNode.__name__ = "yacs.config", "CfgNode", "CfgNode"
+
+
+def to_yacs(cfg):
+    """This module's CfgNode -> the node the reference's `torch.load` turns into a yacs CfgNode."""
+    try:
+        from yacs.config import CfgNode as Y      # a real yacs, if the environment has one
+    except ImportError:
+        Y = _YacsNode
+    n = Y.__new__(Y)
+    dict.__init__(n)
+    n.__dict__.update({"__immutable__": bool(cfg.is_frozen()), "__deprecated_keys__": set(), "__renamed_keys__": {},
+                       "__new_allowed__": False})
+    for k, v in cfg.items():
+        dict.__setitem__(n, k, to_yacs(v) if isinstance(v, CfgNode) else copy.deepcopy(v))
+    return n
+
+
+def from_yacs(node):
+    """A config loaded from a checkpoint (yacs CfgNode, the stand-in, a plain dict or a yaml dump) -> CfgNode."""
+    if isinstance(node, CfgNode):
+        return node
+    if isinstance(node, str):
+        node = yaml.safe_load(node)
+    frozen = bool(getattr(node, "__dict__", {}).get("__immutable__", False))
+    c = CfgNode(node)
+    if frozen:
+        c.freeze()
+    return c
+
+
+class yacs_pickle_compat:
+    """While active, `yacs.config.CfgNode` resolves (for pickle, both directions) to the real yacs class when yacs
+    is installed and to the stand-in otherwise."""
+
+    def __enter__(self):
+        import sys
+        import types
+        self._added = []
+        try:
+            import yacs.config  # noqa: F401
+        except ImportError:
+            for name in ("yacs", "yacs.config"):
+                if name not in sys.modules:
+                    sys.modules[name] = types.ModuleType(name)
+                    self._added.append(name)
+            sys.modules["yacs"].config = sys.modules["yacs.config"]
+            sys.modules["yacs.config"].CfgNode = _YacsNode
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        for name in self._added:
+            sys.modules.pop(name, None)
+        return False
 
 
 def _coerce(new, old, key):

@@ -30,7 +30,25 @@ from . import _lib
 from .linear import _mm_acc, linear as _linear, weight_grad as _weight_grad
 from .streams import parallel as _parallel
 
-__all__ = ["PeriodDiscriminator", "MultiPeriodDiscriminator", "spectral_norm"]
+__all__ = ["PeriodDiscriminator", "MultiPeriodDiscriminator", "spectral_norm", "plain_torch_ops"]
+
+_PLAIN_OPS = [False]
+
+
+class plain_torch_ops:
+    """Inside this context the discriminator runs on plain torch operators (F.conv2d) on any device instead of the
+    HIP im2col + GEMM functions.  Those launch raw kernels in their backward and are therefore differentiable
+    ONCE; the WGAN-GP gradient penalty (model/loss.py:237-260) differentiates the discriminator TWICE
+    (`autograd.grad(create_graph=True)`), which only the plain operators support."""
+
+    def __enter__(self):
+        self._saved = _PLAIN_OPS[0]
+        _PLAIN_OPS[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _PLAIN_OPS[0] = self._saved
+        return False
 
 
 class _SpectralNorm(nn.Module):
@@ -500,7 +518,7 @@ class PeriodDiscriminator(nn.Module):
             x = F.pad(x, (0, n_pad), "reflect")
             t = t + n_pad
         wb = (lambda l: (l.weight.detach(), l.bias.detach())) if detach_weights else (lambda l: (l.weight, l.bias))
-        if not x.is_cuda:  # host/CPU runs (tests, cpu_baseline) keep the plain convolutions
+        if not x.is_cuda or _PLAIN_OPS[0]:  # host runs (tests, cpu_baseline) and double backward: plain convolutions
             x = x.view(b, c, t // self.period, self.period)
             for layer in list(self.layers) + [self.conv_post]:
                 w, bias = wb(layer)
@@ -560,7 +578,8 @@ class MultiPeriodDiscriminator(nn.Module):
         return [torch.flatten(c, 1, -1) for c in cur], StackedFeatures(fmaps, stacks, valid)
 
     def _use_batched(self, x):
-        return x.is_cuda and os.environ.get("VMASR_MPD_BATCHED", "1") == "1" and len(self.discriminators) > 1
+        return (x.is_cuda and not _PLAIN_OPS[0] and os.environ.get("VMASR_MPD_BATCHED", "1") == "1"
+                and len(self.discriminators) > 1)
 
     def forward_single(self, x, detach_weights=False):
         """scores and feature maps of ONE signal batch (used for the generator pass, where the

@@ -108,7 +108,9 @@ class HiFiGANLoss:
     def gradient_penalty(self, real_data, generated_data, discriminator):
         alpha = torch.rand(real_data.size(0), 1, 1, device=real_data.device)
         inter = (alpha * real_data + (1 - alpha) * generated_data).requires_grad_(True)
-        d_inter, _, _, _ = discriminator(inter, None)
+        from .discriminator import plain_torch_ops
+        with plain_torch_ops():        # twice-differentiable operators (the HIP conv functions are once-differentiable)
+            d_inter, _, _, _ = discriminator(inter, None)
         grads = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=[torch.ones_like(o) for o in d_inter],
                                     create_graph=True, retain_graph=True, only_inputs=True)[0]
         grads = grads.view(grads.size(0), -1)

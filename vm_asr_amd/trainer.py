@@ -100,8 +100,12 @@ def build_optimizer(config, models, capturable=False):
     groups = set_weight_decay(models)
     name = config.TRAIN.OPTIMIZER.NAME.lower()
     if name == "adamw":
-        lr = torch.tensor(float(config.TRAIN.BASE_LR)) if capturable else config.TRAIN.BASE_LR
         on_gpu = any(p.is_cuda for g in groups for p in g["params"])
+        # capturable: the learning rate is a DEVICE tensor the fused kernel reads at run time, so the schedule keeps
+        # working when the step is replayed from a HIP graph (a CPU tensor is read with .item() at capture and
+        # frozen into the graph); Trainer.lr_to_device() re-establishes this after .to(device) / load_state_dict
+        dev = next((p.device for g in groups for p in g["params"]), torch.device("cpu"))
+        lr = torch.tensor(float(config.TRAIN.BASE_LR), device=dev) if capturable else config.TRAIN.BASE_LR
         # fused: one multi-tensor kernel per step instead of ~10 foreach passes over 44 M parameters
         extra = dict(fused=True) if (capturable and on_gpu and os.environ.get("VMASR_FUSED_ADAMW", "1") == "1") \
             else dict(foreach=True if capturable else None)
@@ -134,12 +138,27 @@ class CosineWarmupScheduler:
         return self.min_lr + 0.5 * (self.base_lr - self.min_lr) * (1 + math.cos(math.pi * tt / self.t_initial))
 
     def step_update(self, num_updates):
-        lr = self.lr_at(num_updates)
+        lr, done = self.lr_at(num_updates), set()
         for g in self.opt.param_groups:
             if torch.is_tensor(g["lr"]):
-                g["lr"].fill_(lr)  # capturable optimisers keep lr on the device
+                if g["lr"].data_ptr() not in done:      # capturable optimisers keep ONE lr tensor on the device
+                    g["lr"].fill_(lr)
+                    done.add(g["lr"].data_ptr())
             else:
                 g["lr"] = lr
+
+
+def lr_to_device(optimizer, device):
+    """Capturable optimisers: every param group shares one lr tensor that lives on `device` (see build_optimizer).
+    Needed after the models moved to the GPU and after `optimizer.load_state_dict` (which restores a CPU value)."""
+    if optimizer is None or not optimizer.defaults.get("capturable", False):
+        return
+    shared = {}
+    for g in optimizer.param_groups:
+        v = float(g["lr"])
+        if v not in shared:
+            shared[v] = torch.tensor(v, dtype=torch.float32, device=device)
+        g["lr"] = shared[v]
 
 
 class _Logger:
@@ -153,7 +172,7 @@ class _Logger:
 
 
 class BaseTrainer:
-    def __init__(self, models, metric_ftns, optimizer, config, logger=None):
+    def __init__(self, models, metric_ftns, optimizer, config, logger=None, resume_now=True):
         self.config, self.logger = config, logger or _Logger()
         self.models, self.metric_ftns, self.optimizer = models, metric_ftns, optimizer
         self.epochs, self.monitor = config.TRAIN.EPOCHS, config.MONITOR
@@ -170,7 +189,9 @@ class BaseTrainer:
         self.log_dir = config.OUTPUT
         self.epoch_log = {}
         self.do_validation = False
-        if config.MODEL.RESUME_PATH is not None:
+        # (Trainer resumes at the END of its own constructor, once the models sit on their device: the optimiser
+        #  state then loads next to the parameters instead of staying on the host)
+        if config.MODEL.RESUME_PATH is not None and resume_now:
             self._resume_checkpoint()
 
     def _train_epoch(self, epoch):
@@ -185,6 +206,7 @@ class BaseTrainer:
             self._train_epoch(epoch)
             if self.do_validation:
                 self._valid_epoch(epoch)
+            self._sync_epoch_log()
             log = {"epoch": epoch, **self.epoch_log}
             self._log_epoch(log)
             best = False
@@ -204,12 +226,30 @@ class BaseTrainer:
                         break
             self._save_checkpoint(epoch, save_best=best)
 
+    def _sync_epoch_log(self):
+        """Multi-process runs: every rank continues with the MEAN of the ranks' epoch scalars, so that 'improved',
+        early stopping and the NaN abort below are the same decision everywhere (a rank that left train() alone
+        would strand the others in the next all-reduce)."""
+        if self.world <= 1 or not dist.is_initialized():
+            return
+        keys = sorted(k for k, v in self.epoch_log.items() if isinstance(v, (int, float)))
+        dev = getattr(self, "device", torch.device("cpu"))
+        if dist.get_backend() == "gloo":
+            dev = torch.device("cpu")
+        t = torch.tensor([float(self.epoch_log[k]) for k in keys], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)                      # NaN / inf on any rank propagates to all
+        for k, v in zip(keys, (t / self.world).tolist()):
+            self.epoch_log[k] = v
+
     def _save_checkpoint(self, epoch, save_best=False):
         """checkpoint-{latest,best,epoch-N}-{G|mpd}.pth with the reference's dict layout
-        (base/base_trainer.py:130-179); rank 0 writes."""
+        (base/base_trainer.py:130-179), `config` included as an object the reference's loader can `.defrost()`
+        (utils/utils.py:141-145; config.to_yacs); rank 0 writes."""
         if self.rank != 0:
             return
+        from .config import to_yacs, yacs_pickle_compat
         os.makedirs(self.log_dir, exist_ok=True)
+        cfg_obj = to_yacs(self.config) if hasattr(self.config, "is_frozen") else self.config
         for key, model in self.models.items():
             if model is None:
                 continue
@@ -217,16 +257,20 @@ class BaseTrainer:
             mtype = "generator" if key == "generator" else "discriminator"
             state = {"name": name, "epoch": epoch, "state_dict": unwrap(model).state_dict(),
                      "optimizer": self.optimizer[mtype].state_dict(), "monitor_best": self.mnt_best,
-                     "config": self.config.dump() if hasattr(self.config, "dump") else self.config}
-            torch.save(state, os.path.join(self.log_dir, f"checkpoint-latest-{name}.pth"))
-            if self.config.SAVE_EPOCH_FREQ != -1 and epoch % self.config.SAVE_EPOCH_FREQ == 0:
-                torch.save(state, os.path.join(self.log_dir, f"checkpoint-epoch-{epoch}-{name}.pth"))
-            if save_best:
-                torch.save(state, os.path.join(self.log_dir, f"checkpoint-best-{name}.pth"))
+                     "config": cfg_obj}
+            with yacs_pickle_compat():
+                torch.save(state, os.path.join(self.log_dir, f"checkpoint-latest-{name}.pth"))
+                if self.config.SAVE_EPOCH_FREQ != -1 and epoch % self.config.SAVE_EPOCH_FREQ == 0:
+                    torch.save(state, os.path.join(self.log_dir, f"checkpoint-epoch-{epoch}-{name}.pth"))
+                if save_best:
+                    torch.save(state, os.path.join(self.log_dir, f"checkpoint-best-{name}.pth"))
 
     def _resume_checkpoint(self):
         """Loads `checkpoint-best-*.pth` (falls back to latest) from MODEL.RESUME_PATH
-        (utils/utils.py:112-178): state_dict strict, optimizer state, epoch, monitor_best."""
+        (utils/utils.py:112-178): state_dict strict, optimizer state, epoch, monitor_best; the generator's
+        checkpoint also restores the run's config, as the reference does (:141-145).  Reads the reference's own
+        files too (their pickled yacs CfgNode resolves through config.yacs_pickle_compat)."""
+        from .config import from_yacs, yacs_pickle_compat
         path = self.config.MODEL.RESUME_PATH
         for key, model in self.models.items():
             if model is None:
@@ -236,12 +280,21 @@ class BaseTrainer:
             for kind in ("best", "latest"):
                 f = os.path.join(path, f"checkpoint-{kind}-{name}.pth")
                 if os.path.exists(f):
-                    ck = torch.load(f, map_location="cpu", weights_only=False)
+                    with yacs_pickle_compat():
+                        ck = torch.load(f, map_location="cpu", weights_only=False)
                     unwrap(model).load_state_dict(ck["state_dict"], strict=True)
                     if self.optimizer and mtype in self.optimizer and "optimizer" in ck:
-                        self.optimizer[mtype].load_state_dict(ck["optimizer"])
-                    self.start_epoch = ck["epoch"] + 1
-                    self.mnt_best = ck.get("monitor_best", self.mnt_best)
+                        opt = self.optimizer[mtype]
+                        opt.load_state_dict(ck["optimizer"])     # state tensors follow their parameter's device
+                        lr_to_device(opt, next(unwrap(model).parameters()).device)
+                    if key == "generator":
+                        self.start_epoch = ck["epoch"] + 1
+                        self.mnt_best = ck.get("monitor_best", self.mnt_best)
+                        if ck.get("config") is not None:
+                            cfg = from_yacs(ck["config"]).clone()
+                            cfg.MODEL.RESUME_PATH = path
+                            cfg.freeze()
+                            self.config = cfg
                     self.logger.info(f"Resumed {name} from {f} (epoch {ck['epoch']})")
                     break
         if getattr(self, "_shadow_dst", None):
@@ -266,13 +319,16 @@ class Trainer(BaseTrainer):
         amp_scope: what autocast covers when `amp` is on.  "generator" = the reference's scope
         (trainer/trainer.py:138-139: only the generator forward; the losses and the discriminator run
         outside autocast, i.e. in fp32); "step" = generator, losses and discriminator (bf16 MPD)."""
-        super().__init__(models, metric_ftns, optimizers, config, logger)
+        super().__init__(models, metric_ftns, optimizers, config, logger, resume_now=False)
         self.dp_mode = dp_mode
         if amp_scope not in ("generator", "step"):
             raise ValueError(f"amp_scope='{amp_scope}'")
         self.amp_scope = amp_scope
         self._flat, self._flat_params, self._flat_views = {}, {}, {}
-        self._gather = config.TRAIN.ACCUMULATION_STEPS == 1   # fresh grads are packed, not accumulated in place
+        self._acc = max(1, int(config.TRAIN.ACCUMULATION_STEPS))
+        self._gather = self._acc == 1   # fresh grads are packed, not accumulated in place
+        self._micro = 0                 # micro-batches seen (gradient accumulation)
+        self._pending = []              # in-flight gradient all-reduces (async work handles)
         self._graphed = None
         self.device = device[0] if isinstance(device, (tuple, list)) else device
         self.data_loader, self.data_loader_val = data_loader_train, data_loader_val
@@ -294,7 +350,11 @@ class Trainer(BaseTrainer):
         elif self.world > 1:
             self._broadcast_state()
         self.global_step = 0
+        for opt in (self.optimizer_G, getattr(self, "optimizer_D", None)):
+            lr_to_device(opt, self.device)
         self._make_shadows()
+        if config.MODEL.RESUME_PATH is not None:
+            self._resume_checkpoint()      # after .to(device): optimiser state lands next to the parameters
 
     # ---- distributed -----------------------------------------------------------------------
     def _wrap_ddp(self):
@@ -364,6 +424,7 @@ class Trainer(BaseTrainer):
             fmap_real = fr.detach() if hasattr(fr, "stacks") else [[f.detach() for f in fs] for fs in fr]
             d = self.higi_gan_loss.discriminator_loss(y_real, y_gen)
             if self.config.TRAIN.ADVERSARIAL.GAN_LOSS_TYPE == "wgan-gp":
+                # double backward: runs the discriminator on plain (twice differentiable) torch operators
                 d = d + self.higi_gan_loss.gradient_penalty(wave_target, fake, unwrap(self.models["mpd"]))
             out["mpd"] = d
         return out, fmap_real
@@ -424,23 +485,38 @@ class Trainer(BaseTrainer):
             p.grad = v
         torch._foreach_copy_(dst, src)
 
-    def _reduce_grads(self, key):
-        """ONE all-reduce per model per step over RCCL/xGMI (generator 9 MB, MPD 164 MB fp32)."""
+    def _reduce_grads(self, key, async_op=False):
+        """ONE all-reduce (mean) per model per step over RCCL/xGMI (generator 9 MB, MPD 164 MB fp32).
+        async_op: the call returns at once and the collective runs on RCCL's own stream — the caller overlaps it
+        with further work and joins it with _wait_reduces() before the optimiser reads the gradients."""
         if self.world > 1 and self.dp_mode == "flat":
             if key not in self._flat:
                 self._setup_flat(key, None)
             flat = self._flat[key]
-            dist.all_reduce(flat)
-            flat.div_(self.world)
+            avg = dist.get_backend() == "nccl"      # RCCL averages in the collective; gloo has no AVG
+            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
+            self._pending.append((work if async_op else None, None if avg else flat))
+            if not async_op:
+                self._wait_reduces()
+
+    def _wait_reduces(self):
+        for work, flat in self._pending:
+            if work is not None:
+                work.wait()                # the current stream waits for the collective (no host block on RCCL)
+            if flat is not None:
+                flat.div_(self.world)
+        self._pending = []
 
     # ---- one optimisation step (the unit bench.py times) ------------------------------------
-    def _forward_backward(self, wave_input, wave_target, highcut):
-        """forward -> losses -> backward of the G loss and of the D loss (the D graph is built on the
-        same D weights the G pass sees, so both backwards can run before either optimiser step)."""
-        acc = self.config.TRAIN.ACCUMULATION_STEPS
+    def _forward_losses(self, wave_input, wave_target, highcut):
+        """generator forward -> discriminator + generator losses (one autograd graph; the D graph is built on the
+        same D weights the G pass sees, so both backwards can run before either optimiser step).
+        Returns the state the two backward phases consume."""
+        acc = self._acc
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
             wave_out = self.models["generator"](wave_input, highcut)
         shared = self._share_fake_pass()
+        d_losses = {}
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp and self.amp_scope == "step"):
             # D loss first, with the same D weights the G pass sees (reference order, trainer/trainer.py:369-399)
             with self._mpd_weights_once():
@@ -459,26 +535,45 @@ class Trainer(BaseTrainer):
                     d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
                     g_losses = self._generator_losses(wave_out, wave_target, fmap_real)
         total_g = sum(g_losses.values()) / acc
-        self._zero_grads("generator", self.optimizer_G)
-        if shared:
-            from .discriminator import skip_weight_grads
-            with skip_weight_grads():
-                total_g.backward(inputs=self._grad_targets("generator"), retain_graph=True)
-        else:
-            total_g.backward()
-        self._gather_grads("generator")
         logs = {"total_loss": total_g.detach()}
         logs.update({f"generator/{k}": v.detach() for k, v in g_losses.items()})
+        total_d = None
         if self.gan:
             total_d = sum(d_losses.values()) / acc
-            self._zero_grads("mpd", self.optimizer_D)
-            if shared:
-                total_d.backward(inputs=self._grad_targets("mpd"))
-            else:
-                total_d.backward()
-            self._gather_grads("mpd")
             logs["total_disc_loss"] = total_d.detach()
-        return wave_out.detach(), logs
+        return {"wave_out": wave_out, "total_g": total_g, "total_d": total_d, "shared": shared, "logs": logs}
+
+    def _backward_d(self, st, zero=True):
+        """Backward of the discriminator loss (weight gradients of the MPD) + packing into its flat buffer.
+        Runs BEFORE the generator's backward so that the 164 MB MPD all-reduce can overlap the latter."""
+        if not self.gan:
+            return
+        if zero:
+            self._zero_grads("mpd", self.optimizer_D)
+        if st["shared"]:
+            st["total_d"].backward(inputs=self._grad_targets("mpd"), retain_graph=True)
+        else:
+            st["total_d"].backward()
+        self._gather_grads("mpd")
+
+    def _backward_g(self, st, zero=True):
+        """Backward of the generator loss — through the (shared) discriminator pass for input gradients only."""
+        if zero:
+            self._zero_grads("generator", self.optimizer_G)
+        if st["shared"]:
+            from .discriminator import skip_weight_grads
+            with skip_weight_grads():
+                st["total_g"].backward(inputs=self._grad_targets("generator"))
+        else:   # the generator's pass saw the discriminator weights as constants (detach_weights)
+            st["total_g"].backward()
+        self._gather_grads("generator")
+
+    def _forward_backward(self, wave_input, wave_target, highcut, zero=True):
+        """forward -> losses -> backward of the D loss -> backward of the G loss (no collectives, no optimiser)."""
+        st = self._forward_losses(wave_input, wave_target, highcut)
+        self._backward_d(st, zero)
+        self._backward_g(st, zero)
+        return st["wave_out"].detach(), st["logs"]
 
     def _share_fake_pass(self):
         """One discriminator pass over the generated signal for both losses: GPU, flat gradient buffers (no DDP
@@ -534,9 +629,10 @@ class Trainer(BaseTrainer):
         self._refresh_shadows()
 
     def _reduce_and_step(self):
-        self._reduce_grads("generator")
         if self.gan:
-            self._reduce_grads("mpd")
+            self._reduce_grads("mpd", async_op=True)
+        self._reduce_grads("generator", async_op=True)
+        self._wait_reduces()
         self._optimizer_steps()
 
     # ---- low-precision shadow weights ----------------------------------------------------------
@@ -566,11 +662,25 @@ class Trainer(BaseTrainer):
         """One optimisation step of G (and D); returns (wave_out, dict of loss tensors)."""
         if self._graphed is not None:
             out = self._graphed(wave_input, wave_target, highcut)
-        else:
-            out = self._forward_backward(wave_input, wave_target, highcut)
-            self._reduce_and_step()
-        self.global_step += 1
-        return out
+            self.global_step += 1
+            return out
+        # gradient accumulation (TRAIN.ACCUMULATION_STEPS): gradients of `acc` consecutive micro-batches (each
+        # loss / acc) are summed in place; collectives and optimisers run on the last one.  The reference divides
+        # the loss the same way but calls backward only on every acc-th batch (trainer/trainer.py:146-156), i.e. it
+        # drops the other batches; accumulating them is what the option's name promises (DESIGN.md §7).
+        first, last = self._micro % self._acc == 0, (self._micro + 1) % self._acc == 0
+        self._micro += 1
+        st = self._forward_losses(wave_input, wave_target, highcut)
+        self._backward_d(st, zero=first)
+        if last and self.gan:
+            self._reduce_grads("mpd", async_op=True)        # overlaps the generator's backward
+        self._backward_g(st, zero=first)
+        if last:
+            self._reduce_grads("generator", async_op=True)
+            self._wait_reduces()
+            self._optimizer_steps()
+            self.global_step += 1
+        return st["wave_out"].detach(), st["logs"]
 
     def enable_graphs(self, example_batch, warmup=3):
         """Capture forward+backward (one HIP graph) and the optimiser steps (a second one); the
@@ -615,11 +725,15 @@ class Trainer(BaseTrainer):
                 if self.rank == 0:
                     self.logger.info(f"Epoch {epoch} [{batch_idx + 1}/{self.len_epoch}] " +
                                      " ".join(f"{k}={v:.4f}" for k, v in vals.items()))
-            step = (epoch - 1) * self.len_epoch + batch_idx
+        # the learning-rate schedule advances once per EPOCH, with the reference's update index
+        # (trainer/trainer.py:196-218: `(epoch * num_steps + batch_idx) // ACCUMULATION_STEPS` after the batch loop)
+        if count:
+            num_steps = self.len_epoch // self._acc
+            upd = (epoch * num_steps + batch_idx) // self._acc
             if self.lr_scheduler_G is not None:
-                self.lr_scheduler_G.step_update(step // self.config.TRAIN.ACCUMULATION_STEPS)
+                self.lr_scheduler_G.step_update(upd)
             if self.gan and getattr(self, "lr_scheduler_D", None) is not None:
-                self.lr_scheduler_D.step_update(step // self.config.TRAIN.ACCUMULATION_STEPS)
+                self.lr_scheduler_D.step_update(upd)
         self.epoch_log = {k: v / max(1, count) for k, v in sums.items()}
         self.epoch_log["epoch_seconds"] = time.time() - t0
 
@@ -643,9 +757,9 @@ class Trainer(BaseTrainer):
             t = torch.tensor([sums[k] for k in keys] + [float(count)], device=self.device, dtype=torch.float64)
             dist.all_reduce(t)
             sums, count = {k: t[i].item() for i, k in enumerate(keys)}, int(t[-1].item())
+        # validation values go in under "val_*" only: MONITOR ("min lsd", config.py:223) keeps watching the TRAINING
+        # metric, exactly as the reference does (trainer/trainer.py:312-313)
         self.epoch_log.update({f"val_{k}": v / max(1, count) for k, v in sums.items()})
-        if self.mnt_mode != "off" and self.mnt_metric in sums:
-            self.epoch_log[self.mnt_metric] = sums[self.mnt_metric] / max(1, count)
 
 
 def default_metric_ftns(config):
