@@ -10,29 +10,51 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvmasr_oracle.so")
+_LIB64_PATH = os.path.join(_HERE, "libvmasr_oracle64.so")
 _lib = None
+_lib64 = None
+_F64 = [False]
 
-__all__ = ["build", "lib", "num_threads", "sscan_fwd", "sscan_bwd", "cross_scan", "cross_merge",
+
+class float64:
+    """Context manager: inside it every function of this module runs the float64 build of the same C source
+    (libvmasr_oracle64.so) on float64 arrays — the adjudicator of fp32-vs-fp32 differences (vmasr_oracle.c header)."""
+
+    def __enter__(self):
+        self._saved = _F64[0]
+        _F64[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _F64[0] = self._saved
+        return False
+
+
+def _dt():
+    return np.float64 if _F64[0] else np.float32
+
+__all__ = ["build", "lib", "num_threads", "float64", "sscan_fwd", "sscan_bwd", "cross_scan", "cross_merge",
            "dwconv_silu_fwd", "dwconv_silu_bwd", "stft", "stft_bwd", "istft", "istft_bwd", "lsd", "snr"]
 
 
 def build(force=False):
     """Compile the C restatement with gcc (no GPU, no reference needed)."""
     src = os.path.join(_HERE, "vmasr_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libvmasr_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+    for path in (_LIB_PATH, _LIB64_PATH):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(path)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
 def lib():
-    global _lib
+    global _lib, _lib64
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_LIB_PATH)
-        _lib.vmasr_oracle_num_threads.restype = ctypes.c_int
-        _lib.vmasr_oracle_stft_frames.restype = ctypes.c_int
-    return _lib
+        _lib, _lib64 = ctypes.CDLL(_LIB_PATH), ctypes.CDLL(_LIB64_PATH)
+        for l in (_lib, _lib64):
+            l.vmasr_oracle_num_threads.restype = ctypes.c_int
+            l.vmasr_oracle_stft_frames.restype = ctypes.c_int
+    return _lib64 if _F64[0] else _lib
 
 
 def num_threads():
@@ -40,7 +62,7 @@ def num_threads():
 
 
 def _f(a):
-    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    return None if a is None else np.ascontiguousarray(a, dtype=_dt())
 
 
 def _p(a):
@@ -55,7 +77,7 @@ def sscan_fwd(u, delta, A, B, C, D=None, bias=None, softplus=False, return_last_
         C = C[:, None]
     G, N = B.shape[1], B.shape[2]
     out = np.empty_like(u)
-    last = np.empty((batch, dim, N), np.float32)
+    last = np.empty((batch, dim, N), _dt())
     lib().vmasr_oracle_sscan_fwd(_p(u), _p(delta), _p(A), _p(B), _p(C), _p(D), _p(bias),
                                  int(softplus), batch, dim, G, N, L, _p(out), _p(last))
     return (out, last) if return_last_state else out
@@ -72,8 +94,8 @@ def sscan_bwd(u, delta, A, B, C, D, bias, dout, softplus=False):
     du, dd = np.empty_like(u), np.empty_like(u)
     dA = np.empty_like(A)
     dB, dC = np.empty_like(B), np.empty_like(C)
-    dD = np.empty(dim, np.float32) if D is not None else None
-    db = np.empty(dim, np.float32) if bias is not None else None
+    dD = np.empty(dim, _dt()) if D is not None else None
+    db = np.empty(dim, _dt()) if bias is not None else None
     lib().vmasr_oracle_sscan_bwd(_p(u), _p(delta), _p(A), _p(B), _p(C), _p(D), _p(bias), _p(dout),
                                  int(softplus), batch, dim, G, N, L, _p(du), _p(dd), _p(dA),
                                  _p(dB), _p(dC), _p(dD), _p(db))
@@ -85,7 +107,7 @@ def sscan_bwd(u, delta, A, B, C, D, bias, dout, softplus=False):
 def cross_scan(x):
     x = _f(x)
     Bn, C, H, W = x.shape
-    xs = np.empty((Bn, 4, C, H * W), np.float32)
+    xs = np.empty((Bn, 4, C, H * W), _dt())
     lib().vmasr_oracle_cross_scan(_p(x), Bn, C, H, W, _p(xs))
     return xs
 
@@ -94,7 +116,7 @@ def cross_merge(ys):
     ys = _f(ys)
     Bn, K, C, H, W = ys.shape
     assert K == 4
-    y = np.empty((Bn, C, H * W), np.float32)
+    y = np.empty((Bn, C, H * W), _dt())
     lib().vmasr_oracle_cross_merge(_p(ys), Bn, C, H, W, _p(y))
     return y
 
@@ -111,7 +133,7 @@ def dwconv_silu_bwd(x, w, b, g):
     x, w, b, g = _f(x), _f(w), _f(b), _f(g)
     Bn, C, H, W = x.shape
     dx, dw = np.empty_like(x), np.empty_like(w)
-    db = np.empty(C, np.float32)
+    db = np.empty(C, _dt())
     lib().vmasr_oracle_dwconv_silu_bwd(_p(x), _p(w), _p(b), _p(g), Bn, C, H, W, _p(dx), _p(dw), _p(db))
     return dx, dw, db
 
@@ -122,7 +144,7 @@ def stft(wav, n_fft, hop, win, normalized=True, logmag=True):
     lead, T = wav.shape[:-1], wav.shape[-1]
     w2 = wav.reshape(-1, T)
     F, M = n_fft // 2 + 1, 1 + T // hop
-    o0 = np.empty((w2.shape[0], F, M), np.float32)
+    o0 = np.empty((w2.shape[0], F, M), _dt())
     o1 = np.empty_like(o0)
     lib().vmasr_oracle_stft(_p(w2), w2.shape[0], T, n_fft, hop, win, int(normalized), int(logmag),
                             _p(o0), _p(o1))
@@ -134,7 +156,7 @@ def stft_bwd(gre, gim, T, n_fft, hop, win, normalized=False):
     gre, gim = _f(gre), _f(gim)
     lead, (F, M) = gre.shape[:-2], gre.shape[-2:]
     g0, g1 = gre.reshape(-1, F, M), gim.reshape(-1, F, M)
-    gw = np.empty((g0.shape[0], T), np.float32)
+    gw = np.empty((g0.shape[0], T), _dt())
     lib().vmasr_oracle_stft_bwd(_p(g0), _p(g1), g0.shape[0], T, n_fft, hop, win, int(normalized), _p(gw))
     return gw.reshape(*lead, T)
 
@@ -143,7 +165,7 @@ def istft(mag, phase, hop, win):
     mag, phase = _f(mag), _f(phase)
     lead, (F, M) = mag.shape[:-2], mag.shape[-2:]
     m2, p2 = mag.reshape(-1, F, M), phase.reshape(-1, F, M)
-    wav = np.empty((m2.shape[0], hop * (M - 1)), np.float32)
+    wav = np.empty((m2.shape[0], hop * (M - 1)), _dt())
     lib().vmasr_oracle_istft(_p(m2), _p(p2), m2.shape[0], F, M, hop, win, _p(wav))
     return wav.reshape(*lead, -1)
 
@@ -162,7 +184,7 @@ def lsd(output, target, n_fft=2048, hop=512):
     """Log-spectral distance, model/metric.py:5-12,26-29 (non-normalised hann STFT)."""
     def spec(a):
         re, im = stft(a, n_fft, hop, n_fft, normalized=False, logmag=False)
-        return np.sqrt(re.astype(np.float32) ** 2 + im.astype(np.float32) ** 2)
+        return np.sqrt(re.astype(_dt()) ** 2 + im.astype(_dt()) ** 2)
     sp = np.log10(np.maximum(spec(output) ** 2, 1e-8))
     st = np.log10(np.maximum(spec(target) ** 2, 1e-8))
     return float(np.mean(np.sqrt(np.mean((sp - st) ** 2, axis=-2))))

@@ -10,8 +10,13 @@ import torch
 from . import oracle as oracle
 
 
+def _tdt():
+    """torch dtype of the active oracle build (float32, or float64 inside `oracle.float64()`)."""
+    return torch.float64 if oracle._F64[0] else torch.float32
+
+
 def _n(t):
-    return None if t is None else t.detach().float().cpu().numpy()
+    return None if t is None else t.detach().to(_tdt()).cpu().numpy()
 
 
 class OracleSelectiveScan(torch.autograd.Function):
@@ -94,7 +99,7 @@ def oracle_wav2spectro(waveform, n_fft, hop_length, win_length, spectro_scale):
 def oracle_spectro2wav(mag, phase, n_fft, hop_length, win_length, spectro_scale):
     assert spectro_scale == "log2"
     *other, F, M = mag.shape
-    wav = OracleISTFT.apply(mag.reshape(-1, F, M).float(), phase.reshape(-1, F, M).float(), hop_length, win_length)
+    wav = OracleISTFT.apply(mag.reshape(-1, F, M).to(_tdt()), phase.reshape(-1, F, M).to(_tdt()), hop_length, win_length)
     return wav.view(*other, wav.shape[-1])
 
 
@@ -116,12 +121,16 @@ def oracle_stft_reim(waveform, n_fft, hop_length, win_length, normalized=False):
     return OracleSTFTReIm.apply(waveform, n_fft, hop_length, win_length, normalized)
 
 
-def use_oracle(module):
-    """Rewire every SS2D in `module` to the CPU oracle (the reference's own hook mechanism)."""
+def use_oracle(module, f64=False):
+    """Rewire every SS2D in `module` to the CPU oracle (the reference's own hook mechanism).
+    f64: the float64 evaluation (adjudicator): module.double(), no fp32 cast in front of the scan; run the model
+    inside `with oracle.float64(), oracle_stft_patch():`."""
     from vm_asr_amd.vmamba import SS2D
+    if f64:
+        module.double()
     for m in module.modules():
         if isinstance(m, SS2D):
-            m.forward_core = partial(m.forward_corev2, force_fp32=(not m.disable_force32),
+            m.forward_core = partial(m.forward_corev2, force_fp32=(not m.disable_force32) and not f64,
                                      SelectiveScan=OracleSelectiveScan, CrossScan=OracleCrossScan,
                                      CrossMerge=OracleCrossMerge)
             m.conv_act_fn = OracleDWConvSiLU.apply

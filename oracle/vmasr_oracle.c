@@ -23,6 +23,23 @@
 
 #define VMASR_API __attribute__((visibility("default")))
 
+/* float64 build of the SAME source (oracle/Makefile: libvmasr_oracle64.so, -DVMASR_ORACLE_F64): every `float`
+ * below becomes a double and every fp32 math call its double form.  It is the ADJUDICATOR of the parity tests:
+ * where two fp32 evaluations differ by more than the tolerance budget (ill-conditioned spots such as a LayerNorm over
+ * two channels), the one closer to this float64 evaluation is the more accurate one.  Same entry points, arrays
+ * of double.  (The keyword macro is defined after the last #include.) */
+#ifdef VMASR_ORACLE_F64
+#define float double
+#define expf exp
+#define exp2f exp2
+#define log1pf log1p
+#define log2f log2
+#define sqrtf sqrt
+#define sinf sin
+#define cosf cos
+#define atan2f atan2
+#endif
+
 /* F.softplus (threshold 20) as used by selective_scan_ref
  * (kernels/selective_scan/test_selective_scan.py:315-316) and by the CUDA kernel
  * (cus/selective_scan_fwd_kernel.cuh:115-118). */
@@ -381,7 +398,7 @@ VMASR_API void vmasr_oracle_stft(const float *wav, int Bn, int T, int n_fft, int
                     const float r = (float)(re[f] * scale), i = (float)(im[f] * scale);
                     const size_t o = ((size_t)b * F + f) * M + m;
                     if (logmag) {
-                        out0[o] = log2f(sqrtf(r * r + i * i) + 1e-8f);
+                        out0[o] = log2f(sqrtf(r * r + i * i) + (float)1e-8);
                         out1[o] = atan2f(i, r);
                     } else { out0[o] = r; out1[o] = i; }
                 }

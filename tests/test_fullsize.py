@@ -82,8 +82,9 @@ def test_fullsize_forward_hip(tag, hop):
     over TWO channels, (a-b)/sqrt((a-b)^2+4 eps) — where the two channels are within sqrt(eps) ~ 3e-3 of each
     other it multiplies any rounding-level difference by up to 1/sqrt(eps) ~ 300.  That is a property of the
     reference architecture (quirk: output_version v3 ends in a 1-channel VSS block), not of an implementation:
-    two correct fp32 evaluations differ there by ~1e-3 of the peak.  Bounds after it: 5e-3 (max) and 5e-4 (RMS)
-    of the output peak, LSD within 2e-3."""
+    two correct fp32 evaluations differ there by a few 1e-4 of the peak (each sits 1.5e-4 .. 2.6e-4 from the float64
+    answer, test_fullsize_forward_hip_fp64_adjudicated).  Bounds after it: 1e-3 (max) and 1e-4 (RMS) of the output
+    peak, LSD within 1e-3."""
     import oracle
     from oracle.torch_backend import oracle_stft_patch, use_oracle
     z = np.load(os.path.join(GOLDEN, "fullsize.npz"))
@@ -104,10 +105,10 @@ def test_fullsize_forward_hip(tag, hop):
     scale = np.abs(want).max()
     for y, what in ((y_gpu.numpy(), "hip vs reference"), (y_gpu.numpy() - y_cpu.numpy() + want, "hip vs cpu-oracle")):
         d = np.abs(y - want)
-        assert d.max() <= 5e-3 * scale, (tag, what, d.max(), scale)
-        assert np.sqrt((d.astype(np.float64) ** 2).mean()) <= 5e-4 * scale, (tag, what)
+        assert d.max() <= 1e-3 * scale, (tag, what, d.max(), scale)
+        assert np.sqrt((d.astype(np.float64) ** 2).mean()) <= 1e-4 * scale, (tag, what)
     lsd = oracle.lsd(y_gpu.numpy()[:, 0], z[f"{tag}_target"][:, 0])
-    assert abs(lsd - float(z[f"{tag}_lsd"])) < 2e-3, (lsd, float(z[f"{tag}_lsd"]))
+    assert abs(lsd - float(z[f"{tag}_lsd"])) < 1e-3, (lsd, float(z[f"{tag}_lsd"]))
 
 
 # ---- float64-adjudicated accuracy, dims-32 and n_fft-2048 configurations ---------------------------------------
@@ -141,15 +142,15 @@ def test_fullsize_forward_cpu_oracle_fp64_adjudicated(tag):
     _adjudicate(tag, "cpu-oracle", y, y32, y64, target, lsd_ref)
 
 
-K_MAX, K_RMS = 8.0, 4.0
+K_MAX, K_RMS = 2.5, 2.0      # measured on MI355X (round 2): 0.4 .. 1.34 (max), 0.64 .. 1.26 (RMS) over the four cases
 
 
 def _adjudicate(tag, who, y, y32, y64, target, lsd_ref):
     """The exact output is y64 (the reference evaluated in float64, make_golden.py::gen_fullsize2).  The reference's
-    own fp32 run sits e_ref = |y32 - y64| from it; ours must sit within a constant factor of that — the factor,
-    not a prose tolerance, is the claim: K_MAX on the worst sample, K_RMS in RMS.  (A different fp32 evaluation
-    order of the same 34-block network cannot be expected to have the SAME error as the reference's, only the same
-    order of magnitude; both are dominated by the final LayerNorm over two channels, see test_fullsize_forward_hip.)"""
+    own fp32 run sits e_ref = |y32 - y64| from it (1.5e-4 .. 6.7e-4 of the peak at the worst sample — above the
+    1e-4 of north_star, because the last VSS block's LayerNorm over two channels amplifies rounding); ours must be
+    AS CLOSE to the exact answer as the reference's fp32 run is, within the factors K_MAX (worst sample) and K_RMS
+    (RMS): the factor, not a prose tolerance, is the claim."""
     import oracle
     e_ref, e = np.abs(y32.astype(np.float64) - y64), np.abs(y.astype(np.float64) - y64)
     peak = np.abs(y64).max()
@@ -173,53 +174,91 @@ def test_fullsize_forward_hip_fp64_adjudicated(tag):
     _adjudicate(tag, "hip fp32", y, y32, y64, target, lsd_ref)
 
 
+def _oracle64_forward(tag):
+    import oracle
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
+    (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case(tag)
+    m = use_oracle(_model(hop, dims, n_fft, win), f64=True)
+    with oracle.float64(), oracle_stft_patch(), torch.no_grad():
+        y = m(wave.double(), hf)
+    return y.numpy(), y64
+
+
+@pytest.mark.parametrize("tag", ["16k", "48k", "d32", "n2048"])
+def test_float64_oracle_equals_float64_reference(tag):
+    """Pins the ADJUDICATOR: this package's modules in float64 on the float64 build of the oracle's C source
+    (oracle.float64) reproduce the reference's own float64 evaluation (module.double() + selective_scan_ref in
+    double, tests/golden/fullsize2.npz) to 1e-9 of the peak — two independent float64 evaluations of the same
+    network agree, so either can stand for "the exact answer" (used for gradients, where no reference golden of
+    a full-size backward exists: its Python-loop scan cannot be back-propagated at L = 262 144)."""
+    y, y64 = _oracle64_forward(tag)
+    assert y.dtype == np.float64 and np.abs(y - y64).max() <= 1e-9 * np.abs(y64).max()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["48k", "d32"])
 def test_fullsize_forward_hip_bf16_autocast(tag):
     """north_star: 1e-2 for bf16.  The generator under bf16 autocast exactly as the trainer runs it (scan, LayerNorm,
-    STFT in fp32; Linear / conv GEMMs in bf16) against the float64 output: RMS error <= 1e-2 of the peak and LSD
-    within 1e-2 of the reference's.  (The worst single sample is reported, not bounded at 1e-2: the final
-    two-channel LayerNorm turns a bf16-level input difference into an O(1) change of its +-1 output at isolated
-    time-frequency bins, see test_fullsize_forward_hip.)"""
+    STFT in fp32; Linear / conv GEMMs in bf16) against the float64 output.  What holds at 1e-2: the LSD (the parity
+    metric of BASELINE.json).  The WAVEFORM error is ~3e-2 of the peak in RMS — a property of bf16 autocast on this
+    architecture, not of the HIP path: torch's own CPU autocast of the same module on the fp32 oracle kernels
+    (bf16 Linear/conv, everything else fp32 — the reference's autocast policy) lands at the same distance, and that
+    is the bound: RMS error <= 1.5x the CPU-autocast run's, and <= 5e-2 of the peak absolutely."""
     import oracle
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
     (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case(tag)
     m = _model(hop, dims, n_fft, win).to("cuda:0")
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         y = m(wave.cuda(), hf.cuda()).float().cpu().numpy()
-    e, peak = np.abs(y.astype(np.float64) - y64), np.abs(y64).max()
+    m_cpu = use_oracle(_model(hop, dims, n_fft, win))
+    with oracle_stft_patch(), torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        y_cpu = m_cpu(wave, hf).float().numpy()
+    peak = np.abs(y64).max()
+    e, e_cpu = np.abs(y.astype(np.float64) - y64), np.abs(y_cpu.astype(np.float64) - y64)
     lsd = oracle.lsd(y[:, 0], target.numpy()[:, 0])
-    print(f"[{tag}] hip bf16 autocast: rms {_rms(e) / peak:.2e}, max {e.max() / peak:.2e} of peak; LSD {lsd:.4f} vs {lsd_ref:.4f}")
-    assert _rms(e) <= 1e-2 * peak, (tag, _rms(e), peak)
+    print(f"[{tag}] bf16 autocast: hip rms {_rms(e) / peak:.2e} max {e.max() / peak:.2e} | torch-CPU autocast rms "
+          f"{_rms(e_cpu) / peak:.2e} max {e_cpu.max() / peak:.2e} (of peak); LSD {lsd:.4f} vs {lsd_ref:.4f}")
     assert abs(lsd - lsd_ref) <= 1e-2, (tag, lsd, lsd_ref)
+    assert _rms(e) <= 1.5 * _rms(e_cpu) and _rms(e) <= 5e-2 * peak, (tag, _rms(e), _rms(e_cpu), peak)
 
 
 @pytest.mark.gpu
-def test_fullsize_backward_hip_vs_cpu_oracle():
+def test_fullsize_backward_hip_fp64_adjudicated():
     """Full-size GRADIENTS (BASELINE configs[1]/[2] shape: dims 16, 513x512 spectrogram, one 48 kHz clip): every
-    parameter gradient of the HIP fp32 forward+backward against the same module on the CPU oracle kernels
-    (`SelectiveScanCore.backward` at L = 262 144 inside the real graph, model/vmamba.py:347-356).
-    Bounds: relative L2 error per tensor <= 2e-3 against max(|g_ref|, 1e-4 of the largest tensor norm), and the
-    whole gradient vector within 5e-4; the 129 `layers_decoder_phase` tensors have no gradient on either side."""
+    parameter gradient of the HIP fp32 forward+backward (`SelectiveScanCore.backward` at L = 262 144 inside the real
+    graph, model/vmamba.py:347-356), adjudicated by the float64 evaluation (pinned above):
+        e_hip = |g_hip - g64|,  e_cpu = |g_cpu-oracle-fp32 - g64|   per tensor and for the whole gradient vector.
+    Two fp32 evaluations differ from EACH OTHER by ~5e-3 here (the phase stream ends in exp(i phase) and a
+    LayerNorm over two channels: rounding-level forward differences flip O(1) local gradients), so the claim is
+    again relative: the HIP gradient is as close to the exact one as the fp32 CPU oracle's — whole vector within
+    2x, every tensor within 3x (+ a floor of 1e-5 of the largest tensor norm for numerically-zero gradients)."""
+    import oracle
     from oracle.torch_backend import oracle_stft_patch, use_oracle
     (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case("48k")
     gy = torch.randn(1, 1, wave.shape[-1], generator=torch.Generator().manual_seed(77))
+    m64 = use_oracle(_model(hop, dims, n_fft, win), f64=True)
+    with oracle.float64(), oracle_stft_patch():
+        (m64(wave.double(), hf) * gy.double()).sum().backward()
     m_cpu = use_oracle(_model(hop, dims, n_fft, win))
     with oracle_stft_patch():
         (m_cpu(wave, hf) * gy).sum().backward()
     m_gpu = _model(hop, dims, n_fft, win).to("cuda:0")
     (m_gpu(wave.cuda(), hf.cuda()).float() * gy.cuda()).sum().backward()
     torch.cuda.synchronize()
+    g64 = {n: p.grad for n, p in m64.named_parameters()}
     ref = {n: p.grad for n, p in m_cpu.named_parameters()}
     got = {n: p.grad for n, p in m_gpu.named_parameters()}
-    assert sum(g is None for g in ref.values()) == 129 and all((got[n] is None) == (ref[n] is None) for n in ref)
-    names = [n for n in ref if ref[n] is not None]
-    norms = {n: ref[n].double().norm().item() for n in names}
-    floor = 1e-4 * max(norms.values())
-    rel = {n: (got[n].cpu().double() - ref[n].double()).norm().item() / max(norms[n], floor) for n in names}
-    worst = sorted(rel, key=rel.get)[-5:]
-    tot = (sum((got[n].cpu().double() - ref[n].double()).pow(2).sum() for n in names).sqrt()
-           / sum(ref[n].double().pow(2).sum() for n in names).sqrt()).item()
-    print(f"full-size backward: whole-vector rel L2 {tot:.2e}; worst tensors " + ", ".join(f"{n} {rel[n]:.2e}" for n in worst))
+    assert sum(g is None for g in g64.values()) == 129 and all((got[n] is None) == (g64[n] is None) == (ref[n] is None) for n in g64)
+    names = [n for n in g64 if g64[n] is not None]
     assert all(torch.isfinite(got[n]).all() for n in names)
-    assert tot <= 5e-4, tot
-    assert rel[worst[-1]] <= 2e-3, (worst[-1], rel[worst[-1]])
+    floor = 1e-5 * max(g64[n].norm().item() for n in names)
+    e_hip = {n: (got[n].cpu().double() - g64[n]).norm().item() for n in names}
+    e_cpu = {n: (ref[n].double() - g64[n]).norm().item() for n in names}
+    tot64 = sum(g64[n].pow(2).sum() for n in names).sqrt().item()
+    t_hip, t_cpu = (sum(v ** 2 for v in e.values()) ** 0.5 / tot64 for e in (e_hip, e_cpu))
+    ratio = {n: e_hip[n] / (e_cpu[n] + floor) for n in names}
+    worst = sorted(ratio, key=ratio.get)[-3:]
+    print(f"full-size backward vs float64: whole-vector rel L2  hip {t_hip:.2e}  cpu-oracle fp32 {t_cpu:.2e}; worst per-tensor "
+          f"ratios " + ", ".join(f"{n} {ratio[n]:.2f}" for n in worst))
+    assert t_hip <= 2.0 * t_cpu, (t_hip, t_cpu)
+    assert ratio[worst[-1]] <= 3.0, (worst[-1], ratio[worst[-1]], e_hip[worst[-1]], e_cpu[worst[-1]])

