@@ -224,6 +224,11 @@ int vmasr_im2col_kx1(const void *x, void *cols, int64_t N, int32_t H, int32_t C,
 int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                      int32_t pad, int32_t dtype, vmasr_stream_t stream);
 
+/* x (n fp32) -> hi = bf16(x), lo = bf16(x - hi): the operands of an error-compensated 3-GEMM bf16 product that
+ * reproduces the fp32 GEMM of the period discriminator's convolutions (model/discriminator.py:21-147) to ~1e-6
+ * relative (vm_asr_amd/csrc/split.hip).  hi, lo: n bf16 each. */
+int vmasr_split_bf16(const float *x, void *hi, void *lo, int64_t n, vmasr_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents
  * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
@@ -260,6 +265,7 @@ enum {
     VMASR_K_SPECTRAL,
     VMASR_K_IM2COL,
     VMASR_K_COL2IM,
+    VMASR_K_SPLIT_BF16,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

@@ -269,3 +269,78 @@ def test_feature_loss_stacked_host_logic():
     g_slow = torch.autograd.grad(slow, gen_stacks)
     for a, b in zip(g_fast, g_slow):
         assert torch.allclose(a.double(), b, rtol=1e-5, atol=1e-9)
+
+
+# ---- fp32 discriminator GEMMs as error-compensated bf16 triples (csrc/split.hip) ---------------------------------
+@pytest.mark.gpu
+def test_split_bf16_kernel_exactness():
+    """x = hi + lo + r with |r| <= 2^-16 |x| (two bf16 roundings), hi == torch's bf16 rounding; odd sizes / offsets."""
+    from vm_asr_amd.discriminator import split_bf16
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 7, 8, 1000, 4096 * 33 + 5):
+        x = (torch.randn(n, generator=g) * torch.exp(3 * torch.randn(n, generator=g))).cuda()
+        hi, lo = split_bf16(x)
+        assert torch.equal(hi, x.to(torch.bfloat16))
+        assert torch.equal(lo, (x - hi.float()).to(torch.bfloat16))
+        r = (x.double() - hi.double() - lo.double()).abs()
+        assert (r <= 2.0 ** -16 * x.double().abs() + 1e-45).all()
+
+
+@pytest.mark.gpu
+def test_batched_linear_bf16x3_matches_fp64():
+    """The 3-GEMM bf16 form of y = cols @ W^T + b, dcols and dW (the MPD's compute-bound layers) against float64:
+    as accurate as the plain fp32 GEMM path to within a small factor, and far inside fp32 parity (1e-4)."""
+    from vm_asr_amd.discriminator import _BatchedLinearFn, _BatchedLinearSplitFn
+    torch.manual_seed(3)
+    n, M, K, N = 2, 2048, 2560, 512
+    cols = torch.randn(n, M, K, device="cuda")
+    W = (torch.randn(n, N, K, device="cuda") / K ** 0.5)
+    b = torch.randn(n, N, device="cuda")
+    gy = torch.randn(n, M, N, device="cuda")
+    c64, W64, b64, g64 = (t.double().cpu() for t in (cols, W, b, gy))
+    y64 = torch.einsum("nmk,nok->nmo", c64, W64) + b64.unsqueeze(1)
+    dc64 = torch.einsum("nmo,nok->nmk", g64, W64)
+    dw64 = torch.einsum("nmo,nmk->nok", g64, c64)
+    errs = {}
+    for tag, fn in (("bf16x3", lambda c, w, bb: _BatchedLinearSplitFn.apply(c, w, bb)),
+                    ("fp32", lambda c, w, bb: _BatchedLinearFn.apply(c, w, bb, torch.float32))):
+        c, w, bb = cols.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
+        y = fn(c, w, bb)
+        y.backward(gy)
+        errs[tag] = [((a.double().cpu() - r).abs().max() / r.abs().max()).item()
+                     for a, r in ((y, y64), (c.grad, dc64), (w.grad, dw64), (bb.grad, g64.sum(1)))]
+    print("bf16x3 vs fp64:", errs["bf16x3"], " fp32 GEMM vs fp64:", errs["fp32"])
+    for e3, e1 in zip(errs["bf16x3"], errs["fp32"]):
+        assert e3 <= 2e-5 and e3 <= max(20 * e1, 5e-6), (errs)
+
+
+@pytest.mark.gpu
+def test_mpd_hidden32_bf16x3_matches_fp32_path(monkeypatch):
+    """The real discriminator (hidden 32: K*N up to 5120 x 1024) on a short signal: scores, feature maps, the input
+    gradient and every weight gradient of the bf16x3 path == the plain fp32 GEMM path to 1e-4 of each tensor's scale."""
+    import copy
+    from vm_asr_amd.discriminator import MultiPeriodDiscriminator
+    torch.manual_seed(5)
+    D = MultiPeriodDiscriminator(hidden=32).cuda().eval()
+    E = copy.deepcopy(D)
+    x0 = 0.3 * torch.randn(2, 1, 8000, device="cuda")
+    res = {}
+    for tag, mod, mode in (("bf16x3", D, "bf16x3"), ("fp32", E, "fp32")):
+        monkeypatch.setenv("VMASR_MPD_GEMM", mode)
+        x = x0.clone().requires_grad_()
+        scores, fmaps = mod.forward_single(x)
+        loss = sum((s ** 2).mean() for s in scores) + sum(f.abs().mean() for fm in fmaps for f in fm)
+        loss.backward()
+        res[tag] = (scores, [f for fm in fmaps for f in fm], x.grad, {k: p.grad for k, p in mod.named_parameters()})
+    (sa, fa, ga, pa), (sb, fb, gb, pb) = res["bf16x3"], res["fp32"]
+
+    def close(a, b, what, tol=1e-4):
+        err, scale = (a.float() - b.float()).abs().max().item(), max(b.float().abs().max().item(), 1e-12)
+        assert err <= tol * scale, (what, err, scale)
+    for i, (a, b) in enumerate(zip(sa, sb)):
+        close(a, b, f"score {i}")
+    for i, (a, b) in enumerate(zip(fa, fb)):
+        close(a, b, f"fmap {i}")
+    close(ga, gb, "d/dx")
+    for k in pb:
+        close(pa[k], pb[k], f"grad {k}")

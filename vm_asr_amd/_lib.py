@@ -66,6 +66,7 @@ SYMBOLS = {
     "vmasr_spectral_power_iter_batched": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i32, ctypes.c_float, c_vp, c_vp]),
     "vmasr_im2col_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_col2im_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_split_bf16": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -127,7 +128,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 29
+K_COUNT = 30
 
 
 def zeros_f32(device, *shapes):

@@ -428,6 +428,77 @@ class _BatchedLinearFn(torch.autograd.Function):
         return dcols, dw, db, None
 
 
+def split_bf16(x):
+    """fp32 tensor -> (hi, lo) bf16 with x = hi + lo up to 2^-17 |x| (vm_asr_amd/csrc/split.hip)."""
+    x = x.contiguous()
+    with torch.cuda.device(x.device):
+        hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        _lib.check(_lib.lib().vmasr_split_bf16(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(),
+                                               _lib.current_stream(x.device)), "split_bf16")
+    return hi, lo
+
+
+def _bmm3(ah, al, bh, bl):
+    """(ah + al) @ (bh + bl) without the lo*lo term: three bf16 MFMA GEMMs, fp32 output and accumulation."""
+    f32 = torch.float32
+    y = torch.bmm(ah, bh, out_dtype=f32)
+    y += torch.bmm(al, bh, out_dtype=f32)
+    y += torch.bmm(ah, bl, out_dtype=f32)
+    return y
+
+
+def _split_mode(K, N, cdt):
+    """Which GEMMs of the fp32 discriminator run as error-compensated bf16 triples: the compute-bound ones
+    (K*N >= 2^20: the 512->1024 and 1024->1024 convolutions, 87 % of the FLOPs); the small-K layers are
+    memory-bound and stay plain fp32 GEMMs.  VMASR_MPD_GEMM=fp32 switches the triples off."""
+    return cdt == torch.float32 and K * N >= (1 << 20) and os.environ.get("VMASR_MPD_GEMM", "bf16x3") == "bf16x3"
+
+
+class _BatchedLinearSplitFn(torch.autograd.Function):
+    """_BatchedLinearFn for fp32 operands on the bf16 matrix cores: every GEMM (y, dcols, dW) is the
+    error-compensated triple hi*hi + lo*hi + hi*lo of bf16 splits (csrc/split.hip), accumulated in fp32 —
+    the fp32 result to ~1e-6 relative at 16/3 of the fp32 MFMA rate."""
+
+    @staticmethod
+    def forward(ctx, cols, weight, bias):
+        ch, cl = split_bf16(cols)                                        # (n, M, K)
+        w = weight.detach().float()
+        wh, wl = split_bf16(w)                                           # (n, N, K): operand of dcols = gy @ W
+        wth, wtl = split_bf16(w.transpose(1, 2).contiguous())            # (n, K, N): contiguous B operand (see _BatchedLinearFn)
+        y = _bmm3(ch, cl, wth, wtl).add_(bias.detach().float().unsqueeze(1))
+        ctx.save_for_backward(ch, cl, wh, wl)
+        ctx.meta = (weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ch, cl, wh, wl = ctx.saved_tensors
+        wdt, bdt = ctx.meta
+        gy = gy.float().contiguous()
+        n, M, N = gy.shape
+        K = ch.shape[2]
+        gh, gl = split_bf16(gy)
+        dcols = _bmm3(gh, gl, wh, wl) if ctx.needs_input_grad[0] else None
+        if _PHASE["skip_weight_grads"]:
+            return dcols, None, None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            tiles = n * -(-N // 64) * -(-K // 64)
+            want = min(M // 2048, max(1, 512 // tiles))
+            S = max(d for d in range(1, max(1, want) + 1) if (M // 256) % d == 0) if M % 256 == 0 else 1
+            v = (lambda t: t.view(n * S, M // S, t.shape[2])) if S > 1 else (lambda t: t)
+            ght, glt = v(gh).transpose(1, 2), v(gl).transpose(1, 2)
+            f32 = torch.float32
+            part = torch.bmm(ght, v(ch), out_dtype=f32)
+            part += torch.bmm(glt, v(ch), out_dtype=f32)
+            part += torch.bmm(ght, v(cl), out_dtype=f32)
+            dw = (part.view(n, S, N, K).sum(1) if S > 1 else part).to(wdt)
+        if ctx.needs_input_grad[2]:
+            db = gy.sum(1).to(bdt)
+        return dcols, dw, db
+
+
 class _UnstackRowsFn(torch.autograd.Function):
     """(n, rows, N) -> n views y[i, :M_i]; the backward assembles the stacked gradient with one copy per slot
     (autograd's own select/slice backward would zero-fill a full-size tensor per slot)."""
@@ -566,7 +637,10 @@ class MultiPeriodDiscriminator(nn.Module):
             ws = [(l.weight.detach(), l.bias.detach()) if detach_weights else (l.weight, l.bias) for l in layers]
             W = torch.stack([w[:, :, :, 0] for w, _ in ws])                         # (n, Cout, Cin, k)
             W = W.permute(0, 1, 3, 2).reshape(n, W.shape[1], -1)                     # (tap, c) column order
-            y = _BatchedLinearFn.apply(cols, W, torch.stack([b for _, b in ws]), cdt)
+            if _split_mode(W.shape[2], W.shape[1], cdt):
+                y = _BatchedLinearSplitFn.apply(cols, W, torch.stack([b for _, b in ws]))
+            else:
+                y = _BatchedLinearFn.apply(cols, W, torch.stack([b for _, b in ws]), cdt)
             if li < len(discs[0].layers):
                 y = F.gelu(y)
             outs = _UnstackRowsFn.apply(y, *Ms)
