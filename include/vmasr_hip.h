@@ -224,6 +224,33 @@ int vmasr_im2col_kx1(const void *x, void *cols, int64_t N, int32_t H, int32_t C,
 int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                      int32_t pad, int32_t dtype, vmasr_stream_t stream);
 
+/* ---- fused SS2D core (vm_asr_amd/csrc/ss2d.hip) ---------------------------------------------------------
+ * One operator for  y = CrossMerge(selective_scan(CrossScan(x), dt_proj(x_proj(.)), A, B, C, D, dt_bias, softplus))
+ * of SS2D.forward_corev2 (model/vmamba.py:1472-1497; kernels: model/csm_triton.py:7-154,
+ * cus/selective_scan_{fwd,bwd}_kernel.cuh) and its backward, for d_state 1, dt_rank 1, d_inner in {2,4,8,16,32},
+ * H*W a multiple of 256 (vmasr_ss2d_supported).  All buffers are caller-owned device memory:
+ *   x (B,D,H,W) `dtype`;  Wx (4,3,D) = x_proj_weight rows [dt, B, C];  Wdt (4,D) = dt_projs_weight;  dtb (4,D);
+ *   Alog (4D) = A_logs (the operator applies A = -exp(Alog));  Ds (4D);            all weights fp32
+ *   xT (B,D,W,H) `dtype` scratch (kept for the backward);  state (B,4D,H*W/256,2) fp32 (kept for the backward);
+ *   out02, out13 (B,D,H*W) fp32 scratch;  y (B,D,H*W) fp32 = the merged output.
+ * backward: dy (B,D,H*W) fp32 in, dyT / adj (like state) / part (vmasr_ss2d_part_floats) scratch,
+ *   dx (B,D,H,W) `dtype`, dWx (4,3,D), dWdt (4,D), ddtb (4,D), dAlog (4D), dDs (4D) fp32 out (plain stores). */
+typedef struct vmasr_ss2d_params {
+    int32_t B, D, H, W, dtype;
+    const void *x;
+    void *xT;
+    const float *Wx, *Wdt, *dtb, *Alog, *Ds;
+    float *state, *out02, *out13, *y;
+    const float *dy;
+    float *dyT, *adj, *part;
+    void *dx;
+    float *dWx, *dWdt, *ddtb, *dAlog, *dDs;
+} vmasr_ss2d_params;
+int vmasr_ss2d_supported(int32_t d_state, int32_t dt_rank, int32_t d_inner, int32_t H, int32_t W);
+size_t vmasr_ss2d_part_floats(int32_t B, int32_t D, int32_t H, int32_t W);
+int vmasr_ss2d_fwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
+int vmasr_ss2d_bwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
+
 /* x (n fp32) -> hi = bf16(x), lo = bf16(x - hi): the operands of an error-compensated 3-GEMM bf16 product that
  * reproduces the fp32 GEMM of the period discriminator's convolutions (model/discriminator.py:21-147) to ~1e-6
  * relative (vm_asr_amd/csrc/split.hip).  hi, lo: n bf16 each. */
@@ -266,6 +293,13 @@ enum {
     VMASR_K_IM2COL,
     VMASR_K_COL2IM,
     VMASR_K_SPLIT_BF16,
+    VMASR_K_SS2D_TRANSPOSE,     /* fused SS2D core: x -> x^T, dy -> dy^T                 */
+    VMASR_K_SS2D_FWD_AGG,       /* x_proj + dt_proj + per-tile aggregates, 2 directions  */
+    VMASR_K_SS2D_CARRY,         /* scan of the aggregates / adjoint carries / reduce     */
+    VMASR_K_SS2D_FWD_APPLY,     /* x_proj + dt_proj + scan of both directions + add      */
+    VMASR_K_SS2D_MERGE,         /* pair outputs: a + transpose(b)                        */
+    VMASR_K_SS2D_BWD_AGG,
+    VMASR_K_SS2D_BWD_APPLY,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

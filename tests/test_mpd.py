@@ -315,32 +315,41 @@ def test_batched_linear_bf16x3_matches_fp64():
 
 
 @pytest.mark.gpu
-def test_mpd_hidden32_bf16x3_matches_fp32_path(monkeypatch):
-    """The real discriminator (hidden 32: K*N up to 5120 x 1024) on a short signal: scores, feature maps, the input
-    gradient and every weight gradient of the bf16x3 path == the plain fp32 GEMM path to 1e-4 of each tensor's scale."""
+def test_mpd_hidden32_bf16x3_float64_adjudicated(monkeypatch):
+    """The real discriminator (hidden 32: K*N up to 5120 x 1024) on a short signal.  Scores, feature maps, the input
+    gradient and every weight gradient of the bf16x3 path and of the plain fp32-GEMM path are compared with a
+    float64 evaluation (the same module on the CPU in double, plain convolutions):
+      * forward quantities of the bf16x3 path within 1e-4 of each tensor's scale (north_star's fp32 bound);
+      * every tensor: bf16x3's distance from float64 <= 3x the fp32 path's own distance (+ 2e-6 of scale): the
+        triple-GEMM is fp32-grade, what differs between two fp32-grade evaluations of a six-layer GELU network
+        (measured up to 1.1e-4 on one bias gradient) is rounding-order noise, the same for both."""
     import copy
     from vm_asr_amd.discriminator import MultiPeriodDiscriminator
     torch.manual_seed(5)
-    D = MultiPeriodDiscriminator(hidden=32).cuda().eval()
-    E = copy.deepcopy(D)
-    x0 = 0.3 * torch.randn(2, 1, 8000, device="cuda")
-    res = {}
-    for tag, mod, mode in (("bf16x3", D, "bf16x3"), ("fp32", E, "fp32")):
-        monkeypatch.setenv("VMASR_MPD_GEMM", mode)
-        x = x0.clone().requires_grad_()
+    D = MultiPeriodDiscriminator(hidden=32).eval()
+    x0 = 0.3 * torch.randn(2, 1, 8000)
+
+    def run(mod, x, dev):
+        x = x.clone().requires_grad_()
         scores, fmaps = mod.forward_single(x)
         loss = sum((s ** 2).mean() for s in scores) + sum(f.abs().mean() for fm in fmaps for f in fm)
         loss.backward()
-        res[tag] = (scores, [f for fm in fmaps for f in fm], x.grad, {k: p.grad for k, p in mod.named_parameters()})
-    (sa, fa, ga, pa), (sb, fb, gb, pb) = res["bf16x3"], res["fp32"]
-
-    def close(a, b, what, tol=1e-4):
-        err, scale = (a.float() - b.float()).abs().max().item(), max(b.float().abs().max().item(), 1e-12)
-        assert err <= tol * scale, (what, err, scale)
-    for i, (a, b) in enumerate(zip(sa, sb)):
-        close(a, b, f"score {i}")
-    for i, (a, b) in enumerate(zip(fa, fb)):
-        close(a, b, f"fmap {i}")
-    close(ga, gb, "d/dx")
-    for k in pb:
-        close(pa[k], pb[k], f"grad {k}")
+        out = {f"score{i}": _score_ref_order(s, i, dev) for i, s in enumerate(scores)}
+        out.update({f"fmap{i}_{j}": _fmap_ref_layout(f, dev) for i, fm in enumerate(fmaps) for j, f in enumerate(fm)})
+        out["d/dx"] = x.grad
+        out.update({f"grad {k}": p.grad for k, p in mod.named_parameters()})
+        return {k: v.detach().double().cpu() for k, v in out.items()}
+    ref = run(copy.deepcopy(D).double(), x0.double(), "cpu")
+    res = {}
+    for mode in ("bf16x3", "fp32"):
+        monkeypatch.setenv("VMASR_MPD_GEMM", mode)
+        res[mode] = run(copy.deepcopy(D).cuda(), x0.cuda(), "cuda")
+    worst = (0.0, "")
+    for k, r in ref.items():
+        scale = max(r.abs().max().item(), 1e-12)
+        e3, e1 = ((res[m][k] - r).abs().max().item() / scale for m in ("bf16x3", "fp32"))
+        worst = max(worst, (e3 / (e1 + 2e-6 / 3), k))
+        if not k.startswith(("grad", "d/dx")):
+            assert e3 <= 1e-4, (k, e3)
+        assert e3 <= 3 * e1 + 2e-6, (k, e3, e1)
+    print("bf16x3 vs fp32 path, worst error ratio against float64:", worst)

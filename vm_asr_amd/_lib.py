@@ -41,6 +41,13 @@ class SScanBwdParams(ctypes.Structure):
     )
 
 
+class SS2DParams(ctypes.Structure):
+    """POD mirror of vmasr_ss2d_params."""
+    _fields_ = ([(n, c_i32) for n in ("B", "D", "H", "W", "dtype")]
+                + [(n, c_vp) for n in ("x", "xT", "Wx", "Wdt", "dtb", "Alog", "Ds", "state", "out02", "out13", "y",
+                                       "dy", "dyT", "adj", "part", "dx", "dWx", "dWdt", "ddtb", "dAlog", "dDs")])
+
+
 # name -> (restype, argtypes); every symbol declared in include/vmasr_hip.h
 SYMBOLS = {
     "vmasr_abi_version": (ctypes.c_int, []),
@@ -67,6 +74,10 @@ SYMBOLS = {
     "vmasr_im2col_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_col2im_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_split_bf16": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "vmasr_ss2d_supported": (ctypes.c_int, [c_i32] * 5),
+    "vmasr_ss2d_part_floats": (c_sz, [c_i32] * 4),
+    "vmasr_ss2d_fwd": (ctypes.c_int, [ctypes.POINTER(SS2DParams), c_vp]),
+    "vmasr_ss2d_bwd": (ctypes.c_int, [ctypes.POINTER(SS2DParams), c_vp]),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -128,7 +139,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 30
+K_COUNT = 37
 
 
 def zeros_f32(device, *shapes):

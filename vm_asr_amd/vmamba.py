@@ -30,6 +30,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .csm import CrossMergeHIP, CrossScanF32, CrossScanHIP
+from . import ss2d_core as _ss2d
 from . import xproj as _xproj
 from .dwconv import dwconv3x3_silu
 from .layernorm import LayerNorm
@@ -275,8 +276,14 @@ class SS2D(nn.Module):
         K, D, R = dt_projs_weight.shape
         L = H * W
 
-        if (x.is_cuda and force_fp32 and not no_einsum and CrossScan is CrossScanHIP and SelectiveScan is SelectiveScanCore
-                and _xproj.supported(N, R, D) and D <= 32):
+        hip_default = (x.is_cuda and force_fp32 and not no_einsum and CrossScan is CrossScanHIP
+                       and SelectiveScan is SelectiveScanCore and CrossMerge is CrossMergeHIP)
+        if hip_default and delta_softplus and K == 4 and _ss2d.supported(N, R, D, H, W):
+            # the whole core (cross-scan, x_proj, dt_proj, 4 scans, cross-merge) as one fused operator: the
+            # high-resolution stages (d_state 1, dt_rank 1, d_inner <= 32) — csrc/ss2d.hip
+            y = _ss2d.ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+            return self._merge_norm(y, x, B, H, W, to_dtype)
+        if (hip_default and _xproj.supported(N, R, D) and D <= 32):
             # (D <= 32: the map is parallel over positions only; the deep stages have few positions and
             #  D = 64..256 rows, where the batched-GEMM einsums below are the better fit)
             # HIP fast path: the scan streams are produced in fp32 directly and x_proj/dt_proj are one
