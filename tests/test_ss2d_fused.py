@@ -116,7 +116,8 @@ def test_fused_core_equals_unfused_hip_chain_at_benchmark_shapes(shape, monkeypa
                                                      "out_norm.weight", "out_norm.bias")]
     for i, (a, b) in enumerate(zip(res["1"], res["0"])):
         err, scale = (a - b).abs().max().item(), max(b.abs().max().item(), 1e-12)
-        assert err <= 2e-4 * scale, (shape, i, err, scale)
+        # y, dx: 2e-4; parameter gradients are fp32 sums over B*L = 65 k .. 1 M positions in different orders: 1e-3
+        assert err <= (2e-4 if i < 2 else 1e-3) * scale, (shape, i, err, scale)
 
 
 @pytest.mark.gpu
