@@ -221,6 +221,9 @@ int vmasr_spectral_power_iter_batched(const vmasr_spectral_item *items, int32_t 
  * stacked GEMM operand).  Contiguous tensors of `dtype` (VMASR_F32/F16/BF16). */
 int vmasr_im2col_kx1(const void *x, void *cols, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                      int32_t pad, int64_t rows_out, int32_t dtype, vmasr_stream_t stream);
+/* im2col of fp32 x with the bf16 hi/lo split (vmasr_split_bf16) fused into the store: hi, lo (rows_out, k*C) bf16 */
+int vmasr_im2col_kx1_split(const float *x, void *hi, void *lo, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
+                           int32_t pad, int64_t rows_out, vmasr_stream_t stream);
 int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                      int32_t pad, int32_t dtype, vmasr_stream_t stream);
 

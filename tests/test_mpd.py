@@ -353,3 +353,37 @@ def test_mpd_hidden32_bf16x3_float64_adjudicated(monkeypatch):
             assert e3 <= 1e-4, (k, e3)
         assert e3 <= 3 * e1 + 2e-6, (k, e3, e1)
     print("bf16x3 vs fp32 path, worst error ratio against float64:", worst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stride,k,pad", [(3, 5, 2), (1, 5, 2)])
+def test_stacked_conv_split_matches_float64_conv(stride, k, pad):
+    """_StackedConvSplitFn (im2col with the bf16 split fused into its store, 3-GEMM product, column gradient as one
+    GEMM over the concatenated contraction, col2im) == the (k,1) convolution in float64: y, dx, dW, db."""
+    from vm_asr_amd.discriminator import _StackedConvSplitFn, _UnstackRowsFn, _round_up
+    torch.manual_seed(8)
+    C, N, B = 128, 512, 2
+    xs = [torch.randn(B, p, h, C, device="cuda") for p, h in ((2, 301), (3, 200))]
+    W = torch.randn(2, N, k * C, device="cuda") / (k * C) ** 0.5
+    b = torch.randn(2, N, device="cuda")
+    H1 = [(x.shape[2] + 2 * pad - k) // stride + 1 for x in xs]
+    Ms = [B * x.shape[1] * h for x, h in zip(xs, H1)]
+    xr = [x.clone().requires_grad_() for x in xs]
+    Wr, br = W.clone().requires_grad_(), b.clone().requires_grad_()
+    y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), Wr, br, *xr)
+    outs = _UnstackRowsFn.apply(y, *Ms)
+    gys = [torch.randn_like(o) for o in outs]
+    sum((o * g).sum() for o, g in zip(outs, gys)).backward()
+    for i, x in enumerate(xs):
+        x64 = x.double().cpu().permute(0, 3, 2, 1).requires_grad_()                      # (B, C, H, P)
+        w64 = W[i].double().cpu().view(N, k, C).permute(0, 2, 1).unsqueeze(-1).requires_grad_()   # (N, C, k, 1)
+        b64 = b[i].double().cpu().requires_grad_()
+        ref = torch.nn.functional.conv2d(x64, w64, b64, (stride, 1), (pad, 0))           # (B, N, H1, P)
+        g64 = gys[i].double().cpu().view(B, x.shape[1], H1[i], N).permute(0, 3, 2, 1)
+        ref.backward(g64)
+        close = lambda a, r, what: (_ for _ in ()).throw(AssertionError((what, (a - r).abs().max().item(), r.abs().max().item()))) \
+            if (a - r).abs().max() > 2e-5 * r.abs().max() else None                      # noqa: E731
+        close(outs[i].double().cpu().view(B, x.shape[1], H1[i], N).permute(0, 3, 2, 1), ref.detach(), "y")
+        close(xr[i].grad.double().cpu().permute(0, 3, 2, 1), x64.grad, "dx")
+        close(Wr.grad[i].double().cpu().view(N, k, C).permute(0, 2, 1).unsqueeze(-1), w64.grad, "dW")
+        close(br.grad[i].double().cpu(), b64.grad, "db")

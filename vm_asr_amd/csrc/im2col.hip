@@ -45,6 +45,35 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T *__restrict__ x, T 
     }
 }
 
+// im2col of fp32 input with the error-compensated bf16 split of split.hip fused into the store: hi = bf16(v),
+// lo = bf16(v - hi) go to two (rows_out, k*C) bf16 operands (4 B written per element instead of 4 B written + 4 B
+// re-read + 4 B written by im2col followed by vmasr_split_bf16).
+__global__ __launch_bounds__(256) void im2col_split_kernel(const float *__restrict__ x, bf16_t *__restrict__ hi,
+                                                           bf16_t *__restrict__ lo, const ColGeom g) {
+    const int cv = g.C / 4;
+    const long total = g.rows_out * g.k * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        long r = i / cv;
+        const int j = (int)(r % g.k);
+        r /= g.k;
+        const int h1 = (int)(r % g.H1);
+        const int n = (int)(r / g.H1);
+        const int h = h1 * g.stride + j - g.pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < g.N && h >= 0 && h < g.H) v = reinterpret_cast<const float4 *>(x + ((size_t)n * g.H + h) * g.C)[c];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        union { uint2 raw; bf16_t b[4]; } H, L;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            H.b[q] = (bf16_t)e[q];
+            L.b[q] = (bf16_t)(e[q] - (float)H.b[q]);
+        }
+        reinterpret_cast<uint2 *>(hi)[i] = H.raw;
+        reinterpret_cast<uint2 *>(lo)[i] = L.raw;
+    }
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void col2im_kernel(const T *__restrict__ dcols, T *__restrict__ dx, const ColGeom g) {
     const int cv = g.C / V;
@@ -128,6 +157,26 @@ using namespace vmasr;
 VMASR_EXPORT int vmasr_im2col_kx1(const void *x, void *cols, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                                   int32_t pad, int64_t rows_out, int32_t dtype, vmasr_stream_t stream) {
     return run(true, x, cols, N, H, C, k, stride, pad, rows_out, dtype, static_cast<hipStream_t>(stream));
+}
+
+VMASR_EXPORT int vmasr_im2col_kx1_split(const float *x, void *hi, void *lo, int64_t N, int32_t H, int32_t C, int32_t k,
+                                        int32_t stride, int32_t pad, int64_t rows_out, vmasr_stream_t stream) {
+    VMASR_REQUIRE(x && hi && lo, VMASR_EINVAL, "im2col_kx1_split: null tensor");
+    VMASR_REQUIRE(N > 0 && H > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && H + 2 * pad >= k, VMASR_EINVAL,
+                  "im2col_kx1_split: bad geometry (N=%ld H=%d C=%d k=%d stride=%d pad=%d)", (long)N, H, C, k, stride, pad);
+    VMASR_REQUIRE(N <= 0x7fffffff, VMASR_EINVAL, "im2col_kx1_split: too many sequences");
+    VMASR_REQUIRE(C % 4 == 0 && aligned_to(x, 16) && aligned_to(hi, 8) && aligned_to(lo, 8), VMASR_EINVAL,
+                  "im2col_kx1_split: needs C %% 4 == 0 and aligned operands");
+    const int H1 = (H + 2 * pad - k) / stride + 1;
+    VMASR_REQUIRE(rows_out == 0 || rows_out >= N * H1, VMASR_EINVAL, "im2col_kx1_split: rows_out smaller than N*H1");
+    const ColGeom g{(int)N, H, C, k, stride, pad, H1, rows_out ? (long)rows_out : (long)N * H1};
+    const long total = g.rows_out * k * (C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 64);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double bytes = (double)N * H * C * 4 + (double)g.rows_out * k * C * 4;
+    VMASR_LAUNCH(VMASR_K_IM2COL, bytes, im2col_split_kernel, dim3(blocks), dim3(256), 0, st, x, static_cast<bf16_t *>(hi),
+                 static_cast<bf16_t *>(lo), g);
+    return check_launch("im2col_kx1_split");
 }
 
 VMASR_EXPORT int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,

@@ -450,9 +450,9 @@ def _bmm3(ah, al, bh, bl):
 
 def _split_mode(K, N, cdt):
     """Which GEMMs of the fp32 discriminator run as error-compensated bf16 triples: the compute-bound ones
-    (K*N >= 2^20: the 512->1024 and 1024->1024 convolutions, 87 % of the FLOPs); the small-K layers are
-    memory-bound and stay plain fp32 GEMMs.  VMASR_MPD_GEMM=fp32 switches the triples off."""
-    return cdt == torch.float32 and K * N >= (1 << 20) and os.environ.get("VMASR_MPD_GEMM", "bf16x3") == "bf16x3"
+    (K*N >= 2^18: the 128->512, 512->1024 and 1024->1024 convolutions, 98 % of the FLOPs); the two small-K layers
+    are memory-bound and stay plain fp32 GEMMs.  VMASR_MPD_GEMM=fp32 switches the triples off."""
+    return cdt == torch.float32 and K * N >= (1 << 18) and os.environ.get("VMASR_MPD_GEMM", "bf16x3") == "bf16x3"
 
 
 class _BatchedLinearSplitFn(torch.autograd.Function):
@@ -497,6 +497,71 @@ class _BatchedLinearSplitFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             db = gy.sum(1).to(bdt)
         return dcols, dw, db
+
+
+class _StackedConvSplitFn(torch.autograd.Function):
+    """_StackedIm2ColFn + _BatchedLinearSplitFn as one function for fp32 inputs: the im2col kernel writes the bf16
+    hi / lo operands directly (no fp32 column tensor, no separate split pass); the column gradient is ONE GEMM over
+    the concatenated contraction [gh | gl | gh] @ [wh; wh; wl] (the three products accumulate inside the GEMM
+    instead of two read-modify-write passes over the (rows, k*C) gradient), then col2im per slot."""
+
+    @staticmethod
+    def forward(ctx, k, stride, pad, rows, weight, bias, *xs):
+        C, dev = xs[0].shape[3], xs[0].device
+        n, K = len(xs), k * C
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            ch = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
+            cl = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
+            for i, x in enumerate(xs):
+                B, P, H, _ = x.shape
+                xc = x.float().contiguous()
+                _lib.check(lib.vmasr_im2col_kx1_split(xc.data_ptr(), ch[i].data_ptr(), cl[i].data_ptr(), B * P, H, C, k, stride,
+                                                      pad, rows, _lib.current_stream(dev)), "im2col_kx1_split")
+        w = weight.detach().float()
+        wh, wl = split_bf16(w)                                           # (n, N, K)
+        wth, wtl = split_bf16(w.transpose(1, 2).contiguous())            # (n, K, N): contiguous B operand
+        y = _bmm3(ch, cl, wth, wtl).add_(bias.detach().float().unsqueeze(1))
+        ctx.save_for_backward(ch, cl, torch.cat((wh, wh, wl), dim=1))    # (n, 3N, K)
+        ctx.geom = (k, stride, pad, [tuple(x.shape) for x in xs], weight.dtype, bias.dtype, [x.dtype for x in xs])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ch, cl, wcat = ctx.saved_tensors
+        k, stride, pad, shapes, wdt, bdt, xdts = ctx.geom
+        gy = gy.float().contiguous()
+        n, M, N = gy.shape
+        K = ch.shape[2]
+        gh, gl = split_bf16(gy)
+        lib = _lib.lib()
+        dxs = [None] * len(shapes)
+        if any(ctx.needs_input_grad[6:]):
+            dcols = torch.bmm(torch.cat((gh, gl, gh), dim=2), wcat, out_dtype=torch.float32)
+            with torch.cuda.device(gy.device):
+                for i, (B, P, H, C) in enumerate(shapes):
+                    if not ctx.needs_input_grad[6 + i]:
+                        continue
+                    dx = torch.empty((B, P, H, C), dtype=torch.float32, device=gy.device)
+                    _lib.check(lib.vmasr_col2im_kx1(dcols[i].data_ptr(), dx.data_ptr(), B * P, H, C, k, stride, pad, _lib.F32,
+                                                    _lib.current_stream(gy.device)), "col2im_kx1")
+                    dxs[i] = dx.to(xdts[i])
+        dw = db = None
+        if not _PHASE["skip_weight_grads"]:
+            if ctx.needs_input_grad[4]:
+                tiles = n * -(-N // 64) * -(-K // 64)
+                want = min(M // 2048, max(1, 512 // tiles))
+                S = max(d for d in range(1, max(1, want) + 1) if (M // 256) % d == 0) if M % 256 == 0 else 1
+                v = (lambda t: t.view(n * S, M // S, t.shape[2])) if S > 1 else (lambda t: t)
+                ght, glt = v(gh).transpose(1, 2), v(gl).transpose(1, 2)
+                f32 = torch.float32
+                part = torch.bmm(ght, v(ch), out_dtype=f32)
+                part += torch.bmm(glt, v(ch), out_dtype=f32)
+                part += torch.bmm(ght, v(cl), out_dtype=f32)
+                dw = (part.view(n, S, N, K).sum(1) if S > 1 else part).to(wdt)
+            if ctx.needs_input_grad[5]:
+                db = gy.sum(1).to(bdt)
+        return (None, None, None, None, dw, db, *dxs)
 
 
 class _UnstackRowsFn(torch.autograd.Function):
@@ -633,13 +698,13 @@ class MultiPeriodDiscriminator(nn.Module):
             P = [c.shape[1] for c in cur]
             H1 = [(c.shape[2] + 2 * pad - k) // stride + 1 for c in cur]
             Ms = [B * p * h for p, h in zip(P, H1)]
-            cols = _StackedIm2ColFn.apply(k, stride, pad, _round_up(max(Ms), 256), *cur)
             ws = [(l.weight.detach(), l.bias.detach()) if detach_weights else (l.weight, l.bias) for l in layers]
             W = torch.stack([w[:, :, :, 0] for w, _ in ws])                         # (n, Cout, Cin, k)
             W = W.permute(0, 1, 3, 2).reshape(n, W.shape[1], -1)                     # (tap, c) column order
-            if _split_mode(W.shape[2], W.shape[1], cdt):
-                y = _BatchedLinearSplitFn.apply(cols, W, torch.stack([b for _, b in ws]))
+            if _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
+                y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), W, torch.stack([b for _, b in ws]), *cur)
             else:
+                cols = _StackedIm2ColFn.apply(k, stride, pad, _round_up(max(Ms), 256), *cur)
                 y = _BatchedLinearFn.apply(cols, W, torch.stack([b for _, b in ws]), cdt)
             if li < len(discs[0].layers):
                 y = F.gelu(y)
