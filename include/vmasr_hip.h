@@ -227,6 +227,14 @@ int vmasr_im2col_kx1_split(const float *x, void *hi, void *lo, int64_t N, int32_
 int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                      int32_t pad, int32_t dtype, vmasr_stream_t stream);
 
+/* Epilogues of the period discriminator's GEMMs (model/discriminator.py:100-104: conv -> GELU), slots x (M, N) fp32:
+ *   vmasr_bias_gelu_fwd : acc += bias[slot, col] in place (the pre-activation), act = GELU(acc)   (exact erf form)
+ *   vmasr_gelu_bwd_split: gx = g * GELU'(pre) (pre == NULL: gx = g), written only as its bf16 split (hi, lo);
+ *                         db[slot, col] += sum over rows of gx (db zero-initialised by the caller; may be NULL) */
+int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots, int64_t M, int32_t N, vmasr_stream_t stream);
+int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, float *db, int32_t slots, int64_t M, int32_t N,
+                         vmasr_stream_t stream);
+
 /* ---- fused SS2D core (vm_asr_amd/csrc/ss2d.hip) ---------------------------------------------------------
  * One operator for  y = CrossMerge(selective_scan(CrossScan(x), dt_proj(x_proj(.)), A, B, C, D, dt_bias, softplus))
  * of SS2D.forward_corev2 (model/vmamba.py:1472-1497; kernels: model/csm_triton.py:7-154,
@@ -296,6 +304,7 @@ enum {
     VMASR_K_IM2COL,
     VMASR_K_COL2IM,
     VMASR_K_SPLIT_BF16,
+    VMASR_K_BIAS_GELU,          /* discriminator GEMM epilogues (bias + GELU; GELU' + split + bias gradient) */
     VMASR_K_SS2D_TRANSPOSE,     /* fused SS2D core: x -> x^T, dy -> dy^T                 */
     VMASR_K_SS2D_FWD_AGG,       /* x_proj + dt_proj + per-tile aggregates, 2 directions  */
     VMASR_K_SS2D_CARRY,         /* scan of the aggregates / adjoint carries / reduce     */

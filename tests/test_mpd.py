@@ -356,8 +356,8 @@ def test_mpd_hidden32_bf16x3_float64_adjudicated(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stride,k,pad", [(3, 5, 2), (1, 5, 2)])
-def test_stacked_conv_split_matches_float64_conv(stride, k, pad):
+@pytest.mark.parametrize("stride,k,pad,act", [(3, 5, 2, True), (1, 5, 2, True), (1, 5, 2, False)])
+def test_stacked_conv_split_matches_float64_conv(stride, k, pad, act):
     """_StackedConvSplitFn (im2col with the bf16 split fused into its store, 3-GEMM product, column gradient as one
     GEMM over the concatenated contraction, col2im) == the (k,1) convolution in float64: y, dx, dW, db."""
     from vm_asr_amd.discriminator import _StackedConvSplitFn, _UnstackRowsFn, _round_up
@@ -370,7 +370,7 @@ def test_stacked_conv_split_matches_float64_conv(stride, k, pad):
     Ms = [B * x.shape[1] * h for x, h in zip(xs, H1)]
     xr = [x.clone().requires_grad_() for x in xs]
     Wr, br = W.clone().requires_grad_(), b.clone().requires_grad_()
-    y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), Wr, br, *xr)
+    y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, Wr, br, *xr)
     outs = _UnstackRowsFn.apply(y, *Ms)
     gys = [torch.randn_like(o) for o in outs]
     sum((o * g).sum() for o, g in zip(outs, gys)).backward()
@@ -379,6 +379,8 @@ def test_stacked_conv_split_matches_float64_conv(stride, k, pad):
         w64 = W[i].double().cpu().view(N, k, C).permute(0, 2, 1).unsqueeze(-1).requires_grad_()   # (N, C, k, 1)
         b64 = b[i].double().cpu().requires_grad_()
         ref = torch.nn.functional.conv2d(x64, w64, b64, (stride, 1), (pad, 0))           # (B, N, H1, P)
+        if act:
+            ref = torch.nn.functional.gelu(ref)                                          # fused bias + GELU epilogue
         g64 = gys[i].double().cpu().view(B, x.shape[1], H1[i], N).permute(0, 3, 2, 1)
         ref.backward(g64)
         close = lambda a, r, what: (_ for _ in ()).throw(AssertionError((what, (a - r).abs().max().item(), r.abs().max().item()))) \

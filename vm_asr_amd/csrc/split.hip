@@ -55,3 +55,99 @@ VMASR_EXPORT int vmasr_split_bf16(const float *x, void *hi, void *lo, int64_t n,
                  static_cast<bf16_t *>(hi), static_cast<bf16_t *>(lo), n8, (size_t)n);
     return check_launch("split_bf16");
 }
+
+// ---- bias + GELU epilogue of the discriminator's GEMMs, and its backward fused with the bf16 split -------------------
+// forward : pre = acc + bias[col] (in place), act = GELU(pre)  (exact erf form, torch's default)     r 4, w 8 B/elt
+// backward: gx = g * GELU'(pre) -> (hi, lo) bf16 split of gx (the operands of the dcols / dW GEMM triples) and
+//           db[col] += sum_rows gx.  gx itself is never written: r 8, w 4 B/elt instead of GELU-backward (r 8, w 4)
+//           + bias-gradient reduction (r 4) + split (r 4, w 4).
+namespace vmasr {
+namespace {
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// grid: (row chunks, slots); block 256 threads; each thread owns 4 consecutive columns of one or more rows per pass
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(float *__restrict__ acc, const float *__restrict__ bias,
+                                                            float *__restrict__ act, const long M, const int N) {
+    const int slot = blockIdx.y;
+    const int nv = N / 4;                                   // float4 per row
+    const long total = M * nv;
+    float *a = acc + (size_t)slot * M * N, *o = act + (size_t)slot * M * N;
+    const float *b = bias + (size_t)slot * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv);
+        float4 v = reinterpret_cast<float4 *>(a)[i];
+        const float4 bb = reinterpret_cast<const float4 *>(b)[c];
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        reinterpret_cast<float4 *>(a)[i] = v;
+        reinterpret_cast<float4 *>(o)[i] = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+    }
+}
+
+constexpr int kGbRows = 128;   // rows per workgroup of the backward (column sums leave as one atomic per column and workgroup)
+
+__global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__restrict__ pre, const float *__restrict__ g,
+                                                             bf16_t *__restrict__ hi, bf16_t *__restrict__ lo,
+                                                             float *__restrict__ db, const long M, const int N, const int has_act) {
+    const int slot = blockIdx.y;
+    const int nv = N / 4;
+    const int rows_per_pass = 256 / nv > 0 ? 256 / nv : 1;   // nv <= 256 (N <= 1024)
+    const int c = threadIdx.x % nv, rr = threadIdx.x / nv;
+    const size_t base = (size_t)slot * M * N;
+    const long r0 = (long)blockIdx.x * kGbRows;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rr < rows_per_pass) {
+        for (long r = r0 + rr; r < r0 + kGbRows && r < M; r += rows_per_pass) {
+            const size_t i = (base + (size_t)r * N) / 4 + c;
+            float4 gv = reinterpret_cast<const float4 *>(g)[i];
+            if (has_act) {
+                const float4 p = reinterpret_cast<const float4 *>(pre)[i];
+                gv.x *= gelu_grad_f(p.x); gv.y *= gelu_grad_f(p.y); gv.z *= gelu_grad_f(p.z); gv.w *= gelu_grad_f(p.w);
+            }
+            s.x += gv.x; s.y += gv.y; s.z += gv.z; s.w += gv.w;
+            const float e[4] = {gv.x, gv.y, gv.z, gv.w};
+            union { uint2 raw; bf16_t b[4]; } H, L;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split1(e[q], H.b[q], L.b[q]);
+            reinterpret_cast<uint2 *>(hi)[i] = H.raw;
+            reinterpret_cast<uint2 *>(lo)[i] = L.raw;
+        }
+        if (db) {
+            float *d = db + (size_t)slot * N + c * 4;
+            atomicAdd(d + 0, s.x); atomicAdd(d + 1, s.y); atomicAdd(d + 2, s.z); atomicAdd(d + 3, s.w);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace vmasr
+
+VMASR_EXPORT int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots, int64_t M, int32_t N,
+                                     vmasr_stream_t stream) {
+    VMASR_REQUIRE(acc && bias && act, VMASR_EINVAL, "bias_gelu_fwd: null tensor");
+    VMASR_REQUIRE(slots > 0 && slots <= 65535 && M > 0 && N > 0 && N % 4 == 0, VMASR_EINVAL, "bias_gelu_fwd: bad shape");
+    VMASR_REQUIRE(aligned_to(acc, 16) && aligned_to(bias, 16) && aligned_to(act, 16), VMASR_EINVAL, "bias_gelu_fwd: unaligned");
+    const long total = M * (N / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VMASR_LAUNCH(VMASR_K_BIAS_GELU, 12.0 * slots * (double)M * N, bias_gelu_fwd_kernel, dim3(blocks, slots), dim3(256), 0, st, acc,
+                 bias, act, (long)M, N);
+    return check_launch("bias_gelu_fwd");
+}
+
+VMASR_EXPORT int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, float *db, int32_t slots, int64_t M,
+                                      int32_t N, vmasr_stream_t stream) {
+    VMASR_REQUIRE(g && hi && lo, VMASR_EINVAL, "gelu_bwd_split: null tensor");
+    VMASR_REQUIRE(slots > 0 && slots <= 65535 && M > 0 && N > 0 && N % 4 == 0 && N <= 1024, VMASR_EINVAL,
+                  "gelu_bwd_split: bad shape (N must be a multiple of 4, <= 1024)");
+    VMASR_REQUIRE(aligned_to(g, 16) && (!pre || aligned_to(pre, 16)) && aligned_to(hi, 8) && aligned_to(lo, 8) && (!db || aligned_to(db, 16)),
+                  VMASR_EINVAL, "gelu_bwd_split: unaligned");
+    const int blocks = (int)((M + kGbRows - 1) / kGbRows);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VMASR_LAUNCH(VMASR_K_BIAS_GELU, 12.0 * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, slots), dim3(256), 0, st, pre, g,
+                 static_cast<bf16_t *>(hi), static_cast<bf16_t *>(lo), db, (long)M, N, pre ? 1 : 0);
+    return check_launch("gelu_bwd_split");
+}
