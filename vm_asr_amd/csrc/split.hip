@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(float *__restrict__ 
     }
 }
 
-constexpr int kGbRows = 128;   // rows per workgroup of the backward (column sums leave as one atomic per column and workgroup)
+constexpr int kGbRows = 256;   // rows per workgroup of the backward (column sums leave as one atomic per column and workgroup)
 
 __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__restrict__ pre, const float *__restrict__ g,
                                                              bf16_t *__restrict__ hi, bf16_t *__restrict__ lo,
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
     const int c = threadIdx.x % nv, rr = threadIdx.x / nv;
     const size_t base = (size_t)slot * M * N;
     const long r0 = (long)blockIdx.x * kGbRows;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};   // the bias gradient sums 10^4..10^5 rows: fp64 in-thread, fp32 only across workgroups
     if (rr < rows_per_pass) {
         for (long r = r0 + rr; r < r0 + kGbRows && r < M; r += rows_per_pass) {
             const size_t i = (base + (size_t)r * N) / 4 + c;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
                 const float4 p = reinterpret_cast<const float4 *>(pre)[i];
                 gv.x *= gelu_grad_f(p.x); gv.y *= gelu_grad_f(p.y); gv.z *= gelu_grad_f(p.z); gv.w *= gelu_grad_f(p.w);
             }
-            s.x += gv.x; s.y += gv.y; s.z += gv.z; s.w += gv.w;
+            s[0] += gv.x; s[1] += gv.y; s[2] += gv.z; s[3] += gv.w;
             const float e[4] = {gv.x, gv.y, gv.z, gv.w};
             union { uint2 raw; bf16_t b[4]; } H, L;
 #pragma unroll
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
         }
         if (db) {
             float *d = db + (size_t)slot * N + c * 4;
-            atomicAdd(d + 0, s.x); atomicAdd(d + 1, s.y); atomicAdd(d + 2, s.z); atomicAdd(d + 3, s.w);
+            atomicAdd(d + 0, (float)s[0]); atomicAdd(d + 1, (float)s[1]); atomicAdd(d + 2, (float)s[2]); atomicAdd(d + 3, (float)s[3]);
         }
     }
 }
