@@ -230,10 +230,11 @@ int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t 
 /* Epilogues of the period discriminator's GEMMs (model/discriminator.py:100-104: conv -> GELU), slots x (M, N) fp32:
  *   vmasr_bias_gelu_fwd : acc += bias[slot, col] in place (the pre-activation), act = GELU(acc)   (exact erf form)
  *   vmasr_gelu_bwd_split: gx = g * GELU'(pre) (pre == NULL: gx = g), written only as its bf16 split (hi, lo);
+ *                         cat3 (may be NULL): the same split as rows [hi | lo | hi] of width 3N (slots, M, 3N);
  *                         db[slot, col] += sum over rows of gx (db zero-initialised by the caller; may be NULL) */
 int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots, int64_t M, int32_t N, vmasr_stream_t stream);
-int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, float *db, int32_t slots, int64_t M, int32_t N,
-                         vmasr_stream_t stream);
+int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, void *cat3, float *db, int32_t slots, int64_t M,
+                         int32_t N, vmasr_stream_t stream);
 
 /* ---- fused SS2D core (vm_asr_amd/csrc/ss2d.hip) ---------------------------------------------------------
  * One operator for  y = CrossMerge(selective_scan(CrossScan(x), dt_proj(x_proj(.)), A, B, C, D, dt_bias, softplus))

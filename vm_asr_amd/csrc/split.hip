@@ -91,7 +91,8 @@ constexpr int kGbRows = 256;   // rows per workgroup of the backward (column sum
 
 __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__restrict__ pre, const float *__restrict__ g,
                                                              bf16_t *__restrict__ hi, bf16_t *__restrict__ lo,
-                                                             float *__restrict__ db, const long M, const int N, const int has_act) {
+                                                             bf16_t *__restrict__ cat3, float *__restrict__ db, const long M,
+                                                             const int N, const int has_act) {
     const int slot = blockIdx.y;
     const int nv = N / 4;
     const int rows_per_pass = 256 / nv > 0 ? 256 / nv : 1;   // nv <= 256 (N <= 1024)
@@ -114,6 +115,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
             for (int q = 0; q < 4; ++q) split1(e[q], H.b[q], L.b[q]);
             reinterpret_cast<uint2 *>(hi)[i] = H.raw;
             reinterpret_cast<uint2 *>(lo)[i] = L.raw;
+            if (cat3) {   // [hi | lo | hi] rows of width 3N: the A operand of the concatenated-contraction column-gradient GEMM
+                uint2 *row = reinterpret_cast<uint2 *>(cat3 + ((size_t)slot * M + r) * 3 * N);
+                row[c] = H.raw; row[nv + c] = L.raw; row[2 * nv + c] = H.raw;
+            }
         }
         if (db) {
             float *d = db + (size_t)slot * N + c * 4;
@@ -138,16 +143,17 @@ VMASR_EXPORT int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, 
     return check_launch("bias_gelu_fwd");
 }
 
-VMASR_EXPORT int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, float *db, int32_t slots, int64_t M,
-                                      int32_t N, vmasr_stream_t stream) {
+VMASR_EXPORT int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, void *cat3, float *db, int32_t slots,
+                                      int64_t M, int32_t N, vmasr_stream_t stream) {
     VMASR_REQUIRE(g && hi && lo, VMASR_EINVAL, "gelu_bwd_split: null tensor");
     VMASR_REQUIRE(slots > 0 && slots <= 65535 && M > 0 && N > 0 && N % 4 == 0 && N <= 1024, VMASR_EINVAL,
                   "gelu_bwd_split: bad shape (N must be a multiple of 4, <= 1024)");
     VMASR_REQUIRE(aligned_to(g, 16) && (!pre || aligned_to(pre, 16)) && aligned_to(hi, 8) && aligned_to(lo, 8) && (!db || aligned_to(db, 16)),
                   VMASR_EINVAL, "gelu_bwd_split: unaligned");
+    VMASR_REQUIRE(!cat3 || aligned_to(cat3, 8), VMASR_EINVAL, "gelu_bwd_split: unaligned cat3");
     const int blocks = (int)((M + kGbRows - 1) / kGbRows);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    VMASR_LAUNCH(VMASR_K_BIAS_GELU, 12.0 * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, slots), dim3(256), 0, st, pre, g,
-                 static_cast<bf16_t *>(hi), static_cast<bf16_t *>(lo), db, (long)M, N, pre ? 1 : 0);
+    VMASR_LAUNCH(VMASR_K_BIAS_GELU, (cat3 ? 18.0 : 12.0) * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, slots), dim3(256), 0,
+                 st, pre, g, static_cast<bf16_t *>(hi), static_cast<bf16_t *>(lo), static_cast<bf16_t *>(cat3), db, (long)M, N, pre ? 1 : 0);
     return check_launch("gelu_bwd_split");
 }

@@ -553,24 +553,28 @@ class _StackedConvSplitFn(torch.autograd.Function):
         K = ch.shape[2]
         lib = _lib.lib()
         want_db = ctx.needs_input_grad[6] and not _PHASE["skip_weight_grads"]
-        db32 = None
+        want_dx = any(ctx.needs_input_grad[7:])
+        db32 = gcat = None
         if N % 4 == 0 and N <= 1024:
             # one pass: (GELU' *) gradient -> bf16 split (+ bias gradient); the fp32 gradient is never written
             with torch.cuda.device(gy.device):
                 gh = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
                 gl = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
                 db32 = torch.zeros((n, N), dtype=torch.float32, device=gy.device) if want_db else None
+                gcat = torch.empty((n, M, 3 * N), dtype=torch.bfloat16, device=gy.device) if want_dx else None
                 _lib.check(lib.vmasr_gelu_bwd_split(rest[0].data_ptr() if act else None, gy.data_ptr(), gh.data_ptr(), gl.data_ptr(),
-                                                    db32.data_ptr() if want_db else None, n, M, N, _lib.current_stream(gy.device)),
-                           "gelu_bwd_split")
+                                                    gcat.data_ptr() if want_dx else None, db32.data_ptr() if want_db else None,
+                                                    n, M, N, _lib.current_stream(gy.device)), "gelu_bwd_split")
         else:
             if act:
                 gy = torch.ops.aten.gelu_backward(gy, rest[0])
             gh, gl = split_bf16(gy)
             db32 = gy.sum(1) if want_db else None
         dxs = [None] * len(shapes)
-        if any(ctx.needs_input_grad[7:]):
-            dcols = torch.bmm(torch.cat((gh, gl, gh), dim=2), wcat, out_dtype=torch.float32)
+        if want_dx:
+            if gcat is None:
+                gcat = torch.cat((gh, gl, gh), dim=2)
+            dcols = torch.bmm(gcat, wcat, out_dtype=torch.float32)
             with torch.cuda.device(gy.device):
                 for i, (B, P, H, C) in enumerate(shapes):
                     if not ctx.needs_input_grad[7 + i]:

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["fwd", "bwd", "SelectiveScanCore", "selective_scan_fn", "tune"]
+__all__ = ["fwd", "bwd", "fwd_oflex", "bwd_oflex", "SelectiveScanCore", "SelectiveScanOflex", "selective_scan_fn", "tune"]
 
 
 def _chk(cond, msg):
@@ -163,6 +163,50 @@ class SelectiveScanCore(torch.autograd.Function):
             dout = dout.contiguous()
         du, ddelta, dA, dB, dC, dD, ddelta_bias, *rest = bwd(
             u, delta, A, B, C, D, delta_bias, dout, x, ctx.delta_softplus, 1)
+        return (du, ddelta, dA, dB, dC, dD, ddelta_bias, None, None, None, None)
+
+
+# ---- `selective_scan_cuda_oflex` surface (cusoflex/selective_scan_oflex.cpp:157-239 fwd, :241-352 bwd) ----------------
+# oflex = "output flexible": with `out_float` the forward returns fp32 for 16-bit inputs (:218-219, :235-239) and the
+# backward takes an fp32 `dout`.  The kernels of sscan.hip convert every operand to fp32 on load and compute in fp32, so
+# running them on the (exactly) up-converted inputs gives bit-for-bit what an out_float store would: that is how the
+# option is provided — two conversion passes instead of more kernel instantiations, since no shipped config selects a
+# forward type that uses it (model/vmamba.py:785-841).  `out_float=False` is `fwd` / `bwd` unchanged.
+def fwd_oflex(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1, out_float=True):
+    """-> [out (fp32 if out_float else u.dtype), x]"""
+    if not out_float or u.dtype == torch.float32:
+        return fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)
+    _check_common(u, delta, A, B, C, D, delta_bias)
+    return fwd(u.float(), delta.float(), A, B.float(), C.float(), D, delta_bias, delta_softplus, nrows)
+
+
+def bwd_oflex(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows=1):
+    """dout may be fp32 for 16-bit inputs; du, ddelta, dB, dC come back in the input dtype (:335-347)."""
+    if dout.dtype == u.dtype:
+        return bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows)
+    _chk(dout.dtype == torch.float32, "dout must be float32 or match u")
+    du, dd, dA, dB, dC, dD, db = bwd(u.float(), delta.float(), A, B.float(), C.float(), D, delta_bias, dout, x, delta_softplus, nrows)
+    return [du.to(u.dtype), dd.to(delta.dtype), dA, dB.to(B.dtype), dC.to(C.dtype), dD, db]
+
+
+class SelectiveScanOflex(torch.autograd.Function):
+    """model/vmamba.py:358-392 with the HIP operator underneath."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1, backnrows=1, oflex=True):
+        ctx.delta_softplus = delta_softplus
+        out, x, *rest = fwd_oflex(u, delta, A, B, C, D, delta_bias, delta_softplus, 1, oflex)
+        ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dout, *args):
+        u, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
+        if dout.stride(-1) != 1:
+            dout = dout.contiguous()
+        du, ddelta, dA, dB, dC, dD, ddelta_bias, *rest = bwd_oflex(u, delta, A, B, C, D, delta_bias, dout, x, ctx.delta_softplus, 1)
         return (du, ddelta, dA, dB, dC, dD, ddelta_bias, None, None, None, None)
 
 
