@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PMC_FILE = "r02_pmc_traffic.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 
@@ -187,26 +188,34 @@ def main():
         prof = _lib.prof_collect()
         kern = {k: dict(v, avg_us=v["ms"] / v["launches"] * 1e3,
                         gbs=v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0) for k, v in prof.items()}
-        scan = {k: v for k, v in kern.items() if k.startswith("sscan")}
+        # the selective-scan operator = sscan.hip's kernels (deep stages) + the scan kernels of the fused SS2D core
+        # (ss2d.hip: aggregate / carry / apply; its transpose and pair-merge kernels are what is left of cross-scan /
+        # cross-merge and are listed in `kernels`, not counted here)
+        scan = {k: v for k, v in kern.items() if k.startswith("sscan") or k in ("ss2d_fwd_agg", "ss2d_fwd_apply", "ss2d_bwd_agg",
+                                                                                "ss2d_bwd_apply", "ss2d_carry")}
         if scan:
             dom = max(scan, key=lambda k: scan[k]["ms"])
             d = scan[dom]
             # op-level: all scan kernels; algorithmic bytes counted once per op (apply/fwd/bwd kernels carry them)
-            op_bytes = sum(v["alg_bytes"] for k, v in scan.items() if k in ("sscan_fwd", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_apply"))
+            op_bytes = sum(v["alg_bytes"] for k, v in scan.items() if k in ("sscan_fwd", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_apply",
+                                                                           "ss2d_fwd_apply", "ss2d_bwd_apply"))
             op_ms = sum(v["ms"] for v in scan.values())
             # HBM bytes per launch from the committed PMC passes of this same workload (rocprofv3 cannot
-            # run inside bench.py): profiles/r01_pmc_traffic.json, made by tools/pmc_bench_report.py
+            # run inside bench.py): profiles/r02_pmc_traffic.json, made by tools/pmc_bench_report.py
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
                 traffic = pmc[dom]["hbm_bytes_per_launch"] if B == 4 and args.workload == "vm_asr_48k_MPD" else None
             except Exception:
                 pass
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": d["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "traffic_source": f"profiles/{PMC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                   "FETCH_SIZE x2 per the gfx950 correction)" if traffic else None,
+                "bytes_definition": "SURVEY.md 8(d) algorithmic bytes of the selective-scan calls the launch performs (for the fused "
+                                    "ss2d_* kernels: the reference contract's Delta/B/C/direction streams that never reach HBM here "
+                                    "are part of it, so `traffic` << algorithmic bytes is the fusion, not over-fetch)",
                 "avg_launch_us": d["avg_us"],
                 "timed_in": "eager pass of the same K steps right after the timed region (HIP events on the launch stream)",
                 "launches": d["launches"], "alg_bytes_per_launch": d["alg_bytes"] / d["launches"],

@@ -9,6 +9,15 @@ def kid(name):
         d, mode = m.group(1), int(m.group(2))
         return {("fwd", 0): "sscan_fwd", ("fwd", 3): "sscan_fwd", ("fwd", 2): "sscan_fwd_agg", ("fwd", 1): "sscan_fwd_apply",
                 ("bwd", 0): "sscan_bwd", ("bwd", 2): "sscan_bwd_agg", ("bwd", 1): "sscan_bwd_apply"}[(d, mode)]
+    m = re.search(r"ss2d_(fwd|bwd)_kernel<[^>]*?(\d)>", name)
+    if m:
+        return f"ss2d_{m.group(1)}_{'apply' if m.group(2) == '1' else 'agg'}"
+    for k, v in (("ss2d_carry_kernel", "ss2d_carry"), ("ss2d_bwd_reduce_kernel", "ss2d_carry"), ("transpose_hw_kernel", "ss2d_transpose"),
+                 ("merge_pairs_kernel", "ss2d_merge"), ("split_bf16_kernel", "split_bf16"), ("gelu_bwd_split_kernel", "gelu_bwd_split"),
+                 ("bias_gelu_fwd_kernel", "bias_gelu_fwd"), ("im2col_split_kernel", "im2col_split"), ("im2col_kernel", "im2col_kx1"),
+                 ("col2im_kernel", "col2im_kx1")):
+        if k in name:
+            return v
     for k in ("sscan_carry_kernel<false>", "sscan_carry_kernel<true>", "sscan_bwd_reduce_kernel", "cross_scan_kernel",
               "cross_merge_kernel", "dwconv_silu", "stft_like_kernel", "istft_frames_kernel", "istft_ola_kernel",
               "ln_fwd_kernel", "ln_bwd_kernel", "ln_bwd_reduce_kernel", "small_linear_fwd_kernel", "small_linear_bwd_kernel"):

@@ -530,12 +530,18 @@ int run_fwd(const vmasr_ss2d_params &p, hipStream_t st) {
     const size_t sm = lds_bytes(c);
     launch_transpose<T, T>(static_cast<const T *>(p.x), static_cast<T *>(p.xT), p.B * p.D, p.H, p.W, st);
     const FwdArgs a{p.x, p.xT, p.Wx, p.Wdt, p.dtb, p.Alog, p.Ds, p.state, p.out02, p.out13};
-    const double el = (double)p.B * p.D * L;
+    // Bytes reported to the profiler (bench.py's roofline): the apply kernels carry the ALGORITHMIC bytes of the
+    // selective-scan call they perform as SURVEY.md §8(d) defines them for the reference's operator contract
+    // (fwd (3 KD + 2 K N) L s, bwd (5 KD + 4 K N) L s with KD = 4 D, K = 4, N = 1, s = 4: Delta, B, C, the four
+    // direction streams and the four outputs are part of that contract although this operator never materialises
+    // them); the aggregate passes carry what they really re-read.  The kernels' OWN compulsory traffic is far
+    // smaller (forward apply: 2 pairs x (x + out) = 2 (s_x + 4) B per (row, position)) — DESIGN.md §4 quotes both.
+    const double el = (double)p.B * p.D * L, pos = (double)p.B * L;
     SS2D_DISPATCH(ss2d_fwd_kernel, 0, VMASR_K_SS2D_FWD_AGG, 2.0 * el * sizeof(T), a);
     const int nseq = p.B * 4 * p.D;
     VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nseq * ntiles * 16, (ss2d_carry_kernel<false>), dim3((nseq + 3) / 4), dim3(256), 0, st,
                  p.state, nseq, ntiles);
-    SS2D_DISPATCH(ss2d_fwd_kernel, 1, VMASR_K_SS2D_FWD_APPLY, 2.0 * el * (sizeof(T) + 4), a);
+    SS2D_DISPATCH(ss2d_fwd_kernel, 1, VMASR_K_SS2D_FWD_APPLY, (3.0 * 4 * el + 2.0 * 4 * pos) * 4, a);
     const dim3 grid(((p.W + kXT - 1) / kXT) * ((p.H + kXT - 1) / kXT), p.B * p.D);
     VMASR_LAUNCH(VMASR_K_SS2D_MERGE, 12.0 * el, (merge_pairs_kernel<float>), grid, dim3(256), 0, st, p.out02, p.out13, p.y, p.H, p.W);
     return check_launch("ss2d_fwd");
@@ -550,12 +556,12 @@ int run_bwd(const vmasr_ss2d_params &p, hipStream_t st) {
     const size_t sm = lds_bytes(c);
     launch_transpose<float, float>(p.dy, p.dyT, p.B * p.D, p.H, p.W, st);
     BwdArgs q{{p.x, p.xT, p.Wx, p.Wdt, p.dtb, p.Alog, p.Ds, p.state, nullptr, nullptr}, p.dy, p.dyT, p.adj, p.out02, p.out13, p.part};
-    const double el = (double)p.B * p.D * L;
+    const double el = (double)p.B * p.D * L, pos = (double)p.B * L;
     SS2D_DISPATCH(ss2d_bwd_kernel, 0, VMASR_K_SS2D_BWD_AGG, 2.0 * el * (sizeof(T) + 4), q);
     const int nseq = p.B * 4 * p.D;
     VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nseq * ntiles * 16, (ss2d_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st,
                  p.adj, nseq, ntiles);
-    SS2D_DISPATCH(ss2d_bwd_kernel, 1, VMASR_K_SS2D_BWD_APPLY, 2.0 * el * (sizeof(T) + 8), q);
+    SS2D_DISPATCH(ss2d_bwd_kernel, 1, VMASR_K_SS2D_BWD_APPLY, (5.0 * 4 * el + 4.0 * 4 * pos) * 4, q);
     const int nwg = p.B * ntiles;
     VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nwg * 4 * p.D * kNPart * 4, ss2d_bwd_reduce_kernel, dim3((4 * p.D + 3) / 4), dim3(256), 0, st,
                  p.part, nwg, p.D, p.dWx, p.dWdt, p.ddtb, p.dAlog, p.dDs);
