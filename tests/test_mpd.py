@@ -390,3 +390,37 @@ def test_stacked_conv_split_matches_float64_conv(stride, k, pad, act):
         close(xr[i].grad.double().cpu().permute(0, 3, 2, 1), x64.grad, "dx")
         close(Wr.grad[i].double().cpu().view(N, k, C).permute(0, 2, 1).unsqueeze(-1), w64.grad, "dW")
         close(br.grad[i].double().cpu(), b64.grad, "db")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,M,N", [(5, 512, 1024), (2, 300, 512), (3, 1000, 128), (1, 6144, 1024)])
+def test_gelu_epilogue_kernels(n, M, N):
+    """vmasr_bias_gelu_fwd / vmasr_gelu_bwd_split (csrc/split.hip) against torch in float64: pre-activation, GELU,
+    gx = g * GELU'(pre) through its bf16 split (hi + lo), the [hi | lo | hi] operand, and the bias gradient."""
+    from vm_asr_amd import _lib
+    torch.manual_seed(n * 7 + N)
+    acc = torch.randn(n, M, N, device="cuda") * 2
+    bias = torch.randn(n, N, device="cuda")
+    g = torch.randn(n, M, N, device="cuda")
+    lib, st = _lib.lib(), _lib.current_stream(acc.device)
+    pre, act = acc.clone(), torch.empty_like(acc)
+    _lib.check(lib.vmasr_bias_gelu_fwd(pre.data_ptr(), bias.data_ptr(), act.data_ptr(), n, M, N, st), "fwd")
+    p64 = acc.double() + bias.double().unsqueeze(1)
+    assert torch.allclose(pre.double(), p64, rtol=0, atol=1e-6)
+    assert torch.allclose(act.double(), torch.nn.functional.gelu(p64), rtol=1e-5, atol=2e-6)
+    hi, lo = (torch.empty(n, M, N, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    cat3 = torch.empty(n, M, 3 * N, dtype=torch.bfloat16, device="cuda")
+    db = torch.zeros(n, N, device="cuda")
+    _lib.check(lib.vmasr_gelu_bwd_split(pre.data_ptr(), g.data_ptr(), hi.data_ptr(), lo.data_ptr(), cat3.data_ptr(), db.data_ptr(),
+                                        n, M, N, st), "bwd")
+    x = p64.clone().requires_grad_()
+    torch.nn.functional.gelu(x).backward(g.double())
+    gx = x.grad
+    assert torch.allclose(hi.double() + lo.double(), gx, rtol=2e-5, atol=1e-5)
+    assert torch.equal(cat3[:, :, :N], hi) and torch.equal(cat3[:, :, N:2 * N], lo) and torch.equal(cat3[:, :, 2 * N:], hi)
+    want = gx.sum(1)
+    assert (db.double() - want).abs().max() <= 2e-6 * gx.abs().sum(1).max(), ((db.double() - want).abs().max().item(), want.abs().max().item())
+    # no activation: plain split + column sums
+    db.zero_()
+    _lib.check(lib.vmasr_gelu_bwd_split(None, g.data_ptr(), hi.data_ptr(), lo.data_ptr(), None, db.data_ptr(), n, M, N, st), "bwd")
+    assert torch.equal(hi, g.to(torch.bfloat16)) and (db.double() - g.double().sum(1)).abs().max() <= 2e-6 * g.abs().double().sum(1).max()

@@ -67,6 +67,8 @@ def test_fused_core_matches_oracle_chain_fp32(shape):
         e_hip, e_cpu = (a - c).abs().max().item() / scale, (b - c).abs().max().item() / scale
         # north_star: 1e-4 (fp32) on the output; gradients: as close to float64 as the fp32 oracle chain (x4 + floor)
         assert a.shape == c.shape, n
+        if n in ("y", "dx"):
+            print(f"{shape} {n}: |hip - f64| {e_hip:.2e}  |oracle fp32 chain - f64| {e_cpu:.2e}")
         if n == "y":
             assert e_hip <= 1e-4, (shape, n, e_hip, e_cpu)
         assert e_hip <= 4 * e_cpu + 2e-5, (shape, n, e_hip, e_cpu)

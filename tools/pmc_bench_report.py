@@ -9,8 +9,8 @@ def kid(name):
         d, mode = m.group(1), int(m.group(2))
         return {("fwd", 0): "sscan_fwd", ("fwd", 3): "sscan_fwd", ("fwd", 2): "sscan_fwd_agg", ("fwd", 1): "sscan_fwd_apply",
                 ("bwd", 0): "sscan_bwd", ("bwd", 2): "sscan_bwd_agg", ("bwd", 1): "sscan_bwd_apply"}[(d, mode)]
-    m = re.search(r"ss2d_(fwd|bwd)_kernel<[^>]*?(\d)>", name)
-    if m:
+    m = re.search(r"ss2d_(fwd|bwd)_kernel<[^>]*?(\d)>", name) or re.search(r"ss2d_(fwd|bwd)_kernelI\w*?Li(\d)EEE", name)
+    if m:   # (demangled or mangled: rocprofv3 leaves some instantiations mangled)
         return f"ss2d_{m.group(1)}_{'apply' if m.group(2) == '1' else 'agg'}"
     for k, v in (("ss2d_carry_kernel", "ss2d_carry"), ("ss2d_bwd_reduce_kernel", "ss2d_carry"), ("transpose_hw_kernel", "ss2d_transpose"),
                  ("merge_pairs_kernel", "ss2d_merge"), ("split_bf16_kernel", "split_bf16"), ("gelu_bwd_split_kernel", "gelu_bwd_split"),
