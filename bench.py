@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--amp-scope", default="generator", choices=["generator", "step"],
                     help="what bf16 autocast covers: 'generator' = the reference's scope (trainer/trainer.py:138-139: the "
                          "generator forward; losses and discriminator in fp32), 'step' = losses and discriminator too")
+    ap.add_argument("--mpd-gemm", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="the fp32 discriminator's compute-bound GEMMs: 'bf16x3' = error-compensated triple bf16 MFMA products "
+                         "(fp32 operands split into hi + lo bf16, fp32 accumulation; csrc/split.hip), 'fp32' = f32-input MFMA GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
@@ -119,6 +122,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["VMASR_BENCH_WATCHDOG"]), exit=True)
 
+    os.environ["VMASR_MPD_GEMM"] = args.mpd_gemm
     from vm_asr_amd import _lib
     from vm_asr_amd.trainer import init_distributed
     rank, local, world = init_distributed()
@@ -175,7 +179,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32" if args.no_amp else
                   "bf16 autocast over the generator forward as in the reference (selective scan / STFT fp32; losses and "
-                  "discriminator fp32)" if args.amp_scope == "generator" else
+                  "discriminator fp32" + ("; its three compute-bound GEMM layers as error-compensated bf16x3 MFMA products, fp32 "
+                                          "accumulation)" if args.mpd_gemm == "bf16x3" else ")") if args.amp_scope == "generator" else
                   "bf16 autocast over generator, losses and discriminator (selective scan / STFT fp32)"), "data": "synthetic",
         "config": {"workload": f"{args.workload}.yaml full train step (G fwd+bwd, "
                                f"{'MR-STFT+LSGAN+feature losses, MPD fwd+bwd, ' if config.TRAIN.ADVERSARIAL.ENABLE else 'MR-STFT loss, '}"
