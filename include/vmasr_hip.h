@@ -263,6 +263,23 @@ size_t vmasr_ss2d_part_floats(int32_t B, int32_t D, int32_t H, int32_t W);
 int vmasr_ss2d_fwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
 int vmasr_ss2d_bwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
 
+/* ---- glue of SS2D.forwardv2 around the scan core (vm_asr_amd/csrc/ss2d_glue.hip; model/vmamba.py:1535-1550) ----------
+ * ss2d_pre : xz (B*L, 2D) -> xT (B, D, L) = the x half channel-first, sz (B*L, D) = SiLU(z half)
+ *            (replaces chunk + SiLU on a strided view + permute(0,3,1,2).contiguous()); _bwd: (dxT, dsz) -> dxz
+ * ln_gate  : y (B, D, L) fp32, sz -> out (B*L, D) = LayerNorm_D(y^T; gamma, beta, eps) * sz, mean / rstd (B*L) fp32
+ *            (replaces transpose.contiguous + LayerNorm + cast + multiply); _bwd: dout -> dy (B, D, L) fp32, dsz,
+ *            dgamma / dbeta (D) fp32 ACCUMULATED with atomics (caller zero-initialises)
+ * `dtype` is the type of xz / xT / sz / out / dout / dsz; D <= 512, L a multiple of 64 / 32 / 16 for D <= 128 / 256 / 512. */
+int vmasr_ss2d_glue_supported(int32_t D, int32_t L, int32_t dtype);
+int vmasr_ss2d_pre_fwd(const void *xz, void *xT, void *sz, int32_t B, int32_t D, int32_t L, int32_t dtype, vmasr_stream_t stream);
+int vmasr_ss2d_pre_bwd(const void *xz, const void *dxT, const void *dsz, void *dxz, int32_t B, int32_t D, int32_t L, int32_t dtype,
+                       vmasr_stream_t stream);
+int vmasr_ln_gate_fwd(const float *y, const void *sz, const float *gamma, const float *beta, void *out, float *mean, float *rstd,
+                      int32_t B, int32_t D, int32_t L, float eps, int32_t dtype, vmasr_stream_t stream);
+int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta, const float *mean,
+                      const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta, int32_t B, int32_t D, int32_t L,
+                      int32_t dtype, vmasr_stream_t stream);
+
 /* x (n fp32) -> hi = bf16(x), lo = bf16(x - hi): the operands of an error-compensated 3-GEMM bf16 product that
  * reproduces the fp32 GEMM of the period discriminator's convolutions (model/discriminator.py:21-147) to ~1e-6
  * relative (vm_asr_amd/csrc/split.hip).  hi, lo: n bf16 each. */
@@ -313,6 +330,8 @@ enum {
     VMASR_K_SS2D_MERGE,         /* pair outputs: a + transpose(b)                        */
     VMASR_K_SS2D_BWD_AGG,
     VMASR_K_SS2D_BWD_APPLY,
+    VMASR_K_SS2D_PRE,           /* xz -> (x channel-first, SiLU(z)) and its backward          */
+    VMASR_K_LN_GATE,            /* LayerNorm_D(y^T) * SiLU(z) and its backward                */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

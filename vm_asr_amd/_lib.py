@@ -77,6 +77,11 @@ SYMBOLS = {
     "vmasr_split_bf16": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vmasr_bias_gelu_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_gelu_bwd_split": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "vmasr_ss2d_glue_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
+    "vmasr_ss2d_pre_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_ss2d_pre_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_ln_gate_fwd": (ctypes.c_int, [c_vp] * 7 + [c_i32, c_i32, c_i32, ctypes.c_float, c_i32, c_vp]),
+    "vmasr_ln_gate_bwd": (ctypes.c_int, [c_vp] * 11 + [c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_ss2d_supported": (ctypes.c_int, [c_i32] * 5),
     "vmasr_ss2d_part_floats": (c_sz, [c_i32] * 4),
     "vmasr_ss2d_fwd": (ctypes.c_int, [ctypes.POINTER(SS2DParams), c_vp]),
@@ -142,7 +147,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 38
+K_COUNT = 40
 
 
 def zeros_f32(device, *shapes):

@@ -1,0 +1,352 @@
+// ss2d_glue.hip — the memory-bound glue of SS2D.forwardv2 around the scan core, fused into two operators, gfx950.
+//
+// model/vmamba.py:1533-1552 per block:   xz = in_proj(x); x, z = chunk(xz); z = SiLU(z);
+//     x = x.permute(0,3,1,2).contiguous(); x = SiLU(conv2d(x)); y = core(x)            [(B,D,L) merged scan output]
+//     y = out_norm(y.transpose(1,2).contiguous()); y = y.to(x.dtype); y = y * z; out_proj(y)
+// The lines around conv / core are, as ATen, 2 + 4 kernels forward (SiLU on a strided view, a layout copy; a layout
+// copy, LayerNorm, a cast, a multiply) and 3 + 6 backward, each a full pass over (B, L, D) — 12 launches per block
+// and ~50 B of traffic per element for ~14 B of information.  Here:
+//
+//   ss2d_pre   : xz (B L, 2D) -> xT (B, D, L) = channel-first copy of the x half, sz (B L, D) = SiLU(z half)
+//   ln_gate    : y (B, D, L) fp32, sz -> out (B L, D) = LayerNorm_D(y^T) * sz        (+ mean, rstd for the backward)
+// and their backwards (one launch each).  A workgroup owns P consecutive positions x all D channels: the
+// channel-first side is read / written as P-long runs per channel (coalesced along l), the channel-last side as
+// 16-byte vectors per position, and the (D x P) tile crosses between the two layouts through LDS (padded rows:
+// conflict-free both ways).  LayerNorm statistics are two-pass (mean, then centred squares) over the LDS tile.
+#include "common.h"
+
+#include <algorithm>
+
+namespace vmasr {
+namespace {
+
+struct GlueGeom {
+    int B, D, L, P, nch;   // P positions per workgroup, nch = D / CH channel chunks per position
+    float eps;
+};
+
+__device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+
+template <typename T, int CH>
+__device__ __forceinline__ void load_chunk(const T *__restrict__ p, float (&v)[CH]) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (CH == 4) { const float4 q = *reinterpret_cast<const float4 *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+        else if constexpr (CH == 2) { const float2 q = *reinterpret_cast<const float2 *>(p); v[0] = q.x; v[1] = q.y; }
+        else { v[0] = p[0]; }
+    } else {
+        union { uint4 r4; uint2 r2; uint32_t r1; T e[8]; } q;
+        if constexpr (CH == 8) q.r4 = *reinterpret_cast<const uint4 *>(p);
+        else if constexpr (CH == 4) q.r2 = *reinterpret_cast<const uint2 *>(p);
+        else if constexpr (CH == 2) q.r1 = *reinterpret_cast<const uint32_t *>(p);
+        else q.e[0] = p[0];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = to_f32(q.e[i]);
+    }
+}
+
+template <typename T, int CH>
+__device__ __forceinline__ void store_chunk(T *__restrict__ p, const float (&v)[CH]) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (CH == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        else if constexpr (CH == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+        else p[0] = v[0];
+    } else {
+        union { uint4 r4; uint2 r2; uint32_t r1; T e[8]; } q;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) q.e[i] = from_f32<T>(v[i]);
+        if constexpr (CH == 8) *reinterpret_cast<uint4 *>(p) = q.r4;
+        else if constexpr (CH == 4) *reinterpret_cast<uint2 *>(p) = q.r2;
+        else if constexpr (CH == 2) *reinterpret_cast<uint32_t *>(p) = q.r1;
+        else p[0] = q.e[0];
+    }
+}
+
+// (D x P) LDS tile <-> channel-first rows  rows[(b*D + d)*L + l0 + p]   (coalesced along p)
+template <typename T>
+__device__ __forceinline__ void tile_from_rows(float *tile, const T *__restrict__ rows, const GlueGeom &g, const int b, const int l0) {
+    for (int i = threadIdx.x; i < g.D * g.P; i += blockDim.x) {
+        const int d = i / g.P, p = i % g.P;
+        tile[d * (g.P + 1) + p] = to_f32(rows[((size_t)b * g.D + d) * g.L + l0 + p]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tile_to_rows(const float *tile, T *__restrict__ rows, const GlueGeom &g, const int b, const int l0) {
+    for (int i = threadIdx.x; i < g.D * g.P; i += blockDim.x) {
+        const int d = i / g.P, p = i % g.P;
+        rows[((size_t)b * g.D + d) * g.L + l0 + p] = from_f32<T>(tile[d * (g.P + 1) + p]);
+    }
+}
+
+// ---- ss2d_pre ----------------------------------------------------------------------------------------------------
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void ss2d_pre_fwd_kernel(const T *__restrict__ xz, T *__restrict__ xT, T *__restrict__ sz,
+                                                           const GlueGeom g) {
+    extern __shared__ float tile[];
+    const int b = blockIdx.y, l0 = blockIdx.x * g.P;
+    for (int i = threadIdx.x; i < g.P * g.nch; i += blockDim.x) {
+        const int p = i / g.nch, c = i % g.nch;
+        const size_t row = (size_t)b * g.L + l0 + p;
+        float xv[CH], zv[CH];
+        load_chunk<T, CH>(xz + row * 2 * g.D + c * CH, xv);
+        load_chunk<T, CH>(xz + row * 2 * g.D + g.D + c * CH, zv);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            tile[(c * CH + e) * (g.P + 1) + p] = xv[e];
+            zv[e] = zv[e] * sigmoid_f(zv[e]);
+        }
+        store_chunk<T, CH>(sz + row * g.D + c * CH, zv);
+    }
+    __syncthreads();
+    tile_to_rows<T>(tile, xT, g, b, l0);
+}
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void ss2d_pre_bwd_kernel(const T *__restrict__ xz, const T *__restrict__ dxT,
+                                                           const T *__restrict__ dsz, T *__restrict__ dxz, const GlueGeom g) {
+    extern __shared__ float tile[];
+    const int b = blockIdx.y, l0 = blockIdx.x * g.P;
+    tile_from_rows<T>(tile, dxT, g, b, l0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.P * g.nch; i += blockDim.x) {
+        const int p = i / g.nch, c = i % g.nch;
+        const size_t row = (size_t)b * g.L + l0 + p;
+        float dx[CH], zv[CH], gz[CH];
+        load_chunk<T, CH>(xz + row * 2 * g.D + g.D + c * CH, zv);
+        load_chunk<T, CH>(dsz + row * g.D + c * CH, gz);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            dx[e] = tile[(c * CH + e) * (g.P + 1) + p];
+            const float s = sigmoid_f(zv[e]);
+            gz[e] *= s * fmaf(zv[e], 1.f - s, 1.f);     // d SiLU = s (1 + z (1 - s))
+        }
+        store_chunk<T, CH>(dxz + row * 2 * g.D + c * CH, dx);
+        store_chunk<T, CH>(dxz + row * 2 * g.D + g.D + c * CH, gz);
+    }
+}
+
+// ---- ln_gate -------------------------------------------------------------------------------------------------------
+// LDS: tile (D x (P+1)) | red (256 floats) | stat (2 P) | acc (2 D, backward)
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void ln_gate_fwd_kernel(const float *__restrict__ y, const T *__restrict__ sz,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          T *__restrict__ out, float *__restrict__ mean, float *__restrict__ rstd,
+                                                          const GlueGeom g) {
+    extern __shared__ float lds[];
+    float *tile = lds, *red = lds + g.D * (g.P + 1), *stat = red + 256;
+    const int b = blockIdx.y, l0 = blockIdx.x * g.P;
+    tile_from_rows<float>(tile, y, g, b, l0);
+    __syncthreads();
+    // statistics: position p = tid % P, T_ = 256 / P threads per position take the channels t, t + T_, ...
+    const int p = threadIdx.x % g.P, t = threadIdx.x / g.P, TP = blockDim.x / g.P;
+    float s = 0.f;
+    for (int d = t; d < g.D; d += TP) s += tile[d * (g.P + 1) + p];
+    red[t * g.P + p] = s;
+    __syncthreads();
+    float mu = 0.f;
+    for (int k = 0; k < TP; ++k) mu += red[k * g.P + p];
+    mu /= (float)g.D;
+    __syncthreads();
+    float q = 0.f;
+    for (int d = t; d < g.D; d += TP) { const float c = tile[d * (g.P + 1) + p] - mu; q = fmaf(c, c, q); }
+    red[t * g.P + p] = q;
+    __syncthreads();
+    if (t == 0) {
+        float v = 0.f;
+        for (int k = 0; k < TP; ++k) v += red[k * g.P + p];
+        const float rs = rsqrtf(v / (float)g.D + g.eps);
+        stat[p] = mu; stat[g.P + p] = rs;
+        mean[(size_t)b * g.L + l0 + p] = mu;
+        rstd[(size_t)b * g.L + l0 + p] = rs;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.P * g.nch; i += blockDim.x) {
+        const int pp = i / g.nch, c = i % g.nch;
+        const size_t row = (size_t)b * g.L + l0 + pp;
+        float zv[CH], o[CH];
+        load_chunk<T, CH>(sz + row * g.D + c * CH, zv);
+        const float m = stat[pp], r = stat[g.P + pp];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const int d = c * CH + e;
+            o[e] = fmaf((tile[d * (g.P + 1) + pp] - m) * r, gamma[d], beta[d]) * zv[e];
+        }
+        store_chunk<T, CH>(out + row * g.D + c * CH, o);
+    }
+}
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float *__restrict__ y, const T *__restrict__ sz,
+                                                          const T *__restrict__ dout, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, const float *__restrict__ mean,
+                                                          const float *__restrict__ rstd, float *__restrict__ dy,
+                                                          T *__restrict__ dsz, float *__restrict__ dgamma,
+                                                          float *__restrict__ dbeta, const GlueGeom g) {
+    extern __shared__ float lds[];
+    float *tile = lds, *acc = lds + g.D * (g.P + 1);   // acc: dgamma[D], dbeta[D]
+    const int b = blockIdx.y, l0 = blockIdx.x * g.P;
+    for (int i = threadIdx.x; i < 2 * g.D; i += blockDim.x) acc[i] = 0.f;
+    tile_from_rows<float>(tile, y, g, b, l0);
+    __syncthreads();
+    const float invD = 1.f / (float)g.D;
+    float dg[CH], db[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+    const int c = threadIdx.x % g.nch;                   // 256 % nch == 0: the chunk of a thread is loop-invariant
+    for (int i = threadIdx.x; i < g.P * g.nch; i += blockDim.x) {
+        const int pp = i / g.nch;
+        const size_t row = (size_t)b * g.L + l0 + pp;
+        const float m = mean[row], r = rstd[row];
+        float zv[CH], go[CH], xh[CH], gg[CH];
+        load_chunk<T, CH>(sz + row * g.D + c * CH, zv);
+        load_chunk<T, CH>(dout + row * g.D + c * CH, go);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const int d = c * CH + e;
+            xh[e] = (tile[d * (g.P + 1) + pp] - m) * r;
+            const float a = fmaf(xh[e], gamma[d], beta[d]);      // LayerNorm output
+            const float gl = go[e] * zv[e];                      // gradient wrt the LayerNorm output
+            zv[e] = go[e] * a;                                   // gradient wrt sz
+            dg[e] = fmaf(gl, xh[e], dg[e]);
+            db[e] += gl;
+            gg[e] = gl * gamma[d];
+            s1 += gg[e];
+            s2 = fmaf(gg[e], xh[e], s2);
+        }
+        store_chunk<T, CH>(dsz + row * g.D + c * CH, zv);
+        for (int off = g.nch >> 1; off > 0; off >>= 1) {         // the nch lanes of a position are adjacent (nch | 64)
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) tile[(c * CH + e) * (g.P + 1) + pp] = r * (gg[e] - s1 * invD - xh[e] * s2 * invD);
+    }
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        atomicAdd(&acc[c * CH + e], dg[e]);
+        atomicAdd(&acc[g.D + c * CH + e], db[e]);
+    }
+    __syncthreads();
+    tile_to_rows<float>(tile, dy, g, b, l0);
+    for (int d = threadIdx.x; d < g.D; d += blockDim.x) {
+        atomicAdd(dgamma + d, acc[d]);
+        atomicAdd(dbeta + d, acc[g.D + d]);
+    }
+}
+
+int plan(int B, int D, int L, int esz, GlueGeom &g, int &CH, const char *what) {
+    VMASR_REQUIRE(B > 0 && D > 0 && L > 0, VMASR_EINVAL, "%s: non-positive size", what);
+    VMASR_REQUIRE(B <= 65535, VMASR_EINVAL, "%s: batch too large", what);
+    const int V = 16 / esz;
+    CH = D % V == 0 ? V : (D % 4 == 0 ? 4 : (D % 2 == 0 ? 2 : 1));
+    if (esz == 4 && CH > 4) CH = 4;
+    const int nch = D / CH;
+    VMASR_REQUIRE(nch <= 64 && (nch & (nch - 1)) == 0, VMASR_EINVAL, "%s: d_inner / %d must be a power of two <= 64 (d_inner %d)", what, CH, D);
+    const int P = D <= 128 ? 64 : (D <= 256 ? 32 : 16);
+    VMASR_REQUIRE(D <= 512 && L % P == 0, VMASR_EINVAL, "%s: needs d_inner <= 512 and H*W %% %d == 0", what, P);
+    g = GlueGeom{B, D, L, P, nch, 0.f};
+    return 0;
+}
+
+#define GLUE_DISPATCH_CH(KERNEL, T, KID, BYTES, SM, ...)                                                             \
+    do {                                                                                                             \
+        const dim3 grid(g.L / g.P, g.B);                                                                             \
+        if (CH == 8) VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 8>), grid, dim3(256), SM, st, __VA_ARGS__, g);              \
+        else if (CH == 4) VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 4>), grid, dim3(256), SM, st, __VA_ARGS__, g);         \
+        else if (CH == 2) VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2>), grid, dim3(256), SM, st, __VA_ARGS__, g);         \
+        else VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 1>), grid, dim3(256), SM, st, __VA_ARGS__, g);                      \
+    } while (0)
+
+#define GLUE_DISPATCH(KERNEL, KID, BYTES, SM, ...)                                                                   \
+    do {                                                                                                             \
+        if (dtype == VMASR_F32) { using T = float; GLUE_DISPATCH_CH(KERNEL, T, KID, BYTES, SM, GLUE_ARGS(float)); }   \
+        else if (dtype == VMASR_F16) { using T = f16_t; GLUE_DISPATCH_CH(KERNEL, T, KID, BYTES, SM, GLUE_ARGS(f16_t)); } \
+        else { using T = bf16_t; GLUE_DISPATCH_CH(KERNEL, T, KID, BYTES, SM, GLUE_ARGS(bf16_t)); }                    \
+    } while (0)
+
+}  // namespace
+}  // namespace vmasr
+
+using namespace vmasr;
+
+VMASR_EXPORT int vmasr_ss2d_glue_supported(int32_t D, int32_t L, int32_t dtype) {
+    GlueGeom g;
+    int CH;
+    const int esz = dtype == VMASR_F32 ? 4 : 2;
+    if (D <= 0 || L <= 0 || D > 512) return 0;
+    const int V = 16 / esz;
+    int ch = D % V == 0 ? V : (D % 4 == 0 ? 4 : (D % 2 == 0 ? 2 : 1));
+    if (esz == 4 && ch > 4) ch = 4;
+    const int nch = D / ch;
+    if (nch > 64 || (nch & (nch - 1))) return 0;
+    const int P = D <= 128 ? 64 : (D <= 256 ? 32 : 16);
+    (void)g; (void)CH;
+    return L % P == 0 ? 1 : 0;
+}
+
+VMASR_EXPORT int vmasr_ss2d_pre_fwd(const void *xz, void *xT, void *sz, int32_t B, int32_t D, int32_t L, int32_t dtype,
+                                    vmasr_stream_t stream) {
+    GlueGeom g;
+    int CH;
+    const int esz = dtype == VMASR_F32 ? 4 : 2;
+    if (int e = plan(B, D, L, esz, g, CH, "ss2d_pre_fwd")) return e;
+    VMASR_REQUIRE(xz && xT && sz, VMASR_EINVAL, "ss2d_pre_fwd: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t sm = (size_t)D * (g.P + 1) * sizeof(float);
+    const double bytes = (double)B * L * D * esz * 4;
+#define GLUE_ARGS(TT) static_cast<const TT *>(xz), static_cast<TT *>(xT), static_cast<TT *>(sz)
+    GLUE_DISPATCH(ss2d_pre_fwd_kernel, VMASR_K_SS2D_PRE, bytes, sm);
+#undef GLUE_ARGS
+    return check_launch("ss2d_pre_fwd");
+}
+
+VMASR_EXPORT int vmasr_ss2d_pre_bwd(const void *xz, const void *dxT, const void *dsz, void *dxz, int32_t B, int32_t D, int32_t L,
+                                    int32_t dtype, vmasr_stream_t stream) {
+    GlueGeom g;
+    int CH;
+    const int esz = dtype == VMASR_F32 ? 4 : 2;
+    if (int e = plan(B, D, L, esz, g, CH, "ss2d_pre_bwd")) return e;
+    VMASR_REQUIRE(xz && dxT && dsz && dxz, VMASR_EINVAL, "ss2d_pre_bwd: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t sm = (size_t)D * (g.P + 1) * sizeof(float);
+    const double bytes = (double)B * L * D * esz * 5;
+#define GLUE_ARGS(TT) static_cast<const TT *>(xz), static_cast<const TT *>(dxT), static_cast<const TT *>(dsz), static_cast<TT *>(dxz)
+    GLUE_DISPATCH(ss2d_pre_bwd_kernel, VMASR_K_SS2D_PRE, bytes, sm);
+#undef GLUE_ARGS
+    return check_launch("ss2d_pre_bwd");
+}
+
+VMASR_EXPORT int vmasr_ln_gate_fwd(const float *y, const void *sz, const float *gamma, const float *beta, void *out, float *mean,
+                                   float *rstd, int32_t B, int32_t D, int32_t L, float eps, int32_t dtype, vmasr_stream_t stream) {
+    GlueGeom g;
+    int CH;
+    const int esz = dtype == VMASR_F32 ? 4 : 2;
+    if (int e = plan(B, D, L, esz, g, CH, "ln_gate_fwd")) return e;
+    VMASR_REQUIRE(y && sz && gamma && beta && out && mean && rstd, VMASR_EINVAL, "ln_gate_fwd: null tensor");
+    g.eps = eps;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t sm = ((size_t)D * (g.P + 1) + 256 + 2 * g.P) * sizeof(float);
+    const double bytes = (double)B * L * D * (4 + 2 * esz);
+#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), gamma, beta, static_cast<TT *>(out), mean, rstd
+    GLUE_DISPATCH(ln_gate_fwd_kernel, VMASR_K_LN_GATE, bytes, sm);
+#undef GLUE_ARGS
+    return check_launch("ln_gate_fwd");
+}
+
+VMASR_EXPORT int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta,
+                                   const float *mean, const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta,
+                                   int32_t B, int32_t D, int32_t L, int32_t dtype, vmasr_stream_t stream) {
+    GlueGeom g;
+    int CH;
+    const int esz = dtype == VMASR_F32 ? 4 : 2;
+    if (int e = plan(B, D, L, esz, g, CH, "ln_gate_bwd")) return e;
+    VMASR_REQUIRE(y && sz && dout && gamma && beta && mean && rstd && dy && dsz && dgamma && dbeta, VMASR_EINVAL,
+                  "ln_gate_bwd: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t sm = ((size_t)D * (g.P + 1) + 2 * D) * sizeof(float);
+    const double bytes = (double)B * L * D * (8 + 3 * esz);
+#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta
+    GLUE_DISPATCH(ln_gate_bwd_kernel, VMASR_K_LN_GATE, bytes, sm);
+#undef GLUE_ARGS
+    return check_launch("ln_gate_bwd");
+}

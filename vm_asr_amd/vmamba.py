@@ -31,6 +31,7 @@ import torch.utils.checkpoint as checkpoint
 
 from .csm import CrossMergeHIP, CrossScanF32, CrossScanHIP
 from . import ss2d_core as _ss2d
+from . import ss2d_glue as _glue
 from . import xproj as _xproj
 from .dwconv import dwconv3x3_silu
 from .layernorm import LayerNorm
@@ -267,7 +268,9 @@ class SS2D(nn.Module):
     # ---- core (model/vmamba.py:1377-1531) --------------------------------------------------
     def forward_corev2(self, x: torch.Tensor = None, delta_softplus=True, to_dtype=True, force_fp32=False,
                        nrows=-1, backnrows=-1, ssoflex=True, SelectiveScan=None, CrossScan=CrossScanHIP,
-                       CrossMerge=CrossMergeHIP, no_einsum=False, **kwargs):
+                       CrossMerge=CrossMergeHIP, no_einsum=False, merged_only=False, **kwargs):
+        """merged_only: return the cross-merged (B, D, L) fp32 tensor and leave out_norm to the caller (the fused
+        LayerNorm-gate operator of forward())."""
         x_proj_weight, dt_projs_weight, dt_projs_bias = self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias
         A_logs, Ds = self.A_logs, self.Ds
         out_norm = getattr(self, "out_norm", None)
@@ -282,7 +285,7 @@ class SS2D(nn.Module):
             # the whole core (cross-scan, x_proj, dt_proj, 4 scans, cross-merge) as one fused operator: the
             # high-resolution stages (d_state 1, dt_rank 1, d_inner <= 32) — csrc/ss2d.hip
             y = _ss2d.ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
-            return self._merge_norm(y, x, B, H, W, to_dtype)
+            return y if merged_only else self._merge_norm(y, x, B, H, W, to_dtype)
         if (hip_default and _xproj.supported(N, R, D) and D <= 32):
             # (D <= 32: the map is parallel over positions only; the deep stages have few positions and
             #  D = 64..256 rows, where the batched-GEMM einsums below are the better fit)
@@ -293,7 +296,8 @@ class SS2D(nn.Module):
             ys = SelectiveScan.apply(xs.view(B, -1, L), dts, -torch.exp(A_logs.to(torch.float)), Bs, Cs,
                                      Ds.to(torch.float), dt_projs_bias.view(-1).to(torch.float), delta_softplus,
                                      nrows, backnrows, ssoflex).view(B, K, -1, H, W)
-            return self._merge_norm(CrossMerge.apply(ys), x, B, H, W, to_dtype)
+            y = CrossMerge.apply(ys)
+            return y if merged_only else self._merge_norm(y, x, B, H, W, to_dtype)
 
         xs = CrossScan.apply(x)  # (B, K, D, L)
         if no_einsum:
@@ -319,7 +323,8 @@ class SS2D(nn.Module):
 
         ys = SelectiveScan.apply(xs, dts, As, Bs, Cs, Ds, delta_bias, delta_softplus, nrows, backnrows,
                                  ssoflex).view(B, K, -1, H, W)
-        return self._merge_norm(CrossMerge.apply(ys), x, B, H, W, to_dtype)
+        y = CrossMerge.apply(ys)
+        return y if merged_only else self._merge_norm(y, x, B, H, W, to_dtype)
 
     def _merge_norm(self, y, x, B, H, W, to_dtype):
         """out_norm on the merged (B, D, L) tensor -> (B, H, W, D)  (model/vmamba.py:1517-1531)."""
@@ -350,8 +355,25 @@ class SS2D(nn.Module):
             raise RuntimeError("SS2D: vm_asr_amd has no CPU path (expected a CUDA/HIP tensor)")
         return self.act(self.conv2d(x))  # non-default kernel size / activation: MIOpen
 
+    def _fused_glue_ok(self, x):
+        """The HIP glue operators apply: GPU, channel-last, default operator set (no test hooks), z gate with SiLU,
+        3x3 conv, channel-last LayerNorm as out_norm."""
+        fc = self.forward_core
+        return (x.is_cuda and not self.channel_first and not self.disable_z and not self.disable_z_act and self._act_is_silu
+                and self.d_conv == 3 and self.out_norm_shape == "v0" and isinstance(self.out_norm, LayerNorm)
+                and getattr(self, "conv_act_fn", None) is None and isinstance(fc, partial)
+                and fc.keywords.get("SelectiveScan") is SelectiveScanCore and fc.keywords.get("CrossScan") is CrossScanHIP
+                and fc.keywords.get("CrossMerge") is CrossMergeHIP and fc.keywords.get("force_fp32", False))
+
     def forward(self, x: torch.Tensor, **kwargs):
         x = self.in_proj(x)
+        if x.dim() == 4 and self._fused_glue_ok(x) and _glue.supported(self.d_inner, x.shape[1] * x.shape[2], x.dtype):
+            # chunk + SiLU(z) + layout copy as one kernel; LayerNorm + cast + gate (and the layout copy in front of
+            # them) as another (csrc/ss2d_glue.hip)
+            xT, sz = _glue.ss2d_pre(x)
+            y = self.forward_core(self._conv_act(xT), merged_only=True)           # (B, D, L) fp32
+            y = _glue.ln_gate(y, sz, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
+            return self.dropout(self.out_proj(y))
         z = None
         if not self.disable_z:
             x, z = x.chunk(2, dim=(1 if self.channel_first else -1))
