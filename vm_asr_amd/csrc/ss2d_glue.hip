@@ -234,6 +234,173 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float *__restric
     }
 }
 
+// ---- direct variants for d_inner <= 32 (the high-resolution stages: most of the bytes) ---------------------------------
+// One THREAD owns one position and keeps its D channels in registers: the channel-first side is read / written with
+// one coalesced 4-byte access per channel (64 consecutive positions per wave), the channel-last side as the thread's
+// own contiguous row; LayerNorm needs no cross-thread reduction and there is no LDS tile and no barrier on the data
+// path.  The backward walks kIter x 256 positions per workgroup so that the per-channel dgamma / dbeta partials are
+// wave-reduced once per workgroup.
+template <typename T, int D>
+struct RowIO {
+    static constexpr int V = 16 / (int)sizeof(T);
+    static constexpr int CH = D < V ? D : V;
+    __device__ static __forceinline__ void load(const T *__restrict__ p, float (&v)[D]) {
+#pragma unroll
+        for (int c = 0; c < D / CH; ++c) {
+            float t[CH];
+            load_chunk<T, CH>(p + c * CH, t);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) v[c * CH + e] = t[e];
+        }
+    }
+    __device__ static __forceinline__ void store(T *__restrict__ p, const float (&v)[D]) {
+#pragma unroll
+        for (int c = 0; c < D / CH; ++c) {
+            float t[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) t[e] = v[c * CH + e];
+            store_chunk<T, CH>(p + c * CH, t);
+        }
+    }
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ss2d_pre_fwd_direct(const T *__restrict__ xz, T *__restrict__ xT, T *__restrict__ sz,
+                                                           const int L) {
+    const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    const size_t row = (size_t)b * L + l;
+    float xv[D], zv[D];
+    RowIO<T, D>::load(xz + row * 2 * D, xv);
+    RowIO<T, D>::load(xz + row * 2 * D + D, zv);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xT[((size_t)b * D + d) * L + l] = from_f32<T>(xv[d]);
+        zv[d] = zv[d] * sigmoid_f(zv[d]);
+    }
+    RowIO<T, D>::store(sz + row * D, zv);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ss2d_pre_bwd_direct(const T *__restrict__ xz, const T *__restrict__ dxT,
+                                                           const T *__restrict__ dsz, T *__restrict__ dxz, const int L) {
+    const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    const size_t row = (size_t)b * L + l;
+    float dx[D], zv[D], gz[D];
+    RowIO<T, D>::load(xz + row * 2 * D + D, zv);
+    RowIO<T, D>::load(dsz + row * D, gz);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        dx[d] = to_f32(dxT[((size_t)b * D + d) * L + l]);
+        const float s = sigmoid_f(zv[d]);
+        gz[d] *= s * fmaf(zv[d], 1.f - s, 1.f);
+    }
+    RowIO<T, D>::store(dxz + row * 2 * D, dx);
+    RowIO<T, D>::store(dxz + row * 2 * D + D, gz);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ln_gate_fwd_direct(const float *__restrict__ y, const T *__restrict__ sz,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          T *__restrict__ out, float *__restrict__ mean, float *__restrict__ rstd,
+                                                          const int L, const float eps) {
+    const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    const size_t row = (size_t)b * L + l;
+    float v[D], zv[D];
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { v[d] = y[((size_t)b * D + d) * L + l]; s += v[d]; }
+    const float mu = s * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { v[d] -= mu; q = fmaf(v[d], v[d], q); }
+    const float rs = rsqrtf(q * (1.f / D) + eps);
+    RowIO<T, D>::load(sz + row * D, zv);
+#pragma unroll
+    for (int d = 0; d < D; ++d) zv[d] *= fmaf(v[d] * rs, gamma[d], beta[d]);
+    RowIO<T, D>::store(out + row * D, zv);
+    mean[row] = mu;
+    rstd[row] = rs;
+}
+
+constexpr int kGlueIter = 4;
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ln_gate_bwd_direct(const float *__restrict__ y, const T *__restrict__ sz,
+                                                          const T *__restrict__ dout, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, const float *__restrict__ mean,
+                                                          const float *__restrict__ rstd, float *__restrict__ dy,
+                                                          T *__restrict__ dsz, float *__restrict__ dgamma,
+                                                          float *__restrict__ dbeta, const int L) {
+    __shared__ float acc[2 * D];
+    const int b = blockIdx.y;
+    if (threadIdx.x < 2 * D) acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    float dg[D], db[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { dg[d] = 0.f; db[d] = 0.f; }
+#pragma unroll 1
+    for (int k = 0; k < kGlueIter; ++k) {
+        const int l = (blockIdx.x * kGlueIter + k) * 256 + threadIdx.x;
+        if (l >= L) break;
+        const size_t row = (size_t)b * L + l;
+        const float m = mean[row], r = rstd[row];
+        float xh[D], zv[D], go[D];
+        RowIO<T, D>::load(sz + row * D, zv);
+        RowIO<T, D>::load(dout + row * D, go);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            xh[d] = (y[((size_t)b * D + d) * L + l] - m) * r;
+            const float a = fmaf(xh[d], gamma[d], beta[d]);
+            const float gl = go[d] * zv[d];
+            zv[d] = go[d] * a;                   // d sz
+            dg[d] = fmaf(gl, xh[d], dg[d]);
+            db[d] += gl;
+            go[d] = gl * gamma[d];               // g
+            s1 += go[d];
+            s2 = fmaf(go[d], xh[d], s2);
+        }
+        RowIO<T, D>::store(dsz + row * D, zv);
+        s1 *= (1.f / D);
+        s2 *= (1.f / D);
+#pragma unroll
+        for (int d = 0; d < D; ++d) dy[((size_t)b * D + d) * L + l] = r * (go[d] - s1 - xh[d] * s2);
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float a = wave_sum(dg[d]), c = wave_sum(db[d]);
+        if (lane == 0) { atomicAdd(&acc[d], a); atomicAdd(&acc[D + d], c); }
+    }
+    __syncthreads();
+    if (threadIdx.x < D) atomicAdd(dgamma + threadIdx.x, acc[threadIdx.x]);
+    else if (threadIdx.x < 2 * D) atomicAdd(dbeta + threadIdx.x - D, acc[threadIdx.x]);
+}
+
+#define GLUE_DIRECT_D(KERNEL, T, KID, BYTES, GRIDX, ...)                                                              \
+    do {                                                                                                             \
+        const dim3 grid(GRIDX, B);                                                                                   \
+        switch (D) {                                                                                                 \
+            case 2: VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2>), grid, dim3(256), 0, st, __VA_ARGS__); break;            \
+            case 4: VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 4>), grid, dim3(256), 0, st, __VA_ARGS__); break;            \
+            case 8: VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 8>), grid, dim3(256), 0, st, __VA_ARGS__); break;            \
+            case 16: VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 16>), grid, dim3(256), 0, st, __VA_ARGS__); break;          \
+            default: VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 32>), grid, dim3(256), 0, st, __VA_ARGS__);                 \
+        }                                                                                                            \
+    } while (0)
+
+#define GLUE_DIRECT(KERNEL, KID, BYTES, GRIDX)                                                                       \
+    do {                                                                                                             \
+        if (dtype == VMASR_F32) GLUE_DIRECT_D(KERNEL, float, KID, BYTES, GRIDX, GLUE_ARGS(float));                   \
+        else if (dtype == VMASR_F16) GLUE_DIRECT_D(KERNEL, f16_t, KID, BYTES, GRIDX, GLUE_ARGS(f16_t));              \
+        else GLUE_DIRECT_D(KERNEL, bf16_t, KID, BYTES, GRIDX, GLUE_ARGS(bf16_t));                                    \
+    } while (0)
+
+inline bool direct_ok(int D) { return D == 2 || D == 4 || D == 8 || D == 16 || D == 32; }
+
 int plan(int B, int D, int L, int esz, GlueGeom &g, int &CH, const char *what) {
     VMASR_REQUIRE(B > 0 && D > 0 && L > 0, VMASR_EINVAL, "%s: non-positive size", what);
     VMASR_REQUIRE(B <= 65535, VMASR_EINVAL, "%s: batch too large", what);
@@ -294,6 +461,12 @@ VMASR_EXPORT int vmasr_ss2d_pre_fwd(const void *xz, void *xT, void *sz, int32_t 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t sm = (size_t)D * (g.P + 1) * sizeof(float);
     const double bytes = (double)B * L * D * esz * 4;
+    if (direct_ok(D)) {
+#define GLUE_ARGS(TT) static_cast<const TT *>(xz), static_cast<TT *>(xT), static_cast<TT *>(sz), L
+        GLUE_DIRECT(ss2d_pre_fwd_direct, VMASR_K_SS2D_PRE, bytes, (L + 255) / 256);
+#undef GLUE_ARGS
+        return check_launch("ss2d_pre_fwd");
+    }
 #define GLUE_ARGS(TT) static_cast<const TT *>(xz), static_cast<TT *>(xT), static_cast<TT *>(sz)
     GLUE_DISPATCH(ss2d_pre_fwd_kernel, VMASR_K_SS2D_PRE, bytes, sm);
 #undef GLUE_ARGS
@@ -310,6 +483,12 @@ VMASR_EXPORT int vmasr_ss2d_pre_bwd(const void *xz, const void *dxT, const void 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t sm = (size_t)D * (g.P + 1) * sizeof(float);
     const double bytes = (double)B * L * D * esz * 5;
+    if (direct_ok(D)) {
+#define GLUE_ARGS(TT) static_cast<const TT *>(xz), static_cast<const TT *>(dxT), static_cast<const TT *>(dsz), static_cast<TT *>(dxz), L
+        GLUE_DIRECT(ss2d_pre_bwd_direct, VMASR_K_SS2D_PRE, bytes, (L + 255) / 256);
+#undef GLUE_ARGS
+        return check_launch("ss2d_pre_bwd");
+    }
 #define GLUE_ARGS(TT) static_cast<const TT *>(xz), static_cast<const TT *>(dxT), static_cast<const TT *>(dsz), static_cast<TT *>(dxz)
     GLUE_DISPATCH(ss2d_pre_bwd_kernel, VMASR_K_SS2D_PRE, bytes, sm);
 #undef GLUE_ARGS
@@ -327,6 +506,12 @@ VMASR_EXPORT int vmasr_ln_gate_fwd(const float *y, const void *sz, const float *
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t sm = ((size_t)D * (g.P + 1) + 256 + 2 * g.P) * sizeof(float);
     const double bytes = (double)B * L * D * (4 + 2 * esz);
+    if (direct_ok(D)) {
+#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), gamma, beta, static_cast<TT *>(out), mean, rstd, L, eps
+        GLUE_DIRECT(ln_gate_fwd_direct, VMASR_K_LN_GATE, bytes, (L + 255) / 256);
+#undef GLUE_ARGS
+        return check_launch("ln_gate_fwd");
+    }
 #define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), gamma, beta, static_cast<TT *>(out), mean, rstd
     GLUE_DISPATCH(ln_gate_fwd_kernel, VMASR_K_LN_GATE, bytes, sm);
 #undef GLUE_ARGS
@@ -345,6 +530,12 @@ VMASR_EXPORT int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *d
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t sm = ((size_t)D * (g.P + 1) + 2 * D) * sizeof(float);
     const double bytes = (double)B * L * D * (8 + 3 * esz);
+    if (direct_ok(D)) {
+#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta, L
+        GLUE_DIRECT(ln_gate_bwd_direct, VMASR_K_LN_GATE, bytes, (L + 256 * kGlueIter - 1) / (256 * kGlueIter));
+#undef GLUE_ARGS
+        return check_launch("ln_gate_bwd");
+    }
 #define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta
     GLUE_DISPATCH(ln_gate_bwd_kernel, VMASR_K_LN_GATE, bytes, sm);
 #undef GLUE_ARGS
