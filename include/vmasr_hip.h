@@ -269,7 +269,7 @@ int vmasr_ss2d_bwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
  * ln_gate  : y (B, D, L) fp32, sz -> out (B*L, D) = LayerNorm_D(y^T; gamma, beta, eps) * sz, mean / rstd (B*L) fp32
  *            (replaces transpose.contiguous + LayerNorm + cast + multiply); _bwd: dout -> dy (B, D, L) fp32, dsz,
  *            dgamma / dbeta (D) fp32 ACCUMULATED with atomics (caller zero-initialises)
- * `dtype` is the type of xz / xT / sz / out / dout / dsz; D <= 512, L a multiple of 64 / 32 / 16 for D <= 128 / 256 / 512. */
+ * `dtype` is the type of xz / xT / sz / out / dout / dsz; D <= 512, L a multiple of 64 (D <= 32) or 16. */
 int vmasr_ss2d_glue_supported(int32_t D, int32_t L, int32_t dtype);
 int vmasr_ss2d_pre_fwd(const void *xz, void *xT, void *sz, int32_t B, int32_t D, int32_t L, int32_t dtype, vmasr_stream_t stream);
 int vmasr_ss2d_pre_bwd(const void *xz, const void *dxT, const void *dsz, void *dxz, int32_t B, int32_t D, int32_t L, int32_t dtype,

@@ -25,7 +25,9 @@ struct GlueGeom {
     float eps;
 };
 
-__device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+// accurate exp and a true division: these kernels are memory-bound, and the generator ends in a LayerNorm over two
+// channels that amplifies every rounding error upstream (tests/test_fullsize.py) — no fast-math shortcuts here
+__device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + expf(-z)); }
 
 template <typename T, int CH>
 __device__ __forceinline__ void load_chunk(const T *__restrict__ p, float (&v)[CH]) {
@@ -409,7 +411,9 @@ int plan(int B, int D, int L, int esz, GlueGeom &g, int &CH, const char *what) {
     if (esz == 4 && CH > 4) CH = 4;
     const int nch = D / CH;
     VMASR_REQUIRE(nch <= 64 && (nch & (nch - 1)) == 0, VMASR_EINVAL, "%s: d_inner / %d must be a power of two <= 64 (d_inner %d)", what, CH, D);
-    const int P = D <= 128 ? 64 : (D <= 256 ? 32 : 16);
+    // (the LDS-tile kernels serve d_inner >= 64, the deep stages with few positions: 16 positions per workgroup
+    //  keep >= 128 workgroups in flight there; d_inner <= 32 runs the direct kernels)
+    const int P = D <= 32 ? 64 : 16;
     VMASR_REQUIRE(D <= 512 && L % P == 0, VMASR_EINVAL, "%s: needs d_inner <= 512 and H*W %% %d == 0", what, P);
     g = GlueGeom{B, D, L, P, nch, 0.f};
     return 0;
@@ -446,7 +450,7 @@ VMASR_EXPORT int vmasr_ss2d_glue_supported(int32_t D, int32_t L, int32_t dtype) 
     if (esz == 4 && ch > 4) ch = 4;
     const int nch = D / ch;
     if (nch > 64 || (nch & (nch - 1))) return 0;
-    const int P = D <= 128 ? 64 : (D <= 256 ? 32 : 16);
+    const int P = D <= 32 ? 64 : 16;
     (void)g; (void)CH;
     return L % P == 0 ? 1 : 0;
 }
