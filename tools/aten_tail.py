@@ -1,0 +1,34 @@
+"""Which ATen ops make up the elementwise/copy tail of one eager train step (dev tool): torch.profiler, grouped by op and
+input shape, sorted by device time.   usage: python tools/aten_tail.py [top]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+top = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+cfg = bench.make_config("vm_asr_48k_MPD", 0)
+dev = torch.device("cuda", 0)
+tr = bench.build_trainer(cfg, dev, amp=True, capturable=False)
+for m in tr.models.values():
+    m.train()
+batch = bench.synth_batch(cfg, dev, 0)
+for _ in range(3):
+    tr.train_step(*batch)
+torch.cuda.synchronize()
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    tr.train_step(*batch)
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    dt = getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0)
+    if dt > 0:
+        rows.append((dt, e.count, e.key, str(e.input_shapes)[:110]))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f"total self device time {tot / 1e3:.2f} ms over {sum(r[1] for r in rows)} op calls")
+for dt, n, k, sh in rows[:top]:
+    print(f"{dt / 1e3:8.3f} ms {n:5d}  {k:40s} {sh}")
