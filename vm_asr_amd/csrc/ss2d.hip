@@ -143,8 +143,10 @@ struct FwdArgs {
 // Workgroup = TPG tiles x WPT waves; wave `wr` of a tile owns rows d0 .. d0+RW-1; blockIdx.y = pair (0: dirs 0,2 on x;
 // 1: dirs 1,3 on xT).  Direction p scans the tile's positions upwards, p+2 downwards; scan-order tile of the latter
 // is ntiles-1-j.
+// (launch bounds: 4 waves per SIMD = two 512-thread or four 256-thread workgroups per CU, so that one workgroup's
+//  load + LDS-reduce latency is covered by another's scan arithmetic; the apply kernel sits at 132-140 VGPRs without it)
 template <typename T, int RW, int WPT, int TPG, int MODE>
-__global__ __launch_bounds__(64 * WPT * TPG) void ss2d_fwd_kernel(const FwdArgs a, const Geo g) {
+__global__ __launch_bounds__(64 * WPT * TPG, 4) void ss2d_fwd_kernel(const FwdArgs a, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) float4 s_lds[];
     float4 *red = s_lds, *sums = s_lds + (WPT > 1 ? (size_t)TPG * WPT * 6 * 64 : 0);
     const int lane = threadIdx.x & 63;
@@ -288,8 +290,10 @@ struct BwdArgs {
 };
 constexpr int kNPart = 8;  // dWx[0..2], dWdt, dbias, dA, dD, (pad)
 
+// (two rows per wave: the backward keeps ~60 live values per row; with four rows the allocator needs 250 VGPRs = one
+//  workgroup of 2 waves per SIMD per CU.  d_inner 32 is then one 1024-thread workgroup: 4 waves per SIMD, <= 128 VGPRs)
 template <typename T, int RW, int WPT, int TPG, int MODE>
-__global__ __launch_bounds__(64 * WPT * TPG) void ss2d_bwd_kernel(const BwdArgs q, const Geo g) {
+__global__ __launch_bounds__(64 * WPT * TPG, (64 * WPT * TPG) >= 512 ? 4 : 3) void ss2d_bwd_kernel(const BwdArgs q, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) float4 s_lds[];
     float4 *red = s_lds, *sums = s_lds + (WPT > 1 ? (size_t)TPG * WPT * 6 * 64 : 0);
     const FwdArgs &a = q.f;
@@ -489,8 +493,8 @@ int check(const vmasr_ss2d_params &p, const char *what) {
 struct Cfg {
     int RW, WPT, TPG;
 };
-Cfg cfg_for(int D) {
-    const int RW = D >= 4 ? 4 : D;
+Cfg cfg_for(int D, bool bwd = false) {
+    const int RW = bwd ? 2 : (D >= 4 ? 4 : D);
     const int WPT = D / RW;
     return {RW, WPT, WPT >= 4 ? 1 : 4 / WPT};
 }
@@ -504,6 +508,30 @@ void launch_transpose(const TI *x, TO *xt, int planes, int H, int W, hipStream_t
     VMASR_LAUNCH(VMASR_K_SS2D_TRANSPOSE, (double)planes * H * W * (sizeof(TI) + sizeof(TO)), (transpose_hw_kernel<TI, TO>), grid,
                  dim3(256), 0, st, x, xt, H, W);
 }
+
+// backward: RW = 2 -> WPT = D/2 in {1, 2, 4, 8, 16}
+#define SS2D_DISPATCH_BWD(KERNEL, MODE, KID, BYTES, ARGS)                                                               \
+    do {                                                                                                                \
+        const dim3 grid(p.B * geo.tile_groups, 2);                                                                      \
+        const dim3 block(64 * c.WPT * c.TPG);                                                                           \
+        if (c.WPT == 1)                                                                                                 \
+            VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 1, 4, MODE>), grid, block, sm, st, ARGS, geo);                        \
+        else if (c.WPT == 2)                                                                                            \
+            VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 2, 2, MODE>), grid, block, sm, st, ARGS, geo);                        \
+        else if (c.WPT == 4)                                                                                            \
+            VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 4, 1, MODE>), grid, block, sm, st, ARGS, geo);                        \
+        else if (c.WPT == 8)                                                                                            \
+            VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 8, 1, MODE>), grid, block, sm, st, ARGS, geo);                        \
+        else {                                                                                                          \
+            static bool once = [] {                                                                                     \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<T, 2, 16, 1, MODE>),                    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);                      \
+                return true;                                                                                            \
+            }();                                                                                                        \
+            (void)once;                                                                                                 \
+            VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 16, 1, MODE>), grid, block, sm, st, ARGS, geo);                       \
+        }                                                                                                               \
+    } while (0)
 
 #define SS2D_DISPATCH(KERNEL, MODE, KID, BYTES, ARGS)                                                                   \
     do {                                                                                                                \
@@ -550,18 +578,18 @@ int run_fwd(const vmasr_ss2d_params &p, hipStream_t st) {
 template <typename T>
 int run_bwd(const vmasr_ss2d_params &p, hipStream_t st) {
     const int L = p.H * p.W, ntiles = L / kTile;
-    const Cfg c = cfg_for(p.D);
+    const Cfg c = cfg_for(p.D, true);
     VMASR_REQUIRE(ntiles % c.TPG == 0, VMASR_EINVAL, "ss2d_bwd: tile count must be a multiple of %d", c.TPG);
     const Geo geo{p.B, p.D, L, ntiles, ntiles / c.TPG};
     const size_t sm = lds_bytes(c);
     launch_transpose<float, float>(p.dy, p.dyT, p.B * p.D, p.H, p.W, st);
     BwdArgs q{{p.x, p.xT, p.Wx, p.Wdt, p.dtb, p.Alog, p.Ds, p.state, nullptr, nullptr}, p.dy, p.dyT, p.adj, p.out02, p.out13, p.part};
     const double el = (double)p.B * p.D * L, pos = (double)p.B * L;
-    SS2D_DISPATCH(ss2d_bwd_kernel, 0, VMASR_K_SS2D_BWD_AGG, 2.0 * el * (sizeof(T) + 4), q);
+    SS2D_DISPATCH_BWD(ss2d_bwd_kernel, 0, VMASR_K_SS2D_BWD_AGG, 2.0 * el * (sizeof(T) + 4), q);
     const int nseq = p.B * 4 * p.D;
     VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nseq * ntiles * 16, (ss2d_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st,
                  p.adj, nseq, ntiles);
-    SS2D_DISPATCH(ss2d_bwd_kernel, 1, VMASR_K_SS2D_BWD_APPLY, (5.0 * 4 * el + 4.0 * 4 * pos) * 4, q);
+    SS2D_DISPATCH_BWD(ss2d_bwd_kernel, 1, VMASR_K_SS2D_BWD_APPLY, (5.0 * 4 * el + 4.0 * 4 * pos) * 4, q);
     const int nwg = p.B * ntiles;
     VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nwg * 4 * p.D * kNPart * 4, ss2d_bwd_reduce_kernel, dim3((4 * p.D + 3) / 4), dim3(256), 0, st,
                  p.part, nwg, p.D, p.dWx, p.dWdt, p.ddtb, p.dAlog, p.dDs);
@@ -582,8 +610,8 @@ VMASR_EXPORT int vmasr_ss2d_supported(int32_t d_state, int32_t dt_rank, int32_t 
     if (!(d_inner == 2 || d_inner == 4 || d_inner == 8 || d_inner == 16 || d_inner == 32)) return 0;
     const long L = (long)H * W;
     if (L % kTile) return 0;
-    const Cfg c = cfg_for(d_inner);
-    return ((L / kTile) % c.TPG == 0) ? 1 : 0;
+    const Cfg c = cfg_for(d_inner), cb = cfg_for(d_inner, true);
+    return ((L / kTile) % c.TPG == 0 && (L / kTile) % cb.TPG == 0) ? 1 : 0;
 }
 
 VMASR_EXPORT size_t vmasr_ss2d_part_floats(int32_t B, int32_t D, int32_t H, int32_t W) {
