@@ -223,10 +223,17 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float *__restric
 #pragma unroll
         for (int e = 0; e < CH; ++e) tile[(c * CH + e) * (g.P + 1) + pp] = r * (gg[e] - s1 * invD - xh[e] * s2 * invD);
     }
+    // lanes l, l + nch, l + 2 nch, ... of a wave hold the same channels: fold them first (one LDS atomic per wave and channel)
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
-        atomicAdd(&acc[c * CH + e], dg[e]);
-        atomicAdd(&acc[g.D + c * CH + e], db[e]);
+        for (int off = g.nch; off < 64; off <<= 1) {
+            dg[e] += __shfl_xor(dg[e], off);
+            db[e] += __shfl_xor(db[e], off);
+        }
+        if ((threadIdx.x & 63) < g.nch) {
+            atomicAdd(&acc[c * CH + e], dg[e]);
+            atomicAdd(&acc[g.D + c * CH + e], db[e]);
+        }
     }
     __syncthreads();
     tile_to_rows<float>(tile, dy, g, b, l0);
@@ -327,7 +334,8 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_direct(const float *__restric
     rstd[row] = rs;
 }
 
-constexpr int kGlueIter = 4;
+constexpr int kGlueMaxBlocks = 64;   // workgroups per batch element of the direct backward (bounds the same-address
+                                     // atomics of dgamma / dbeta: 2 D per workgroup)
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void ln_gate_bwd_direct(const float *__restrict__ y, const T *__restrict__ sz,
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_direct(const float *__restric
                                                           const float *__restrict__ beta, const float *__restrict__ mean,
                                                           const float *__restrict__ rstd, float *__restrict__ dy,
                                                           T *__restrict__ dsz, float *__restrict__ dgamma,
-                                                          float *__restrict__ dbeta, const int L) {
+                                                          float *__restrict__ dbeta, const int L, const int iters) {
     __shared__ float acc[2 * D];
     const int b = blockIdx.y;
     if (threadIdx.x < 2 * D) acc[threadIdx.x] = 0.f;
@@ -344,8 +352,8 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_direct(const float *__restric
 #pragma unroll
     for (int d = 0; d < D; ++d) { dg[d] = 0.f; db[d] = 0.f; }
 #pragma unroll 1
-    for (int k = 0; k < kGlueIter; ++k) {
-        const int l = (blockIdx.x * kGlueIter + k) * 256 + threadIdx.x;
+    for (int k = 0; k < iters; ++k) {
+        const int l = (k * gridDim.x + blockIdx.x) * 256 + threadIdx.x;   // consecutive workgroups take consecutive chunks
         if (l >= L) break;
         const size_t row = (size_t)b * L + l;
         const float m = mean[row], r = rstd[row];
@@ -535,8 +543,9 @@ VMASR_EXPORT int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *d
     const size_t sm = ((size_t)D * (g.P + 1) + 2 * D) * sizeof(float);
     const double bytes = (double)B * L * D * (8 + 3 * esz);
     if (direct_ok(D)) {
-#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta, L
-        GLUE_DIRECT(ln_gate_bwd_direct, VMASR_K_LN_GATE, bytes, (L + 256 * kGlueIter - 1) / (256 * kGlueIter));
+        const int chunks = (L + 255) / 256, nblk = std::min(chunks, kGlueMaxBlocks), iters = (chunks + nblk - 1) / nblk;
+#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta, L, iters
+        GLUE_DIRECT(ln_gate_bwd_direct, VMASR_K_LN_GATE, bytes, nblk);
 #undef GLUE_ARGS
         return check_launch("ln_gate_bwd");
     }
