@@ -290,10 +290,11 @@ struct BwdArgs {
 };
 constexpr int kNPart = 8;  // dWx[0..2], dWdt, dbias, dA, dD, (pad)
 
-// (two rows per wave: the backward keeps ~60 live values per row; with four rows the allocator needs 250 VGPRs = one
-//  workgroup of 2 waves per SIMD per CU.  d_inner 32 is then one 1024-thread workgroup: 4 waves per SIMD, <= 128 VGPRs)
+// (the backward keeps ~60 live values per row: two rows per wave -> 137-150 VGPRs, 3 waves per SIMD; d_inner 32 keeps
+//  four rows per wave (8 waves, 250 VGPRs, one workgroup per CU): as a 1024-thread workgroup of two-row waves it would
+//  have to fit 128 VGPRs and spills — measured 3x the HBM traffic through scratch for no gain in time)
 template <typename T, int RW, int WPT, int TPG, int MODE>
-__global__ __launch_bounds__(64 * WPT * TPG, (64 * WPT * TPG) >= 512 ? 4 : 3) void ss2d_bwd_kernel(const BwdArgs q, const Geo g) {
+__global__ __launch_bounds__(64 * WPT * TPG, (64 * WPT * TPG) >= 512 ? 2 : 3) void ss2d_bwd_kernel(const BwdArgs q, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) float4 s_lds[];
     float4 *red = s_lds, *sums = s_lds + (WPT > 1 ? (size_t)TPG * WPT * 6 * 64 : 0);
     const FwdArgs &a = q.f;
@@ -494,7 +495,7 @@ struct Cfg {
     int RW, WPT, TPG;
 };
 Cfg cfg_for(int D, bool bwd = false) {
-    const int RW = bwd ? 2 : (D >= 4 ? 4 : D);
+    const int RW = (bwd && D < 32) ? 2 : (D >= 4 ? 4 : D);
     const int WPT = D / RW;
     return {RW, WPT, WPT >= 4 ? 1 : 4 / WPT};
 }
@@ -509,7 +510,7 @@ void launch_transpose(const TI *x, TO *xt, int planes, int H, int W, hipStream_t
                  dim3(256), 0, st, x, xt, H, W);
 }
 
-// backward: RW = 2 -> WPT = D/2 in {1, 2, 4, 8, 16}
+// backward: RW = 2 -> WPT = D/2 in {1, 2, 4, 8}; d_inner 32: RW = 4, WPT = 8
 #define SS2D_DISPATCH_BWD(KERNEL, MODE, KID, BYTES, ARGS)                                                               \
     do {                                                                                                                \
         const dim3 grid(p.B * geo.tile_groups, 2);                                                                      \
@@ -520,17 +521,10 @@ void launch_transpose(const TI *x, TO *xt, int planes, int H, int W, hipStream_t
             VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 2, 2, MODE>), grid, block, sm, st, ARGS, geo);                        \
         else if (c.WPT == 4)                                                                                            \
             VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 4, 1, MODE>), grid, block, sm, st, ARGS, geo);                        \
-        else if (c.WPT == 8)                                                                                            \
+        else if (c.WPT == 8 && c.RW == 2)                                                                               \
             VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 8, 1, MODE>), grid, block, sm, st, ARGS, geo);                        \
-        else {                                                                                                          \
-            static bool once = [] {                                                                                     \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<T, 2, 16, 1, MODE>),                    \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);                      \
-                return true;                                                                                            \
-            }();                                                                                                        \
-            (void)once;                                                                                                 \
-            VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 2, 16, 1, MODE>), grid, block, sm, st, ARGS, geo);                       \
-        }                                                                                                               \
+        else   /* d_inner 32: four rows per wave */                                                                     \
+            VMASR_LAUNCH(KID, BYTES, (KERNEL<T, 4, 8, 1, MODE>), grid, block, sm, st, ARGS, geo);                        \
     } while (0)
 
 #define SS2D_DISPATCH(KERNEL, MODE, KID, BYTES, ARGS)                                                                   \
