@@ -243,9 +243,9 @@ int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, v
  * H*W a multiple of 256 (vmasr_ss2d_supported).  All buffers are caller-owned device memory:
  *   x (B,D,H,W) `dtype`;  Wx (4,3,D) = x_proj_weight rows [dt, B, C];  Wdt (4,D) = dt_projs_weight;  dtb (4,D);
  *   Alog (4D) = A_logs (the operator applies A = -exp(Alog));  Ds (4D);            all weights fp32
- *   xT (B,D,W,H) `dtype` scratch (kept for the backward);  state (B,4D,H*W/256,4) fp32 (kept for the backward);
+ *   xT (B,D,W,H) `dtype` scratch (kept for the backward);  state (B,4D,H*W/256,2) fp32 (kept for the backward);
  *   out02, out13 (B,D,H*W) fp32 scratch;  y (B,D,H*W) fp32 = the merged output.
- * backward: dy (B,D,H*W) fp32 in, dyT / adj (B,4D,H*W/256,2) / part (vmasr_ss2d_part_floats) scratch,
+ * backward: dy (B,D,H*W) fp32 in, dyT / adj (like state) / part (vmasr_ss2d_part_floats) scratch,
  *   dx (B,D,H,W) `dtype`, dWx (4,3,D), dWdt (4,D), ddtb (4,D), dAlog (4D), dDs (4D) fp32 out (plain stores). */
 typedef struct vmasr_ss2d_params {
     int32_t B, D, H, W, dtype;
@@ -325,7 +325,7 @@ enum {
     VMASR_K_BIAS_GELU,          /* discriminator GEMM epilogues (bias + GELU; GELU' + split + bias gradient) */
     VMASR_K_SS2D_TRANSPOSE,     /* fused SS2D core: x -> x^T, dy -> dy^T                 */
     VMASR_K_SS2D_FWD_AGG,       /* x_proj + dt_proj + per-tile aggregates, 2 directions  */
-    VMASR_K_SS2D_CARRY,         /* reduce of the per-workgroup parameter-gradient partials */
+    VMASR_K_SS2D_CARRY,         /* scan of the aggregates / adjoint carries / reduce     */
     VMASR_K_SS2D_FWD_APPLY,     /* x_proj + dt_proj + scan of both directions + add      */
     VMASR_K_SS2D_MERGE,         /* pair outputs: a + transpose(b)                        */
     VMASR_K_SS2D_BWD_AGG,

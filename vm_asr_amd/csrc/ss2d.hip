@@ -131,45 +131,11 @@ __device__ __forceinline__ void reduce_over_waves(float (&v)[NV][4], float4 *red
     }
 }
 
-// State entering scan tile s = the aggregates of tiles [0, s) applied to 0, in order.  agg: 4 floats per tile, (a, b)
-// first.  Lane l folds the contiguous run [l*per, (l+1)*per); one pair-monoid wave scan composes the runs.
-__device__ __forceinline__ float fold_prefix(const float *__restrict__ agg, const int s, const int lane) {
-    if (s == 0) return 0.f;                                   // wave-uniform
-    const int per = (s + 63) >> 6;
-    const int c0 = lane * per, c1 = min(s, c0 + per);
-    Pair run{1.f, 0.f};
-    for (int c = c0; c < c1; ++c) {
-        const float2 e = *reinterpret_cast<const float2 *>(agg + (size_t)c * 4);
-        run = then(run, Pair{e.x, e.y});
-    }
-    Pair ex, tot;
-    wave_scan_fwd(run, lane, ex, tot);
-    return tot.b;
-}
-
-// Adjoint carry entering scan tile s from the right = the adjoint aggregates of tiles (s, n) applied to 0, LAST tile
-// first.  adj: 2 floats per tile.  Lane 0 owns the rightmost run.
-__device__ __forceinline__ float fold_suffix(const float *__restrict__ adj, const int s, const int n, const int lane) {
-    const int cnt = n - 1 - s;
-    if (cnt <= 0) return 0.f;                                 // wave-uniform
-    const int per = (cnt + 63) >> 6;
-    const int c1 = n - lane * per, c0 = max(s + 1, c1 - per);
-    Pair run{1.f, 0.f};
-    for (int c = c1 - 1; c >= c0; --c) {
-        const float2 e = *reinterpret_cast<const float2 *>(adj + (size_t)c * 2);
-        run = then(run, Pair{e.x, e.y});
-    }
-    Pair ex, tot;
-    wave_scan_fwd(run, lane, ex, tot);                        // lane order == right-to-left order
-    return tot.b;
-}
-
 struct FwdArgs {
     const void *x, *xT;          // (B, D, L) in (h,w) / (w,h) order, dtype T
     const float *Wx, *Wdt, *dtb; // (4,3,D), (4,D), (4,D)
     const float *Alog, *Dsk;     // (4D), (4D)
-    float *state;                // (B, 4D, ntiles, 4): per scan tile [prod a, h_end] (aggregate pass) and [h entering the tile]
-                                 // (apply pass; kept for the backward)
+    float *state;                // (B, 4D, ntiles, 2): per-tile aggregates -> (after the carry kernel) end-of-tile states
     float *out02, *out13;        // (B, D, L) fp32, memory order of x / xT
 };
 
@@ -246,14 +212,11 @@ __global__ __launch_bounds__(64 * WPT * TPG, 4) void ss2d_fwd_kernel(const FwdAr
                 for (int i = 2; i >= 0; --i) agg = then(agg, Pair{av[i], bv[i]});
                 wave_scan_rev(agg, lane, excl, tot);
             }
-            float *st = a.state + (((size_t)b * 4 * D + kd) * g.ntiles) * 4;
+            float *st = a.state + (((size_t)b * 4 * D + kd) * g.ntiles) * 2;
             if constexpr (MODE == 0) {
-                if (lane == 0) *reinterpret_cast<float2 *>(st + (size_t)s * 4) = make_float2(tot.a, tot.b);
+                if (lane == 0) *reinterpret_cast<float2 *>(st + (size_t)s * 2) = make_float2(tot.a, tot.b);
             } else {
-                // carry-in: fold the aggregates of the scan tiles [0, s) here (lanes own contiguous runs, one wave scan)
-                // instead of a separate scan-of-aggregates launch; it is kept in the state array for the backward
-                const float hin = fold_prefix(st, s, lane);
-                if (lane == 0) st[(size_t)s * 4 + 2] = hin;
+                const float hin = s > 0 ? st[(size_t)(s - 1) * 2 + 1] : 0.f;
                 float h = fmaf(excl.a, hin, excl.b);
                 if (kk == 0) {
 #pragma unroll
@@ -279,6 +242,40 @@ __global__ __launch_bounds__(64 * WPT * TPG, 4) void ss2d_fwd_kernel(const FwdAr
     }
 }
 
+// In-place scan of the per-tile aggregates of every (batch, direction, row) sequence: x[c] <- x[0] then ... then x[c]
+// (REVERSE: exclusive from the right, .y <- carry entering tile c from tile c+1).  One wave per sequence.
+template <bool REVERSE>
+__global__ __launch_bounds__(256) void ss2d_carry_kernel(float *__restrict__ x, const int nseq, const int n_chunks) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= nseq) return;
+    float *base = x + (size_t)seq * n_chunks * 2;
+    const int per = (n_chunks + 63) / 64;
+    Pair excl, tot;
+    if constexpr (!REVERSE) {
+        const int c0 = lane * per, c1 = min(n_chunks, c0 + per);
+        Pair agg{1.f, 0.f};
+        for (int c = c0; c < c1; ++c) agg = then(agg, Pair{base[c * 2], base[c * 2 + 1]});
+        wave_scan_fwd(agg, lane, excl, tot);
+        Pair run = excl;
+        for (int c = c0; c < c1; ++c) {
+            run = then(run, Pair{base[c * 2], base[c * 2 + 1]});
+            base[c * 2] = run.a;
+            base[c * 2 + 1] = run.b;
+        }
+    } else {
+        const int c1 = n_chunks - lane * per, c0 = max(0, c1 - per);
+        Pair agg{1.f, 0.f};
+        for (int c = c1 - 1; c >= c0; --c) agg = then(agg, Pair{base[c * 2], base[c * 2 + 1]});
+        wave_scan_fwd(agg, lane, excl, tot);  // lane order == right-to-left order
+        Pair run = excl;
+        for (int c = c1 - 1; c >= c0; --c) {
+            const Pair mine{base[c * 2], base[c * 2 + 1]};
+            base[c * 2 + 1] = run.b;  // carry entering tile c from the right (0 at the end)
+            run = then(run, mine);
+        }
+    }
+}
 
 // ---- backward ---------------------------------------------------------------------------------------------------
 // Adjoint of h_t = a_t h_{t-1} + b_t, y_t = C_t h_t:  g_t = dout_t C_t + a_{t+1} g_{t+1}.  With G_t := a_t g_t the
@@ -287,7 +284,7 @@ __global__ __launch_bounds__(64 * WPT * TPG, 4) void ss2d_fwd_kernel(const FwdAr
 struct BwdArgs {
     FwdArgs f;                   // x, xT, weights, state (end-of-tile states of the forward)
     const float *dy, *dyT;       // (B, D, L) fp32: gradient of the merged output in (h,w) / (w,h) order
-    float *adj;                  // (B, 4D, ntiles, 2): adjoint aggregates (folded into carries by the apply pass)
+    float *adj;                  // (B, 4D, ntiles, 2): adjoint aggregates -> carries
     float *dx02, *dx13;          // (B, D, L) fp32: gradient wrt x from each pair, memory order of x / xT
     float *part;                 // (B * ntiles * 2 pairs, 2 dirs, D, 8): per-workgroup partial sums of the weight gradients
 };
@@ -380,9 +377,9 @@ __global__ __launch_bounds__(64 * WPT * TPG, (64 * WPT * TPG) >= 512 ? 2 : 3) vo
                 continue;
             }
             // forward recurrence of the tile restarted from the saved state
-            const float *st = a.state + (((size_t)b * 4 * D + kd) * g.ntiles) * 4;
-            const float hin = st[(size_t)s * 4 + 2];                      // stored by the forward's apply pass
-            const float Gin = fold_suffix(adj, s, g.ntiles, lane);        // carry entering this tile from scan tile s+1
+            const float *st = a.state + (((size_t)b * 4 * D + kd) * g.ntiles) * 2;
+            const float hin = s > 0 ? st[(size_t)(s - 1) * 2 + 1] : 0.f;
+            const float Gin = adj[(size_t)s * 2 + 1];   // carry entering this tile from scan-tile s+1
             Pair agg, excl, tot;
             float hv[4];
             if (kk == 0) {
@@ -563,6 +560,9 @@ int run_fwd(const vmasr_ss2d_params &p, hipStream_t st) {
     // smaller (forward apply: 2 pairs x (x + out) = 2 (s_x + 4) B per (row, position)) — DESIGN.md §4 quotes both.
     const double el = (double)p.B * p.D * L, pos = (double)p.B * L;
     SS2D_DISPATCH(ss2d_fwd_kernel, 0, VMASR_K_SS2D_FWD_AGG, 2.0 * el * sizeof(T), a);
+    const int nseq = p.B * 4 * p.D;
+    VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nseq * ntiles * 16, (ss2d_carry_kernel<false>), dim3((nseq + 3) / 4), dim3(256), 0, st,
+                 p.state, nseq, ntiles);
     SS2D_DISPATCH(ss2d_fwd_kernel, 1, VMASR_K_SS2D_FWD_APPLY, (3.0 * 4 * el + 2.0 * 4 * pos) * 4, a);
     const dim3 grid(((p.W + kXT - 1) / kXT) * ((p.H + kXT - 1) / kXT), p.B * p.D);
     VMASR_LAUNCH(VMASR_K_SS2D_MERGE, 12.0 * el, (merge_pairs_kernel<float>), grid, dim3(256), 0, st, p.out02, p.out13, p.y, p.H, p.W);
@@ -580,6 +580,9 @@ int run_bwd(const vmasr_ss2d_params &p, hipStream_t st) {
     BwdArgs q{{p.x, p.xT, p.Wx, p.Wdt, p.dtb, p.Alog, p.Ds, p.state, nullptr, nullptr}, p.dy, p.dyT, p.adj, p.out02, p.out13, p.part};
     const double el = (double)p.B * p.D * L, pos = (double)p.B * L;
     SS2D_DISPATCH_BWD(ss2d_bwd_kernel, 0, VMASR_K_SS2D_BWD_AGG, 2.0 * el * (sizeof(T) + 4), q);
+    const int nseq = p.B * 4 * p.D;
+    VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nseq * ntiles * 16, (ss2d_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st,
+                 p.adj, nseq, ntiles);
     SS2D_DISPATCH_BWD(ss2d_bwd_kernel, 1, VMASR_K_SS2D_BWD_APPLY, (5.0 * 4 * el + 4.0 * 4 * pos) * 4, q);
     const int nwg = p.B * ntiles;
     VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nwg * 4 * p.D * kNPart * 4, ss2d_bwd_reduce_kernel, dim3((4 * p.D + 3) / 4), dim3(256), 0, st,
@@ -600,7 +603,7 @@ VMASR_EXPORT int vmasr_ss2d_supported(int32_t d_state, int32_t dt_rank, int32_t 
     if (d_state != 1 || dt_rank != 1) return 0;
     if (!(d_inner == 2 || d_inner == 4 || d_inner == 8 || d_inner == 16 || d_inner == 32)) return 0;
     const long L = (long)H * W;
-    if (L % kTile || L / kTile > 8192) return 0;             // (the carry folds read up to ntiles/64 aggregates per lane)
+    if (L % kTile) return 0;
     const Cfg c = cfg_for(d_inner), cb = cfg_for(d_inner, true);
     return ((L / kTile) % c.TPG == 0 && (L / kTile) % cb.TPG == 0) ? 1 : 0;
 }

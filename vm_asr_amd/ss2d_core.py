@@ -43,7 +43,7 @@ class _SS2DCoreFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             xT = torch.empty_like(x)
-            state = torch.empty((B, 4 * D, nt, 4), **f32)
+            state = torch.empty((B, 4 * D, nt, 2), **f32)
             scratch = torch.empty((2, B, D, L), **f32)
             y = torch.empty((B, D, L), **f32)
             p = _lib.SS2DParams()
