@@ -493,6 +493,8 @@ class Trainer(BaseTrainer):
             if key not in self._flat:
                 self._setup_flat(key, None)
             flat = self._flat[key]
+            if os.environ.get("VMASR_OVERLAP_REDUCE", "1") != "1":
+                async_op = False                    # escape hatch: collectives strictly between the graphs, no overlap
             avg = dist.get_backend() == "nccl"      # RCCL averages in the collective; gloo has no AVG
             work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
             self._pending.append((work if async_op else None, None if avg else flat))
