@@ -226,6 +226,19 @@ int vmasr_im2col_kx1_split(const float *x, void *hi, void *lo, int64_t N, int32_
                            int32_t pad, int64_t rows_out, vmasr_stream_t stream);
 int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                      int32_t pad, int32_t dtype, vmasr_stream_t stream);
+/* Multi-slot variants for the stacked discriminator pass (n <= 8 convolutions of equal C/k/stride/pad, per-slot
+ * N_i sequences of H_i): ONE launch per layer instead of n.  xs / dxs / srcs are HOST arrays of device pointers.
+ *   im2col_split_multi: hi, lo (n, rows_out, k*C) bf16, slot i = split im2col of xs[i], zero rows below N_i*H1_i
+ *   col2im_multi      : dcols (n, rows, k*C) -> dxs[i] (N_i, H_i, C); a NULL dxs[i] is skipped
+ *   stack_rows        : full (n, rows, row_bytes) = srcs[i]'s first Ms[i] rows, zeros below (all zeros if NULL);
+ *                       the gradient of `y[i, :M_i]` views for all slots (reference: autograd's slice backward). */
+int vmasr_im2col_kx1_split_multi(const float *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, void *hi, void *lo,
+                                 int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows_out, vmasr_stream_t stream);
+int vmasr_col2im_kx1_multi(const void *dcols, void *const *dxs, const int64_t *Ns, const int32_t *Hs, int32_t n, int32_t C,
+                           int32_t k, int32_t stride, int32_t pad, int64_t rows, int32_t dtype, vmasr_stream_t stream);
+int vmasr_stack_rows(const void *const *srcs, const int64_t *Ms, int32_t n, void *full, int64_t rows, int64_t row_bytes,
+                     vmasr_stream_t stream);
+
 
 /* Epilogues of the period discriminator's GEMMs (model/discriminator.py:100-104: conv -> GELU), slots x (M, N) fp32:
  *   vmasr_bias_gelu_fwd : acc += bias[slot, col] in place (the pre-activation), act = GELU(acc)   (exact erf form)
@@ -332,6 +345,7 @@ enum {
     VMASR_K_SS2D_BWD_APPLY,
     VMASR_K_SS2D_PRE,           /* xz -> (x channel-first, SiLU(z)) and its backward          */
     VMASR_K_LN_GATE,            /* LayerNorm_D(y^T) * SiLU(z) and its backward                */
+    VMASR_K_STACK_ROWS,         /* gradient of the stacked discriminator views: copy + zero pad  */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

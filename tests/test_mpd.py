@@ -429,3 +429,55 @@ def test_gelu_epilogue_kernels(n, M, N):
     db.zero_()
     _lib.check(lib.vmasr_gelu_bwd_split(None, g.data_ptr(), hi.data_ptr(), lo.data_ptr(), None, db.data_ptr(), n, M, N, st), "bwd")
     assert torch.equal(hi, g.to(torch.bfloat16)) and (db.double() - g.double().sum(1)).abs().max() <= 2e-6 * g.abs().double().sum(1).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,stride,pad,C", [(5, 3, 2, 32), (5, 1, 2, 8), (3, 1, 1, 64)])
+def test_multi_slot_kernels_equal_single_slot(k, stride, pad, C):
+    """vmasr_im2col_kx1_split_multi / vmasr_col2im_kx1_multi / vmasr_stack_rows (one launch for all slots of a stacked
+    discriminator layer) are bit-identical to the per-slot entry points and to torch copies + zero fill."""
+    from vm_asr_amd import _lib
+    from vm_asr_amd.discriminator import _slot_arrays
+    torch.manual_seed(k * 100 + C)
+    lib, dev = _lib.lib(), torch.device("cuda")
+    st = _lib.current_stream(dev)
+    geoms = [(4 * 2, 97), (4 * 3, 65), (4 * 5, 40), (4 * 7, 29), (4 * 11, 19)]          # (N_i, H_i): ragged like the 5 periods
+    xs = [torch.randn(N, H, C, device=dev) for N, H in geoms]
+    H1s = [(H + 2 * pad - k) // stride + 1 for _, H in geoms]
+    rows = -(-max(N * h1 for (N, _), h1 in zip(geoms, H1s)) // 256) * 256
+    n, K = len(xs), k * C
+    hi, lo = (torch.full((n, rows, K), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    ptrs, Ns, Hs = _slot_arrays([x.data_ptr() for x in xs], [g[0] for g in geoms], [g[1] for g in geoms])
+    _lib.check(lib.vmasr_im2col_kx1_split_multi(ptrs, Ns, Hs, n, hi.data_ptr(), lo.data_ptr(), C, k, stride, pad, rows, st), "multi")
+    for i, (x, (N, H)) in enumerate(zip(xs, geoms)):
+        h1, l1 = (torch.empty((rows, K), dtype=torch.bfloat16, device=dev) for _ in range(2))
+        _lib.check(lib.vmasr_im2col_kx1_split(x.data_ptr(), h1.data_ptr(), l1.data_ptr(), N, H, C, k, stride, pad, rows, st), "single")
+        assert torch.equal(hi[i], h1) and torch.equal(lo[i], l1), i
+        assert not hi[i, N * H1s[i]:].any() and not lo[i, N * H1s[i]:].any()
+    # col2im: slot 2 has no destination (its input needed no gradient)
+    for dt in (torch.float32, torch.bfloat16):
+        dcols = torch.randn(n, rows, K, device=dev).to(dt)
+        outs = [torch.full((N, H, C), 3.0, dtype=dt, device=dev) if i != 2 else None for i, (N, H) in enumerate(geoms)]
+        ptrs, Ns, Hs = _slot_arrays([o.data_ptr() if o is not None else 0 for o in outs], [g[0] for g in geoms], [g[1] for g in geoms])
+        _lib.check(lib.vmasr_col2im_kx1_multi(dcols.data_ptr(), ptrs, Ns, Hs, n, C, k, stride, pad, rows, _lib.torch_dtype_code(dt), st), "multi")
+        for i, (N, H) in enumerate(geoms):
+            if outs[i] is None:
+                continue
+            one = torch.empty((N, H, C), dtype=dt, device=dev)
+            _lib.check(lib.vmasr_col2im_kx1(dcols[i].data_ptr(), one.data_ptr(), N, H, C, k, stride, pad, _lib.torch_dtype_code(dt), st), "single")
+            assert torch.equal(outs[i], one), (dt, i)
+    # stack_rows: ragged valid rows, one missing source, 16-byte and byte paths (odd width)
+    for width, dt in ((K, torch.float32), (33, torch.float32), (7, torch.bfloat16)):
+        Ms = [rows, 100, 0, 257, 31]
+        gs = [torch.randn(m, width, device=dev).to(dt) if i != 3 else None for i, m in enumerate(Ms)]
+        full = torch.full((n, rows, width), 5.0, dtype=dt, device=dev)
+        ptrs, Mc, _ = _slot_arrays([g.data_ptr() if g is not None else 0 for g in gs], Ms)
+        _lib.check(lib.vmasr_stack_rows(ptrs, Mc, n, full.data_ptr(), rows, width * full.element_size(), st), "stack_rows")
+        for i, (g, m) in enumerate(zip(gs, Ms)):
+            if g is None:
+                assert not full[i].any()
+            else:
+                assert torch.equal(full[i, :m], g) and not full[i, m:].any(), (width, i)
+    # argument validation
+    assert lib.vmasr_stack_rows(ptrs, Mc, 9, full.data_ptr(), rows, 4, st) != 0
+    assert b"slots" in lib.vmasr_last_error()

@@ -113,6 +113,122 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T *__restrict__ dcols
     }
 }
 
+
+// ---- multi-slot variants: the stacked discriminator pass runs n <= kMaxSlots (k,1) convolutions of identical
+// (C, k, stride, pad) but different (N_i, H_i) per layer; one launch with blockIdx.y = slot replaces n launches
+// (the per-slot kernels last 3-20 us each, the same order as the launch gap between them).
+constexpr int kMaxSlots = 8;
+
+struct SlotTable {
+    const void *src[kMaxSlots];
+    void *dst[kMaxSlots];
+    int N[kMaxSlots], H[kMaxSlots], H1[kMaxSlots];
+    long rows[kMaxSlots];        // stack_rows: valid rows of the slot
+};
+
+__global__ __launch_bounds__(256) void im2col_split_multi_kernel(const SlotTable t, bf16_t *__restrict__ hi,
+                                                                 bf16_t *__restrict__ lo, const ColGeom g0) {
+    const int s = blockIdx.y;
+    const float *__restrict__ x = static_cast<const float *>(t.src[s]);
+    const int N = t.N[s], H = t.H[s], H1 = t.H1[s];
+    const int cv = g0.C / 4;
+    const long total = g0.rows_out * g0.k * cv;
+    uint2 *__restrict__ oh = reinterpret_cast<uint2 *>(hi) + (size_t)s * total;
+    uint2 *__restrict__ ol = reinterpret_cast<uint2 *>(lo) + (size_t)s * total;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        long r = i / cv;
+        const int j = (int)(r % g0.k);
+        r /= g0.k;
+        const int h1 = (int)(r % H1);
+        const long n = r / H1;
+        const int h = h1 * g0.stride + j - g0.pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N && h >= 0 && h < H) v = reinterpret_cast<const float4 *>(x + ((size_t)n * H + h) * g0.C)[c];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        union { uint2 raw; bf16_t b[4]; } Hh, L;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Hh.b[q] = (bf16_t)e[q];
+            L.b[q] = (bf16_t)(e[q] - (float)Hh.b[q]);
+        }
+        oh[i] = Hh.raw;
+        ol[i] = L.raw;
+    }
+}
+
+// dcols (n, rows, k*C) -> dx_s (N_s, H_s, C) for every slot with a destination
+template <typename T, int V>
+__global__ __launch_bounds__(256) void col2im_multi_kernel(const T *__restrict__ dcols_all, const SlotTable t, const ColGeom g0) {
+    const int s = blockIdx.y;
+    T *__restrict__ dx = static_cast<T *>(t.dst[s]);
+    if (!dx) return;
+    const int N = t.N[s], H = t.H[s], H1 = t.H1[s];
+    const T *__restrict__ dcols = dcols_all + (size_t)s * g0.rows_out * g0.k * g0.C;
+    const int cv = g0.C / V;
+    const long total = (long)N * H * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        const long r = i / cv;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int j = (h + g0.pad) % g0.stride; j < g0.k; j += g0.stride) {
+            const int q = h + g0.pad - j;
+            if (q < 0) break;
+            const int h1 = q / g0.stride;
+            if (h1 >= H1) continue;
+            const T *src = dcols + ((((size_t)n * H1 + h1) * g0.k + j) * g0.C) + (size_t)c * V;
+            if constexpr (V == 1) {
+                acc[0] += to_f32(src[0]);
+            } else {
+                union { uint4 raw; T e[V]; } q4;
+                q4.raw = *reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += to_f32(q4.e[e]);
+            }
+        }
+        T *dst = dx + ((size_t)n * H + h) * g0.C + (size_t)c * V;
+        if constexpr (V == 1) {
+            dst[0] = from_f32<T>(acc[0]);
+        } else {
+            union { uint4 raw; T e[V]; } o;
+#pragma unroll
+            for (int e = 0; e < V; ++e) o.e[e] = from_f32<T>(acc[e]);
+            *reinterpret_cast<uint4 *>(dst) = o.raw;
+        }
+    }
+}
+
+// full (n, rows, W bytes): slot s = its source's first rows[s]*W bytes, zeros below (and all zeros without a source).
+// U = uint4 (16-byte path) or unsigned char.
+template <typename U>
+__global__ __launch_bounds__(256) void stack_rows_kernel(const SlotTable t, U *__restrict__ full, const long slot_units) {
+    const int s = blockIdx.y;
+    const U *__restrict__ src = static_cast<const U *>(t.src[s]);
+    const long valid = src ? t.rows[s] : 0;                // in units of U
+    U *__restrict__ out = full + (size_t)s * slot_units;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < slot_units; i += (long)gridDim.x * blockDim.x) {
+        U v{};
+        if (i < valid) v = src[i];
+        out[i] = v;
+    }
+}
+
+template <typename T>
+int launch_col2im_multi(const void *dcols, const SlotTable &t, int n, long max_total_elems, const ColGeom &g, bool vec_ok, double bytes,
+                        hipStream_t st) {
+    constexpr int V = 16 / sizeof(T);
+    const bool vec = vec_ok && (g.C % V == 0);
+    const long total = max_total_elems / (vec ? V : 1);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
+    if (vec) VMASR_LAUNCH(VMASR_K_COL2IM, bytes, (col2im_multi_kernel<T, V>), dim3(blocks, n), dim3(256), 0, st, static_cast<const T *>(dcols), t, g);
+    else VMASR_LAUNCH(VMASR_K_COL2IM, bytes, (col2im_multi_kernel<T, 1>), dim3(blocks, n), dim3(256), 0, st, static_cast<const T *>(dcols), t, g);
+    return check_launch("col2im_kx1_multi");
+}
+
 template <typename T>
 int launch(bool fwd, const void *src, void *dst, const ColGeom &g, hipStream_t st) {
     constexpr int V = 16 / sizeof(T);
@@ -182,4 +298,108 @@ VMASR_EXPORT int vmasr_im2col_kx1_split(const float *x, void *hi, void *lo, int6
 VMASR_EXPORT int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t C, int32_t k, int32_t stride,
                                   int32_t pad, int32_t dtype, vmasr_stream_t stream) {
     return run(false, dcols, dx, N, H, C, k, stride, pad, 0, dtype, static_cast<hipStream_t>(stream));
+}
+
+VMASR_EXPORT int vmasr_im2col_kx1_split_multi(const float *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, void *hi,
+                                              void *lo, int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows_out,
+                                              vmasr_stream_t stream) {
+    VMASR_REQUIRE(xs && Ns && Hs && hi && lo, VMASR_EINVAL, "im2col_kx1_split_multi: null argument");
+    VMASR_REQUIRE(n > 0 && n <= kMaxSlots, VMASR_EINVAL, "im2col_kx1_split_multi: 1..%d slots (got %d)", kMaxSlots, n);
+    VMASR_REQUIRE(C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && rows_out > 0, VMASR_EINVAL,
+                  "im2col_kx1_split_multi: bad geometry (C=%d k=%d stride=%d pad=%d rows_out=%ld)", C, k, stride, pad, (long)rows_out);
+    VMASR_REQUIRE(aligned_to(hi, 8) && aligned_to(lo, 8) && ((size_t)rows_out * k * C) % 4 == 0, VMASR_EINVAL,
+                  "im2col_kx1_split_multi: unaligned operands");
+    SlotTable t{};
+    double bytes = 0;
+    for (int s = 0; s < n; ++s) {
+        VMASR_REQUIRE(xs[s] && aligned_to(xs[s], 16), VMASR_EINVAL, "im2col_kx1_split_multi: slot %d null or unaligned", s);
+        VMASR_REQUIRE(Ns[s] > 0 && Ns[s] <= 0x7fffffff && Hs[s] > 0 && Hs[s] + 2 * pad >= k, VMASR_EINVAL,
+                      "im2col_kx1_split_multi: slot %d bad geometry (N=%ld H=%d)", s, (long)Ns[s], Hs[s]);
+        const int H1 = (Hs[s] + 2 * pad - k) / stride + 1;
+        VMASR_REQUIRE(rows_out >= Ns[s] * H1, VMASR_EINVAL, "im2col_kx1_split_multi: rows_out smaller than N*H1 of slot %d", s);
+        t.src[s] = xs[s];
+        t.N[s] = (int)Ns[s];
+        t.H[s] = Hs[s];
+        t.H1[s] = H1;
+        bytes += (double)Ns[s] * Hs[s] * C * 4 + (double)rows_out * k * C * 4;
+    }
+    const ColGeom g{0, 0, C, k, stride, pad, 0, (long)rows_out};
+    const long total = (long)rows_out * k * (C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VMASR_LAUNCH(VMASR_K_IM2COL, bytes, im2col_split_multi_kernel, dim3(blocks, n), dim3(256), 0, st, t, static_cast<bf16_t *>(hi),
+                 static_cast<bf16_t *>(lo), g);
+    return check_launch("im2col_kx1_split_multi");
+}
+
+VMASR_EXPORT int vmasr_col2im_kx1_multi(const void *dcols, void *const *dxs, const int64_t *Ns, const int32_t *Hs, int32_t n,
+                                        int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows, int32_t dtype,
+                                        vmasr_stream_t stream) {
+    VMASR_REQUIRE(dcols && dxs && Ns && Hs, VMASR_EINVAL, "col2im_kx1_multi: null argument");
+    VMASR_REQUIRE(n > 0 && n <= kMaxSlots, VMASR_EINVAL, "col2im_kx1_multi: 1..%d slots (got %d)", kMaxSlots, n);
+    VMASR_REQUIRE(C > 0 && k > 0 && stride > 0 && pad >= 0 && rows > 0, VMASR_EINVAL,
+                  "col2im_kx1_multi: bad geometry (C=%d k=%d stride=%d pad=%d rows=%ld)", C, k, stride, pad, (long)rows);
+    const size_t esz = dtype == VMASR_F32 ? 4 : 2;
+    SlotTable t{};
+    bool vec_ok = aligned_to(dcols, 16) && ((size_t)rows * k * C * esz) % 16 == 0;
+    long max_total = 0;
+    double bytes = 0;
+    bool any = false;
+    for (int s = 0; s < n; ++s) {
+        VMASR_REQUIRE(Ns[s] > 0 && Ns[s] <= 0x7fffffff && Hs[s] > 0 && Hs[s] + 2 * pad >= k, VMASR_EINVAL,
+                      "col2im_kx1_multi: slot %d bad geometry (N=%ld H=%d)", s, (long)Ns[s], Hs[s]);
+        const int H1 = (Hs[s] + 2 * pad - k) / stride + 1;
+        VMASR_REQUIRE(rows >= Ns[s] * H1, VMASR_EINVAL, "col2im_kx1_multi: rows smaller than N*H1 of slot %d", s);
+        t.dst[s] = dxs[s];
+        t.N[s] = (int)Ns[s];
+        t.H[s] = Hs[s];
+        t.H1[s] = H1;
+        if (!dxs[s]) continue;
+        any = true;
+        vec_ok = vec_ok && aligned_to(dxs[s], 16);
+        max_total = std::max(max_total, (long)Ns[s] * Hs[s] * C);
+        bytes += ((double)Ns[s] * Hs[s] * C + (double)Ns[s] * H1 * k * C) * esz;
+    }
+    if (!any) return VMASR_OK;
+    const ColGeom g{0, 0, C, k, stride, pad, 0, (long)rows};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case VMASR_F32: return launch_col2im_multi<float>(dcols, t, n, max_total, g, vec_ok, bytes, st);
+        case VMASR_F16: return launch_col2im_multi<f16_t>(dcols, t, n, max_total, g, vec_ok, bytes, st);
+        case VMASR_BF16: return launch_col2im_multi<bf16_t>(dcols, t, n, max_total, g, vec_ok, bytes, st);
+    }
+    set_error("col2im_kx1_multi: unsupported dtype %d", dtype);
+    return VMASR_EINVAL;
+}
+
+VMASR_EXPORT int vmasr_stack_rows(const void *const *srcs, const int64_t *Ms, int32_t n, void *full, int64_t rows, int64_t row_bytes,
+                                  vmasr_stream_t stream) {
+    VMASR_REQUIRE(srcs && Ms && full, VMASR_EINVAL, "stack_rows: null argument");
+    VMASR_REQUIRE(n > 0 && n <= kMaxSlots, VMASR_EINVAL, "stack_rows: 1..%d slots (got %d)", kMaxSlots, n);
+    VMASR_REQUIRE(rows > 0 && row_bytes > 0, VMASR_EINVAL, "stack_rows: bad shape (rows=%ld row_bytes=%ld)", (long)rows, (long)row_bytes);
+    SlotTable t{};
+    const long slot_bytes = (long)rows * row_bytes;
+    bool vec = aligned_to(full, 16) && slot_bytes % 16 == 0;
+    double bytes = (double)n * slot_bytes;
+    for (int s = 0; s < n; ++s) {
+        VMASR_REQUIRE(Ms[s] >= 0 && Ms[s] <= rows, VMASR_EINVAL, "stack_rows: slot %d has %ld rows of %ld", s, (long)Ms[s], (long)rows);
+        t.src[s] = srcs[s];
+        t.rows[s] = (long)Ms[s] * row_bytes;
+        if (srcs[s]) {
+            vec = vec && aligned_to(srcs[s], 16) && t.rows[s] % 16 == 0;
+            bytes += (double)t.rows[s];
+        }
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (vec) {
+        for (int s = 0; s < n; ++s) t.rows[s] /= 16;
+        const long units = slot_bytes / 16;
+        const int blocks = (int)std::min<long>((units + 255) / 256, 256L * 16);
+        VMASR_LAUNCH(VMASR_K_STACK_ROWS, bytes, stack_rows_kernel<uint4>, dim3(blocks, n), dim3(256), 0, st, t, static_cast<uint4 *>(full), units);
+    } else {
+        const int blocks = (int)std::min<long>((slot_bytes + 255) / 256, 256L * 16);
+        VMASR_LAUNCH(VMASR_K_STACK_ROWS, bytes, stack_rows_kernel<unsigned char>, dim3(blocks, n), dim3(256), 0, st, t,
+                     static_cast<unsigned char *>(full), slot_bytes);
+    }
+    return check_launch("stack_rows");
 }

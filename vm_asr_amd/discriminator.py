@@ -339,6 +339,16 @@ def _round_up(v, m):
     return -(-v // m) * m
 
 
+def _slot_arrays(ptrs, Ns, Hs=None):
+    """ctypes host arrays (device pointers, per-slot sizes) of the multi-slot entry points (include/vmasr_hip.h)."""
+    import ctypes
+    n = len(ptrs)
+    a = (ctypes.c_void_p * n)(*[ctypes.c_void_p(p) if p else None for p in ptrs])
+    b = (ctypes.c_int64 * n)(*Ns)
+    c = (ctypes.c_int32 * n)(*Hs) if Hs is not None else None
+    return a, b, c
+
+
 class _StackedIm2ColFn(torch.autograd.Function):
     """n channel-last inputs (B, P_i, H_i, C) -> one (n, rows, k*C) column tensor, slot i holding the im2col
     of input i in its first B*P_i*H1_i rows and zeros below (vmasr_im2col_kx1 with rows_out)."""
@@ -362,13 +372,11 @@ class _StackedIm2ColFn(torch.autograd.Function):
         k, stride, pad, shapes = ctx.geom
         g = g.contiguous()
         lib = _lib.lib()
-        dxs = []
         with torch.cuda.device(g.device):
-            for i, (B, P, H, C) in enumerate(shapes):
-                dx = torch.empty((B, P, H, C), dtype=g.dtype, device=g.device)
-                _lib.check(lib.vmasr_col2im_kx1(g[i].data_ptr(), dx.data_ptr(), B * P, H, C, k, stride, pad,
-                                                _lib.torch_dtype_code(g.dtype), _lib.current_stream(g.device)), "col2im_kx1")
-                dxs.append(dx)
+            dxs = [torch.empty(shp, dtype=g.dtype, device=g.device) for shp in shapes]
+            ptrs, Ns, Hs = _slot_arrays([d.data_ptr() for d in dxs], [B * P for B, P, _, _ in shapes], [H for _, _, H, _ in shapes])
+            _lib.check(lib.vmasr_col2im_kx1_multi(g.data_ptr(), ptrs, Ns, Hs, len(shapes), shapes[0][3], k, stride, pad, g.shape[1],
+                                                  _lib.torch_dtype_code(g.dtype), _lib.current_stream(g.device)), "col2im_kx1_multi")
         return (None, None, None, None, *dxs)
 
 
@@ -515,11 +523,10 @@ class _StackedConvSplitFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             ch = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
             cl = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
-            for i, x in enumerate(xs):
-                B, P, H, _ = x.shape
-                xc = x.float().contiguous()
-                _lib.check(lib.vmasr_im2col_kx1_split(xc.data_ptr(), ch[i].data_ptr(), cl[i].data_ptr(), B * P, H, C, k, stride,
-                                                      pad, rows, _lib.current_stream(dev)), "im2col_kx1_split")
+            xcs = [x.float().contiguous() for x in xs]
+            ptrs, Ns, Hs = _slot_arrays([x.data_ptr() for x in xcs], [x.shape[0] * x.shape[1] for x in xcs], [x.shape[2] for x in xcs])
+            _lib.check(lib.vmasr_im2col_kx1_split_multi(ptrs, Ns, Hs, n, ch.data_ptr(), cl.data_ptr(), C, k, stride, pad, rows,
+                                                        _lib.current_stream(dev)), "im2col_kx1_split_multi")
         w = weight.detach().float()
         wh, wl = split_bf16(w)                                           # (n, N, K)
         wth, wtl = split_bf16(w.transpose(1, 2).contiguous())            # (n, K, N): contiguous B operand
@@ -576,13 +583,13 @@ class _StackedConvSplitFn(torch.autograd.Function):
                 gcat = torch.cat((gh, gl, gh), dim=2)
             dcols = torch.bmm(gcat, wcat, out_dtype=torch.float32)
             with torch.cuda.device(gy.device):
-                for i, (B, P, H, C) in enumerate(shapes):
-                    if not ctx.needs_input_grad[7 + i]:
-                        continue
-                    dx = torch.empty((B, P, H, C), dtype=torch.float32, device=gy.device)
-                    _lib.check(lib.vmasr_col2im_kx1(dcols[i].data_ptr(), dx.data_ptr(), B * P, H, C, k, stride, pad, _lib.F32,
-                                                    _lib.current_stream(gy.device)), "col2im_kx1")
-                    dxs[i] = dx.to(xdts[i])
+                outs = [torch.empty(shp, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[7 + i] else None
+                        for i, shp in enumerate(shapes)]
+                ptrs, Ns, Hs = _slot_arrays([o.data_ptr() if o is not None else 0 for o in outs],
+                                            [B * P for B, P, _, _ in shapes], [H for _, _, H, _ in shapes])
+                _lib.check(lib.vmasr_col2im_kx1_multi(dcols.data_ptr(), ptrs, Ns, Hs, n, shapes[0][3], k, stride, pad, M, _lib.F32,
+                                                      _lib.current_stream(gy.device)), "col2im_kx1_multi")
+                dxs = [o.to(xdts[i]) if o is not None else None for i, o in enumerate(outs)]
         dw = db = None
         if not _PHASE["skip_weight_grads"]:
             if ctx.needs_input_grad[5]:
@@ -614,6 +621,14 @@ class _UnstackRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         ref = next(g for g in gs if g is not None)
+        if ref.is_cuda and len(gs) <= 8:
+            with torch.cuda.device(ref.device):
+                full = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+                gc = [g.contiguous() if g is not None else None for g in gs]
+                ptrs, Ms, _ = _slot_arrays([g.data_ptr() if g is not None else 0 for g in gc], list(ctx.Ms))
+                _lib.check(_lib.lib().vmasr_stack_rows(ptrs, Ms, len(gs), full.data_ptr(), ctx.shape[1],
+                                                       ctx.shape[2] * ref.element_size(), _lib.current_stream(ref.device)), "stack_rows")
+            return (full, *([None] * len(ctx.Ms)))
         full = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
         for i, (g, m) in enumerate(zip(gs, ctx.Ms)):
             if g is None:
