@@ -456,6 +456,41 @@ def _bmm3(ah, al, bh, bl):
     return y
 
 
+def _split_k(n, N, K, M):
+    """Split factor S of the weight-gradient GEMM's contraction (M rows): hipBLASLt runs these as 256x256 macro
+    tiles, so a (N, K) output with few tiles leaves most of the 256 CUs idle unless the contraction is spread over
+    S batches.  Measured on MI355X (tools/bench_gemm.py, profiles/r02_gemm_layouts.log): 512x640 (30 tiles for five
+    slots) 203 us at S=1, 80 us at S=8; 1024x5120 (400 tiles = 1.56 waves of CUs) 491 us at S=1, 362 us at S=3;
+    1024x2560 is flat (190 / 182 us)."""
+    if M % 256:
+        return 1
+    tiles = n * -(-N // 256) * -(-K // 256)
+    blocks = M // 256
+    if tiles <= 64:
+        want = 8
+    elif 256 < tiles < 512:
+        want = 3
+    else:
+        return 1
+    return max(d for d in range(1, want + 1) if blocks % d == 0)
+
+
+def _dw3(gh, gl, ch, cl, wdt):
+    """dW = (gh + gl)^T (ch + cl) without lo*lo over the stacked rows: the three products of all S contraction
+    slabs land in ONE (3, n*S, N, K) buffer that a single reduction sums (instead of two read-modify-write passes
+    plus a slab sum)."""
+    n, M, N = gh.shape
+    K = ch.shape[2]
+    S = _split_k(n, N, K, M)
+    v = (lambda t: t.view(n * S, M // S, t.shape[2])) if S > 1 else (lambda t: t)
+    ght, glt = v(gh).transpose(1, 2), v(gl).transpose(1, 2)
+    parts = torch.empty((3, n * S, N, K), dtype=torch.float32, device=gh.device)
+    torch.bmm(ght, v(ch), out_dtype=torch.float32, out=parts[0])
+    torch.bmm(glt, v(ch), out_dtype=torch.float32, out=parts[1])
+    torch.bmm(ght, v(cl), out_dtype=torch.float32, out=parts[2])
+    return parts.view(3, n, S, N, K).sum((0, 2)).to(wdt)
+
+
 def _split_mode(K, N, cdt):
     """Which GEMMs of the fp32 discriminator run as error-compensated bf16 triples: the compute-bound ones
     (K*N >= 2^18: the 128->512, 512->1024 and 1024->1024 convolutions, 98 % of the FLOPs); the two small-K layers
@@ -492,16 +527,7 @@ class _BatchedLinearSplitFn(torch.autograd.Function):
             return dcols, None, None
         dw = db = None
         if ctx.needs_input_grad[1]:
-            tiles = n * -(-N // 64) * -(-K // 64)
-            want = min(M // 2048, max(1, 512 // tiles))
-            S = max(d for d in range(1, max(1, want) + 1) if (M // 256) % d == 0) if M % 256 == 0 else 1
-            v = (lambda t: t.view(n * S, M // S, t.shape[2])) if S > 1 else (lambda t: t)
-            ght, glt = v(gh).transpose(1, 2), v(gl).transpose(1, 2)
-            f32 = torch.float32
-            part = torch.bmm(ght, v(ch), out_dtype=f32)
-            part += torch.bmm(glt, v(ch), out_dtype=f32)
-            part += torch.bmm(ght, v(cl), out_dtype=f32)
-            dw = (part.view(n, S, N, K).sum(1) if S > 1 else part).to(wdt)
+            dw = _dw3(gh, gl, ch, cl, wdt)
         if ctx.needs_input_grad[2]:
             db = gy.sum(1).to(bdt)
         return dcols, dw, db
@@ -528,7 +554,6 @@ class _StackedConvSplitFn(torch.autograd.Function):
             _lib.check(lib.vmasr_im2col_kx1_split_multi(ptrs, Ns, Hs, n, ch.data_ptr(), cl.data_ptr(), C, k, stride, pad, rows,
                                                         _lib.current_stream(dev)), "im2col_kx1_split_multi")
         w = weight.detach().float()
-        wh, wl = split_bf16(w)                                           # (n, N, K)
         wth, wtl = split_bf16(w.transpose(1, 2).contiguous())            # (n, K, N): contiguous B operand
         y = _bmm3(ch, cl, wth, wtl)
         b32 = bias.detach().float().contiguous()
@@ -546,7 +571,9 @@ class _StackedConvSplitFn(torch.autograd.Function):
             if act:
                 pre = y
                 y = F.gelu(pre)
-        wcat = torch.cat((wh, wh, wl), dim=1)                             # (n, 3N, K)
+        # B operand of the column-gradient GEMM, [wh; wh; wl] (n, 3N, K), kept as the transpose of a contiguous
+        # (n, K, 3N) tensor: hipBLASLt's kernels for that layout are ~9 % faster here (tools/bench_gemm.py)
+        wcat = torch.cat((wth, wth, wtl), dim=2)                          # (n, K, 3N)
         ctx.save_for_backward(ch, cl, wcat, *([pre] if pre is not None else []))
         ctx.geom = (k, stride, pad, [tuple(x.shape) for x in xs], weight.dtype, bias.dtype, [x.dtype for x in xs], act, fused)
         return y
@@ -581,7 +608,7 @@ class _StackedConvSplitFn(torch.autograd.Function):
         if want_dx:
             if gcat is None:
                 gcat = torch.cat((gh, gl, gh), dim=2)
-            dcols = torch.bmm(gcat, wcat, out_dtype=torch.float32)
+            dcols = torch.bmm(gcat, wcat.transpose(1, 2), out_dtype=torch.float32)
             with torch.cuda.device(gy.device):
                 outs = [torch.empty(shp, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[7 + i] else None
                         for i, shp in enumerate(shapes)]
@@ -593,16 +620,7 @@ class _StackedConvSplitFn(torch.autograd.Function):
         dw = db = None
         if not _PHASE["skip_weight_grads"]:
             if ctx.needs_input_grad[5]:
-                tiles = n * -(-N // 64) * -(-K // 64)
-                want = min(M // 2048, max(1, 512 // tiles))
-                S = max(d for d in range(1, max(1, want) + 1) if (M // 256) % d == 0) if M % 256 == 0 else 1
-                v = (lambda t: t.view(n * S, M // S, t.shape[2])) if S > 1 else (lambda t: t)
-                ght, glt = v(gh).transpose(1, 2), v(gl).transpose(1, 2)
-                f32 = torch.float32
-                part = torch.bmm(ght, v(ch), out_dtype=f32)
-                part += torch.bmm(glt, v(ch), out_dtype=f32)
-                part += torch.bmm(ght, v(cl), out_dtype=f32)
-                dw = (part.view(n, S, N, K).sum(1) if S > 1 else part).to(wdt)
+                dw = _dw3(gh, gl, ch, cl, wdt)
             if ctx.needs_input_grad[6]:
                 db = db32.to(bdt)
         return (None, None, None, None, None, dw, db, *dxs)
