@@ -244,6 +244,7 @@ int vmasr_stack_rows(const void *const *srcs, const int64_t *Ms, int32_t n, void
  *   vmasr_bias_gelu_fwd : acc += bias[slot, col] in place (the pre-activation), act = GELU(acc)   (exact erf form)
  *   vmasr_gelu_bwd_split: gx = g * GELU'(pre) (pre == NULL: gx = g), written only as its bf16 split (hi, lo);
  *                         cat3 (may be NULL): the same split as rows [hi | lo | hi] of width 3N (slots, M, 3N);
+ *                         hi and lo may both be NULL when cat3 is given (its first two column blocks ARE hi and lo);
  *                         db[slot, col] += sum over rows of gx (db zero-initialised by the caller; may be NULL) */
 int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots, int64_t M, int32_t N, vmasr_stream_t stream);
 int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, void *cat3, float *db, int32_t slots, int64_t M,

@@ -398,7 +398,7 @@ def test_stacked_conv_split_matches_float64_conv(stride, k, pad, act):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,M,N", [(5, 512, 1024), (2, 300, 512), (3, 1000, 128), (1, 6144, 1024)])
+@pytest.mark.parametrize("n,M,N", [(5, 512, 1024), (2, 300, 512), (3, 1000, 128), (1, 6144, 1024), (2, 257, 520), (3, 70, 36)])
 def test_gelu_epilogue_kernels(n, M, N):
     """vmasr_bias_gelu_fwd / vmasr_gelu_bwd_split (csrc/split.hip) against torch in float64: pre-activation, GELU,
     gx = g * GELU'(pre) through its bf16 split (hi + lo), the [hi | lo | hi] operand, and the bias gradient."""
@@ -425,6 +425,12 @@ def test_gelu_epilogue_kernels(n, M, N):
     assert torch.equal(cat3[:, :, :N], hi) and torch.equal(cat3[:, :, N:2 * N], lo) and torch.equal(cat3[:, :, 2 * N:], hi)
     want = gx.sum(1)
     assert (db.double() - want).abs().max() <= 2e-6 * gx.abs().sum(1).max(), ((db.double() - want).abs().max().item(), want.abs().max().item())
+    # cat3 alone (hi = lo = NULL): what the training step uses when the column gradient is wanted
+    cat3b = torch.zeros_like(cat3)
+    db.zero_()
+    _lib.check(lib.vmasr_gelu_bwd_split(pre.data_ptr(), g.data_ptr(), None, None, cat3b.data_ptr(), db.data_ptr(), n, M, N, st), "bwd")
+    assert torch.equal(cat3b, cat3) and (db.double() - want).abs().max() <= 2e-6 * gx.abs().sum(1).max()
+    assert lib.vmasr_gelu_bwd_split(pre.data_ptr(), g.data_ptr(), None, None, None, None, n, M, N, st) != 0
     # no activation: plain split + column sums
     db.zero_()
     _lib.check(lib.vmasr_gelu_bwd_split(None, g.data_ptr(), hi.data_ptr(), lo.data_ptr(), None, db.data_ptr(), n, M, N, st), "bwd")

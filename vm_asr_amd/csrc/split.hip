@@ -88,19 +88,22 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(float *__restrict__ 
 }
 
 constexpr int kGbRows = 256;   // rows per workgroup of the backward (column sums leave as one atomic per column and workgroup)
+constexpr int kGbLanes = 64;   // float4 lanes (256 columns) per workgroup: a (256 rows x 256 columns) tile, so that
+                               // (M/256) x (N/256) x slots workgroups fill the chip (120 workgroups at 256 rows x N before)
 
 __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__restrict__ pre, const float *__restrict__ g,
                                                              bf16_t *__restrict__ hi, bf16_t *__restrict__ lo,
                                                              bf16_t *__restrict__ cat3, float *__restrict__ db, const long M,
                                                              const int N, const int has_act) {
-    const int slot = blockIdx.y;
+    const int slot = blockIdx.z;
     const int nv = N / 4;
-    const int rows_per_pass = 256 / nv > 0 ? 256 / nv : 1;   // nv <= 256 (N <= 1024)
-    const int c = threadIdx.x % nv, rr = threadIdx.x / nv;
+    const int lanes = nv < kGbLanes ? nv : kGbLanes;          // float4 columns of this workgroup's chunk
+    const int rows_per_pass = 256 / lanes;
+    const int c = blockIdx.y * kGbLanes + threadIdx.x % lanes, rr = threadIdx.x / lanes;
     const size_t base = (size_t)slot * M * N;
     const long r0 = (long)blockIdx.x * kGbRows;
     double s[4] = {0.0, 0.0, 0.0, 0.0};   // the bias gradient sums 10^4..10^5 rows: fp64 in-thread, fp32 only across workgroups
-    if (rr < rows_per_pass) {
+    if (rr < rows_per_pass && c < nv) {
         for (long r = r0 + rr; r < r0 + kGbRows && r < M; r += rows_per_pass) {
             const size_t i = (base + (size_t)r * N) / 4 + c;
             float4 gv = reinterpret_cast<const float4 *>(g)[i];
@@ -113,8 +116,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
             union { uint2 raw; bf16_t b[4]; } H, L;
 #pragma unroll
             for (int q = 0; q < 4; ++q) split1(e[q], H.b[q], L.b[q]);
-            reinterpret_cast<uint2 *>(hi)[i] = H.raw;
-            reinterpret_cast<uint2 *>(lo)[i] = L.raw;
+            if (hi) {
+                reinterpret_cast<uint2 *>(hi)[i] = H.raw;
+                reinterpret_cast<uint2 *>(lo)[i] = L.raw;
+            }
             if (cat3) {   // [hi | lo | hi] rows of width 3N: the A operand of the concatenated-contraction column-gradient GEMM
                 uint2 *row = reinterpret_cast<uint2 *>(cat3 + ((size_t)slot * M + r) * 3 * N);
                 row[c] = H.raw; row[nv + c] = L.raw; row[2 * nv + c] = H.raw;
@@ -145,15 +150,18 @@ VMASR_EXPORT int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, 
 
 VMASR_EXPORT int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, void *cat3, float *db, int32_t slots,
                                       int64_t M, int32_t N, vmasr_stream_t stream) {
-    VMASR_REQUIRE(g && hi && lo, VMASR_EINVAL, "gelu_bwd_split: null tensor");
+    VMASR_REQUIRE(g && ((hi && lo) || (!hi && !lo && cat3)), VMASR_EINVAL,
+                  "gelu_bwd_split: null tensor (g, and hi + lo or cat3 alone, are required)");
     VMASR_REQUIRE(slots > 0 && slots <= 65535 && M > 0 && N > 0 && N % 4 == 0 && N <= 1024, VMASR_EINVAL,
                   "gelu_bwd_split: bad shape (N must be a multiple of 4, <= 1024)");
-    VMASR_REQUIRE(aligned_to(g, 16) && (!pre || aligned_to(pre, 16)) && aligned_to(hi, 8) && aligned_to(lo, 8) && (!db || aligned_to(db, 16)),
+    VMASR_REQUIRE(aligned_to(g, 16) && (!pre || aligned_to(pre, 16)) && (!hi || (aligned_to(hi, 8) && aligned_to(lo, 8))) && (!db || aligned_to(db, 16)),
                   VMASR_EINVAL, "gelu_bwd_split: unaligned");
     VMASR_REQUIRE(!cat3 || aligned_to(cat3, 8), VMASR_EINVAL, "gelu_bwd_split: unaligned cat3");
     const int blocks = (int)((M + kGbRows - 1) / kGbRows);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    VMASR_LAUNCH(VMASR_K_BIAS_GELU, (cat3 ? 18.0 : 12.0) * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, slots), dim3(256), 0,
+    const int chunks = (N / 4 + kGbLanes - 1) / kGbLanes;
+    const double per_elem = (pre ? 8.0 : 4.0) + (hi ? 4.0 : 0.0) + (cat3 ? 6.0 : 0.0);
+    VMASR_LAUNCH(VMASR_K_BIAS_GELU, per_elem * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, chunks, slots), dim3(256), 0,
                  st, pre, g, static_cast<bf16_t *>(hi), static_cast<bf16_t *>(lo), static_cast<bf16_t *>(cat3), db, (long)M, N, pre ? 1 : 0);
     return check_launch("gelu_bwd_split");
 }

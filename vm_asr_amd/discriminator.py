@@ -592,11 +592,15 @@ class _StackedConvSplitFn(torch.autograd.Function):
         if N % 4 == 0 and N <= 1024:
             # one pass: (GELU' *) gradient -> bf16 split (+ bias gradient); the fp32 gradient is never written
             with torch.cuda.device(gy.device):
-                gh = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
-                gl = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
                 db32 = torch.zeros((n, N), dtype=torch.float32, device=gy.device) if want_db else None
-                gcat = torch.empty((n, M, 3 * N), dtype=torch.bfloat16, device=gy.device) if want_dx else None
-                _lib.check(lib.vmasr_gelu_bwd_split(rest[0].data_ptr() if act else None, gy.data_ptr(), gh.data_ptr(), gl.data_ptr(),
+                if want_dx:    # [gh | gl | gh]: the weight-gradient GEMMs read gh, gl as column blocks of it (lda = 3N)
+                    gcat = torch.empty((n, M, 3 * N), dtype=torch.bfloat16, device=gy.device)
+                    gh, gl = gcat[:, :, :N], gcat[:, :, N:2 * N]
+                else:
+                    gh = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
+                    gl = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
+                _lib.check(lib.vmasr_gelu_bwd_split(rest[0].data_ptr() if act else None, gy.data_ptr(),
+                                                    None if want_dx else gh.data_ptr(), None if want_dx else gl.data_ptr(),
                                                     gcat.data_ptr() if want_dx else None, db32.data_ptr() if want_db else None,
                                                     n, M, N, _lib.current_stream(gy.device)), "gelu_bwd_split")
         else:
