@@ -241,12 +241,17 @@ int vmasr_stack_rows(const void *const *srcs, const int64_t *Ms, int32_t n, void
 
 
 /* Epilogues of the period discriminator's GEMMs (model/discriminator.py:100-104: conv -> GELU), slots x (M, N) fp32:
- *   vmasr_bias_gelu_fwd : acc += bias[slot, col] in place (the pre-activation), act = GELU(acc)   (exact erf form)
+ *   vmasr_bias_gelu_fwd : acc (parts, slots, M, N): acc[0] = sum_p acc[p] + bias[slot, col] (the pre-activation, in place),
+ *                         act = GELU(acc[0]) (exact erf form); parts = 1..8 (3: the products of a bf16 GEMM triple)
  *   vmasr_gelu_bwd_split: gx = g * GELU'(pre) (pre == NULL: gx = g), written only as its bf16 split (hi, lo);
  *                         cat3 (may be NULL): the same split as rows [hi | lo | hi] of width 3N (slots, M, 3N);
  *                         hi and lo may both be NULL when cat3 is given (its first two column blocks ARE hi and lo);
  *                         db[slot, col] += sum over rows of gx (db zero-initialised by the caller; may be NULL) */
-int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots, int64_t M, int32_t N, vmasr_stream_t stream);
+int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots, int64_t M, int32_t N, int32_t parts,
+                        vmasr_stream_t stream);
+/* w (n, N, K) fp32 -> out (n, K, 3N) bf16 = [hi^T | hi^T | lo^T] of the bf16 split of w: the B operands of the
+ * forward GEMM triple (column blocks 0 and 2) and of the concatenated-contraction column-gradient GEMM (all of it) */
+int vmasr_weight_prep_split(const float *w, void *out, int32_t n, int32_t N, int32_t K, vmasr_stream_t stream);
 int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, void *cat3, float *db, int32_t slots, int64_t M,
                          int32_t N, vmasr_stream_t stream);
 

@@ -409,7 +409,12 @@ def test_gelu_epilogue_kernels(n, M, N):
     g = torch.randn(n, M, N, device="cuda")
     lib, st = _lib.lib(), _lib.current_stream(acc.device)
     pre, act = acc.clone(), torch.empty_like(acc)
-    _lib.check(lib.vmasr_bias_gelu_fwd(pre.data_ptr(), bias.data_ptr(), act.data_ptr(), n, M, N, st), "fwd")
+    _lib.check(lib.vmasr_bias_gelu_fwd(pre.data_ptr(), bias.data_ptr(), act.data_ptr(), n, M, N, 1, st), "fwd")
+    # three parts side by side (the products of a GEMM triple): summed by the epilogue, pre-activation left in part 0
+    parts = torch.stack((acc * 0.5, acc * 0.25, acc * 0.25)).contiguous()
+    act3 = torch.empty_like(acc)
+    _lib.check(lib.vmasr_bias_gelu_fwd(parts.data_ptr(), bias.data_ptr(), act3.data_ptr(), n, M, N, 3, st), "fwd3")
+    assert torch.equal(parts[0], pre) and torch.equal(act3, act)
     p64 = acc.double() + bias.double().unsqueeze(1)
     assert torch.allclose(pre.double(), p64, rtol=0, atol=1e-6)
     assert torch.allclose(act.double(), torch.nn.functional.gelu(p64), rtol=1e-5, atol=2e-6)
@@ -487,3 +492,18 @@ def test_multi_slot_kernels_equal_single_slot(k, stride, pad, C):
     # argument validation
     assert lib.vmasr_stack_rows(ptrs, Mc, 9, full.data_ptr(), rows, 4, st) != 0
     assert b"slots" in lib.vmasr_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,N,K", [(5, 512, 640), (2, 1024, 2560), (3, 70, 100), (1, 1, 3072)])
+def test_weight_prep_split_kernel(n, N, K):
+    """vmasr_weight_prep_split: w (n, N, K) fp32 -> (n, K, 3N) bf16 [hi^T | hi^T | lo^T], bit-identical to
+    transpose + vmasr_split_bf16 + cat."""
+    from vm_asr_amd import _lib
+    from vm_asr_amd.discriminator import split_bf16
+    torch.manual_seed(N + K)
+    w = torch.randn(n, N, K, device="cuda")
+    out = torch.full((n, K, 3 * N), 9.0, dtype=torch.bfloat16, device="cuda")
+    _lib.check(_lib.lib().vmasr_weight_prep_split(w.data_ptr(), out.data_ptr(), n, N, K, _lib.current_stream(w.device)), "prep")
+    hi, lo = split_bf16(w.transpose(1, 2).contiguous())
+    assert torch.equal(out, torch.cat((hi, hi, lo), dim=2))

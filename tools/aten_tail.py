@@ -23,9 +23,12 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     tr.train_step(*batch)
     torch.cuda.synchronize()
 rows = []
+from torch.autograd import DeviceType  # noqa: E402
+mode = os.environ.get("TAIL_ROWS", "ops")     # ops: host ops with the device time of the kernels they launched; kernels: by kernel
 for e in prof.key_averages(group_by_input_shape=True):
     dt = getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0)
-    if dt > 0:
+    is_kernel = e.device_type != DeviceType.CPU
+    if dt > 0 and is_kernel == (mode == "kernels"):
         rows.append((dt, e.count, e.key, str(e.input_shapes)[:110]))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)

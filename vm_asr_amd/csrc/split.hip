@@ -69,9 +69,12 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
-// grid: (row chunks, slots); block 256 threads; each thread owns 4 consecutive columns of one or more rows per pass
+// grid: (row chunks, slots); block 256 threads; each thread owns 4 consecutive columns of one or more rows per pass.
+// acc is (parts, slots, M, N): the pre-activation is the SUM of the parts (the three products of an error-compensated
+// GEMM triple, written side by side instead of accumulated by two read-modify-write passes) + bias, stored into part 0.
 __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(float *__restrict__ acc, const float *__restrict__ bias,
-                                                            float *__restrict__ act, const long M, const int N) {
+                                                            float *__restrict__ act, const long M, const int N, const int parts,
+                                                            const size_t part_stride) {
     const int slot = blockIdx.y;
     const int nv = N / 4;                                   // float4 per row
     const long total = M * nv;
@@ -80,10 +83,40 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(float *__restrict__ 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % nv);
         float4 v = reinterpret_cast<float4 *>(a)[i];
+        for (int p = 1; p < parts; ++p) {
+            const float4 q = reinterpret_cast<const float4 *>(a + (size_t)p * part_stride)[i];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
         const float4 bb = reinterpret_cast<const float4 *>(b)[c];
         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
         reinterpret_cast<float4 *>(a)[i] = v;
         reinterpret_cast<float4 *>(o)[i] = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+    }
+}
+
+// Weight operand of the stacked convolutions' GEMM triples: w (n, N, K) fp32 -> out (n, K, 3N) bf16 = [hi^T | hi^T | lo^T].
+// Columns [0, N) and [2N, 3N) are the forward GEMM's B operands (y = ch hi^T + cl hi^T + ch lo^T), the whole thing is
+// the B^T of the concatenated-contraction column-gradient GEMM.  One pass (r 4, w 6 B/elt) instead of transpose copy +
+// split + cat (r 14, w 14).  64 x 64 tiles through LDS; grid (K tiles, N tiles, n).
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float *__restrict__ w, bf16_t *__restrict__ out, const int N, const int K) {
+    __shared__ float tile[64][65];
+    const int slot = blockIdx.z, k0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+    const float *src = w + (size_t)slot * N * K;
+    bf16_t *dst = out + (size_t)slot * K * 3 * N;
+    const int tx = threadIdx.x % 64, ty = threadIdx.x / 64;          // 4 rows of 64 per pass
+    for (int r = ty; r < 64; r += 4) {
+        const int o = o0 + r, k = k0 + tx;
+        tile[r][tx] = (o < N && k < K) ? src[(size_t)o * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {                               // r: k within the tile, tx: o within the tile
+        const int k = k0 + r, o = o0 + tx;
+        if (k < K && o < N) {
+            bf16_t h, l;
+            split1(tile[tx][r], h, l);
+            bf16_t *row = dst + (size_t)k * 3 * N;
+            row[o] = h; row[N + o] = h; row[2 * N + o] = l;
+        }
     }
 }
 
@@ -135,16 +168,27 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
 }  // namespace
 }  // namespace vmasr
 
-VMASR_EXPORT int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots, int64_t M, int32_t N,
+VMASR_EXPORT int vmasr_weight_prep_split(const float *w, void *out, int32_t n, int32_t N, int32_t K, vmasr_stream_t stream) {
+    VMASR_REQUIRE(w && out, VMASR_EINVAL, "weight_prep_split: null tensor");
+    VMASR_REQUIRE(n > 0 && n <= 65535 && N > 0 && K > 0, VMASR_EINVAL, "weight_prep_split: bad shape (n=%d N=%d K=%d)", n, N, K);
+    const dim3 grid((K + 63) / 64, (N + 63) / 64, n);
+    VMASR_REQUIRE(grid.y <= 65535, VMASR_EINVAL, "weight_prep_split: N too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VMASR_LAUNCH(VMASR_K_SPLIT_BF16, 10.0 * n * (double)N * K, weight_prep_kernel, grid, dim3(256), 0, st, w, static_cast<bf16_t *>(out), N, K);
+    return check_launch("weight_prep_split");
+}
+
+VMASR_EXPORT int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots, int64_t M, int32_t N, int32_t parts,
                                      vmasr_stream_t stream) {
     VMASR_REQUIRE(acc && bias && act, VMASR_EINVAL, "bias_gelu_fwd: null tensor");
-    VMASR_REQUIRE(slots > 0 && slots <= 65535 && M > 0 && N > 0 && N % 4 == 0, VMASR_EINVAL, "bias_gelu_fwd: bad shape");
+    VMASR_REQUIRE(slots > 0 && slots <= 65535 && M > 0 && N > 0 && N % 4 == 0 && parts >= 1 && parts <= 8, VMASR_EINVAL,
+                  "bias_gelu_fwd: bad shape");
     VMASR_REQUIRE(aligned_to(acc, 16) && aligned_to(bias, 16) && aligned_to(act, 16), VMASR_EINVAL, "bias_gelu_fwd: unaligned");
     const long total = M * (N / 4);
     const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    VMASR_LAUNCH(VMASR_K_BIAS_GELU, 12.0 * slots * (double)M * N, bias_gelu_fwd_kernel, dim3(blocks, slots), dim3(256), 0, st, acc,
-                 bias, act, (long)M, N);
+    VMASR_LAUNCH(VMASR_K_BIAS_GELU, (8.0 + 4.0 * parts) * slots * (double)M * N, bias_gelu_fwd_kernel, dim3(blocks, slots), dim3(256), 0,
+                 st, acc, bias, act, (long)M, N, parts, (size_t)slots * M * N);
     return check_launch("bias_gelu_fwd");
 }
 

@@ -553,27 +553,36 @@ class _StackedConvSplitFn(torch.autograd.Function):
             ptrs, Ns, Hs = _slot_arrays([x.data_ptr() for x in xcs], [x.shape[0] * x.shape[1] for x in xcs], [x.shape[2] for x in xcs])
             _lib.check(lib.vmasr_im2col_kx1_split_multi(ptrs, Ns, Hs, n, ch.data_ptr(), cl.data_ptr(), C, k, stride, pad, rows,
                                                         _lib.current_stream(dev)), "im2col_kx1_split_multi")
-        w = weight.detach().float()
-        wth, wtl = split_bf16(w.transpose(1, 2).contiguous())            # (n, K, N): contiguous B operand
-        y = _bmm3(ch, cl, wth, wtl)
+        # weights: one pass to the (n, K, 3N) bf16 operand [hi^T | hi^T | lo^T] (csrc/split.hip): column blocks 0 and 2 are
+        # the forward B operands; all of it, transposed, is the [wh; wh; wl] operand of the column-gradient GEMM
+        # (kept as the transpose of a contiguous tensor: hipBLASLt's kernels for that layout are ~9 % faster here)
+        w = weight.detach().float().contiguous()
+        N = w.shape[1]
+        with torch.cuda.device(dev):
+            wcat = torch.empty((n, K, 3 * N), dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.vmasr_weight_prep_split(w.data_ptr(), wcat.data_ptr(), n, N, K, _lib.current_stream(dev)), "weight_prep_split")
+        wth, wtl = wcat[:, :, :N], wcat[:, :, 2 * N:]
         b32 = bias.detach().float().contiguous()
-        N = y.shape[2]
         fused = act and N % 4 == 0 and N <= 1024
         pre = None
         if fused:
-            pre = y                                                       # becomes acc + bias in place
+            # the three products side by side; the epilogue sums them, adds the bias (-> pre, in place in part 0) and applies GELU
+            f32 = torch.float32
             with torch.cuda.device(dev):
+                parts = torch.empty((3, n, rows, N), dtype=f32, device=dev)
+                torch.bmm(ch, wth, out_dtype=f32, out=parts[0])
+                torch.bmm(cl, wth, out_dtype=f32, out=parts[1])
+                torch.bmm(ch, wtl, out_dtype=f32, out=parts[2])
+                pre = parts[0]
                 y = torch.empty_like(pre)
-                _lib.check(lib.vmasr_bias_gelu_fwd(pre.data_ptr(), b32.data_ptr(), y.data_ptr(), n, rows, N,
+                _lib.check(lib.vmasr_bias_gelu_fwd(parts.data_ptr(), b32.data_ptr(), y.data_ptr(), n, rows, N, 3,
                                                    _lib.current_stream(dev)), "bias_gelu_fwd")
         else:
+            y = _bmm3(ch, cl, wth, wtl)
             y.add_(b32.unsqueeze(1))
             if act:
                 pre = y
                 y = F.gelu(pre)
-        # B operand of the column-gradient GEMM, [wh; wh; wl] (n, 3N, K), kept as the transpose of a contiguous
-        # (n, K, 3N) tensor: hipBLASLt's kernels for that layout are ~9 % faster here (tools/bench_gemm.py)
-        wcat = torch.cat((wth, wth, wtl), dim=2)                          # (n, K, 3N)
         ctx.save_for_backward(ch, cl, wcat, *([pre] if pre is not None else []))
         ctx.geom = (k, stride, pad, [tuple(x.shape) for x in xs], weight.dtype, bias.dtype, [x.dtype for x in xs], act, fused)
         return y
