@@ -254,6 +254,8 @@ int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots
 int vmasr_weight_prep_split(const float *w, void *out, int32_t n, int32_t N, int32_t K, vmasr_stream_t stream);
 int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, void *cat3, float *db, int32_t slots, int64_t M,
                          int32_t N, vmasr_stream_t stream);
+/* the same pass with the fp32 gradient as output (layers whose GEMMs stay fp32): gx = g * GELU'(pre), db += column sums */
+int vmasr_gelu_bwd(const float *pre, const float *g, float *gx, float *db, int32_t slots, int64_t M, int32_t N, vmasr_stream_t stream);
 
 /* ---- fused SS2D core (vm_asr_amd/csrc/ss2d.hip) ---------------------------------------------------------
  * One operator for  y = CrossMerge(selective_scan(CrossScan(x), dt_proj(x_proj(.)), A, B, C, D, dt_bias, softplus))

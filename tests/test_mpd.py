@@ -507,3 +507,24 @@ def test_weight_prep_split_kernel(n, N, K):
     _lib.check(_lib.lib().vmasr_weight_prep_split(w.data_ptr(), out.data_ptr(), n, N, K, _lib.current_stream(w.device)), "prep")
     hi, lo = split_bf16(w.transpose(1, 2).contiguous())
     assert torch.equal(out, torch.cat((hi, hi, lo), dim=2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,M,K,N", [(5, 2048, 160, 128), (3, 1000, 5, 32), (2, 512, 96, 36)])
+def test_batched_linear_fused_gelu_matches_float64(n, M, K, N):
+    """_BatchedLinearFn(act=True) on fp32 GPU operands (bias + GELU epilogue kernel; GELU' + bias gradient in one
+    backward pass) == GELU(cols W^T + b) in float64, values and all three gradients."""
+    from vm_asr_amd.discriminator import _BatchedLinearFn
+    torch.manual_seed(M + N)
+    cols = torch.randn(n, M, K, device="cuda", requires_grad=True)
+    W = (torch.randn(n, N, K, device="cuda") / K ** 0.5).requires_grad_()
+    b = torch.randn(n, N, device="cuda", requires_grad=True)
+    g = torch.randn(n, M, N, device="cuda")
+    y = _BatchedLinearFn.apply(cols, W, b, torch.float32, True)
+    y.backward(g)
+    c64, W64, b64 = (t.detach().double().requires_grad_() for t in (cols, W, b))
+    y64 = torch.nn.functional.gelu(torch.einsum("imk,ink->imn", c64, W64) + b64.unsqueeze(1))
+    y64.backward(g.double())
+    for name, got, want in (("y", y, y64), ("dcols", cols.grad, c64.grad), ("dW", W.grad, W64.grad), ("db", b.grad, b64.grad)):
+        err = (got.double() - want).abs().max().item() / want.abs().max().item()
+        assert err <= 2e-5, (name, err)

@@ -79,6 +79,7 @@ SYMBOLS = {
     "vmasr_stack_rows": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp]),
     "vmasr_split_bf16": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vmasr_bias_gelu_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
+    "vmasr_gelu_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_weight_prep_split": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_gelu_bwd_split": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_ss2d_glue_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),

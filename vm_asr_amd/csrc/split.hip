@@ -126,8 +126,8 @@ constexpr int kGbLanes = 64;   // float4 lanes (256 columns) per workgroup: a (2
 
 __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__restrict__ pre, const float *__restrict__ g,
                                                              bf16_t *__restrict__ hi, bf16_t *__restrict__ lo,
-                                                             bf16_t *__restrict__ cat3, float *__restrict__ db, const long M,
-                                                             const int N, const int has_act) {
+                                                             bf16_t *__restrict__ cat3, float *__restrict__ gx,
+                                                             float *__restrict__ db, const long M, const int N, const int has_act) {
     const int slot = blockIdx.z;
     const int nv = N / 4;
     const int lanes = nv < kGbLanes ? nv : kGbLanes;          // float4 columns of this workgroup's chunk
@@ -145,6 +145,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
                 gv.x *= gelu_grad_f(p.x); gv.y *= gelu_grad_f(p.y); gv.z *= gelu_grad_f(p.z); gv.w *= gelu_grad_f(p.w);
             }
             s[0] += gv.x; s[1] += gv.y; s[2] += gv.z; s[3] += gv.w;
+            if (gx) {   // fp32 gradient for the plain-fp32 GEMM layers (no split operands)
+                reinterpret_cast<float4 *>(gx)[i] = gv;
+                continue;
+            }
             const float e[4] = {gv.x, gv.y, gv.z, gv.w};
             union { uint2 raw; bf16_t b[4]; } H, L;
 #pragma unroll
@@ -158,9 +162,19 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
                 row[c] = H.raw; row[nv + c] = L.raw; row[2 * nv + c] = H.raw;
             }
         }
-        if (db) {
+    }
+    if (db) {   // fold the row groups of the workgroup in LDS, then ONE atomic per column and workgroup
+        __shared__ float red[256][4];
+        red[threadIdx.x][0] = (float)s[0]; red[threadIdx.x][1] = (float)s[1]; red[threadIdx.x][2] = (float)s[2]; red[threadIdx.x][3] = (float)s[3];
+        __syncthreads();
+        if (rr == 0 && c < nv) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < rows_per_pass; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] += red[q * lanes + threadIdx.x][e];
+            }
             float *d = db + (size_t)slot * N + c * 4;
-            atomicAdd(d + 0, (float)s[0]); atomicAdd(d + 1, (float)s[1]); atomicAdd(d + 2, (float)s[2]); atomicAdd(d + 3, (float)s[3]);
+            atomicAdd(d + 0, t[0]); atomicAdd(d + 1, t[1]); atomicAdd(d + 2, t[2]); atomicAdd(d + 3, t[3]);
         }
     }
 }
@@ -206,6 +220,22 @@ VMASR_EXPORT int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi
     const int chunks = (N / 4 + kGbLanes - 1) / kGbLanes;
     const double per_elem = (pre ? 8.0 : 4.0) + (hi ? 4.0 : 0.0) + (cat3 ? 6.0 : 0.0);
     VMASR_LAUNCH(VMASR_K_BIAS_GELU, per_elem * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, chunks, slots), dim3(256), 0,
-                 st, pre, g, static_cast<bf16_t *>(hi), static_cast<bf16_t *>(lo), static_cast<bf16_t *>(cat3), db, (long)M, N, pre ? 1 : 0);
+                 st, pre, g, static_cast<bf16_t *>(hi), static_cast<bf16_t *>(lo), static_cast<bf16_t *>(cat3), static_cast<float *>(nullptr), db, (long)M, N,
+                 pre ? 1 : 0);
     return check_launch("gelu_bwd_split");
+}
+
+VMASR_EXPORT int vmasr_gelu_bwd(const float *pre, const float *g, float *gx, float *db, int32_t slots, int64_t M, int32_t N,
+                                vmasr_stream_t stream) {
+    VMASR_REQUIRE(pre && g && gx, VMASR_EINVAL, "gelu_bwd: null tensor");
+    VMASR_REQUIRE(slots > 0 && slots <= 65535 && M > 0 && N > 0 && N % 4 == 0 && N <= 1024, VMASR_EINVAL,
+                  "gelu_bwd: bad shape (N must be a multiple of 4, <= 1024)");
+    VMASR_REQUIRE(aligned_to(g, 16) && aligned_to(pre, 16) && aligned_to(gx, 16) && (!db || aligned_to(db, 16)), VMASR_EINVAL,
+                  "gelu_bwd: unaligned");
+    const int blocks = (int)((M + kGbRows - 1) / kGbRows);
+    const int chunks = (N / 4 + kGbLanes - 1) / kGbLanes;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VMASR_LAUNCH(VMASR_K_BIAS_GELU, 12.0 * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, chunks, slots), dim3(256), 0, st, pre, g,
+                 static_cast<bf16_t *>(nullptr), static_cast<bf16_t *>(nullptr), static_cast<bf16_t *>(nullptr), gx, db, (long)M, N, 1);
+    return check_launch("gelu_bwd");
 }

@@ -399,27 +399,56 @@ class _BatchedLinearFn(torch.autograd.Function):
     GEMM for the column gradient, the weight gradient split over the rows into a larger batch (fp32 sum)."""
 
     @staticmethod
-    def forward(ctx, cols, weight, bias, cdt):
+    def forward(ctx, cols, weight, bias, cdt, act=False):
+        """act: GELU on the output; for fp32 operands on the GPU the bias + GELU epilogue and, in the backward, GELU' + the
+        bias gradient are single passes (csrc/split.hip) instead of add_, gelu, gelu_backward and a column sum."""
         wc = weight.detach().to(cdt)                                   # (n, N, K): the operand of dcols = gy @ W
         # The forward operand is a CONTIGUOUS (n, K, N) copy: batched bf16 GEMMs with a transposed-view B operand
         # fault the GPU on ROCm 7.2 / hipBLASLt for e.g. (5, 36608, 640) x (5, 640, 512)^T (tools/bmm_probe.py);
         # contiguous-B ("NN") and transposed-A ("TN", the weight gradient) forms are fine at every MPD shape.
-        y = torch.bmm(cols, wc.transpose(1, 2).contiguous()).add_(bias.detach().to(cdt).unsqueeze(1))
-        ctx.save_for_backward(cols, wc)
-        ctx.meta = (weight.dtype, bias.dtype)
+        y = torch.bmm(cols, wc.transpose(1, 2).contiguous())
+        n, M, N = y.shape
+        fused = act and y.is_cuda and y.dtype == torch.float32 and N % 4 == 0 and N <= 1024
+        pre = None
+        if fused:
+            pre = y
+            with torch.cuda.device(y.device):
+                y = torch.empty_like(pre)
+                _lib.check(_lib.lib().vmasr_bias_gelu_fwd(pre.data_ptr(), bias.detach().float().contiguous().data_ptr(), y.data_ptr(),
+                                                          n, M, N, 1, _lib.current_stream(y.device)), "bias_gelu_fwd")
+        else:
+            y.add_(bias.detach().to(cdt).unsqueeze(1))
+            if act:
+                pre = y
+                y = F.gelu(pre)
+        ctx.save_for_backward(cols, wc, *([pre] if pre is not None else []))
+        ctx.meta = (weight.dtype, bias.dtype, act, fused)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        cols, wc = ctx.saved_tensors
-        wdt, bdt = ctx.meta
+        cols, wc, *rest = ctx.saved_tensors
+        wdt, bdt, act, fused = ctx.meta
         gy = gy.contiguous()
         n, M, N = gy.shape
         K = cols.shape[2]
+        skip_w = _PHASE["skip_weight_grads"]
+        db = None
+        if fused:
+            want_db = ctx.needs_input_grad[2] and not skip_w
+            with torch.cuda.device(gy.device):
+                gx = torch.empty_like(gy)
+                db32 = torch.zeros((n, N), dtype=torch.float32, device=gy.device) if want_db else None
+                _lib.check(_lib.lib().vmasr_gelu_bwd(rest[0].data_ptr(), gy.data_ptr(), gx.data_ptr(), db32.data_ptr() if want_db else None,
+                                                     n, M, N, _lib.current_stream(gy.device)), "gelu_bwd")
+            gy = gx
+            db = db32.to(bdt) if want_db else None
+        elif act:
+            gy = torch.ops.aten.gelu_backward(gy, rest[0])
         dcols = torch.bmm(gy, wc) if ctx.needs_input_grad[0] else None
-        dw = db = None
-        if _PHASE["skip_weight_grads"]:
-            return dcols, None, None, None
+        dw = None
+        if skip_w:
+            return dcols, None, None, None, None
         if ctx.needs_input_grad[1]:
             acc = torch.float32 if gy.dtype in (torch.float16, torch.bfloat16) else gy.dtype
             tiles = n * -(-N // 64) * -(-K // 64)
@@ -431,9 +460,9 @@ class _BatchedLinearFn(torch.autograd.Function):
             else:
                 dw = _mm_acc(gy.transpose(1, 2), cols, acc)
             dw = dw.to(wdt)
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and not fused:
             db = gy.sum(1, dtype=torch.float32 if gy.dtype in (torch.float16, torch.bfloat16) else None).to(bdt)
-        return dcols, dw, db, None
+        return dcols, dw, db, None, None
 
 
 def split_bf16(x):
@@ -782,16 +811,15 @@ class MultiPeriodDiscriminator(nn.Module):
             H1 = [(c.shape[2] + 2 * pad - k) // stride + 1 for c in cur]
             Ms = [B * p * h for p, h in zip(P, H1)]
             ws = [(l.weight.detach(), l.bias.detach()) if detach_weights else (l.weight, l.bias) for l in layers]
-            W = torch.stack([w[:, :, :, 0] for w, _ in ws])                         # (n, Cout, Cin, k)
-            W = W.permute(0, 1, 3, 2).reshape(n, W.shape[1], -1)                     # (tap, c) column order
+            # (n, Cout, k, Cin) -> (n, Cout, k*Cin): (tap, c) column order, gathered by the stack's own copy
+            W = torch.stack([w.squeeze(3).transpose(1, 2) for w, _ in ws])
+            W = W.reshape(n, W.shape[1], -1)
             act = li < len(discs[0].layers)
             if _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
                 y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, W, torch.stack([b for _, b in ws]), *cur)
             else:
                 cols = _StackedIm2ColFn.apply(k, stride, pad, _round_up(max(Ms), 256), *cur)
-                y = _BatchedLinearFn.apply(cols, W, torch.stack([b for _, b in ws]), cdt)
-                if act:
-                    y = F.gelu(y)
+                y = _BatchedLinearFn.apply(cols, W, torch.stack([b for _, b in ws]), cdt, act)
             outs = _UnstackRowsFn.apply(y, *Ms)
             cur = [o.view(B, p, h, -1) for o, p, h in zip(outs, P, H1)]
             for f, c in zip(fmaps, cur):
