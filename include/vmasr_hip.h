@@ -257,6 +257,17 @@ int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, v
 /* the same pass with the fp32 gradient as output (layers whose GEMMs stay fp32): gx = g * GELU'(pre), db += column sums */
 int vmasr_gelu_bwd(const float *pre, const float *g, float *gx, float *db, int32_t slots, int64_t M, int32_t N, vmasr_stream_t stream);
 
+/* Feature-matching loss of the stacked discriminator pass (model/loss.py:227-235: mean over maps of mean |r - g|):
+ *   real (n, rows_r, N), gen (n, rows_g, N) fp32; slot s compares its first valid[s] rows (valid, scale: HOST arrays);
+ *   fwd: partials[s * vmasr_masked_l1_blocks() + b] = scale[s] * partial sum of |gen - real| (fp64; the caller adds them),
+ *        sgn (n, rows_g, N) int8 (may be NULL) = sign(gen - real) on the valid part (the rest is not written);
+ *   bwd: dgen (n, rows_g, N) = gout[0] * scale[s] * sgn on the valid part, 0 on the padding rows (gout: DEVICE scalar). */
+int32_t vmasr_masked_l1_blocks(void);
+int vmasr_masked_l1_fwd(const float *real, const float *gen, void *sgn, double *partials, const int64_t *valid, const float *scale,
+                        int32_t n, int64_t rows_r, int64_t rows_g, int32_t N, vmasr_stream_t stream);
+int vmasr_masked_l1_bwd(const void *sgn, const float *gout, float *dgen, const int64_t *valid, const float *scale, int32_t n,
+                        int64_t rows_g, int32_t N, vmasr_stream_t stream);
+
 /* ---- fused SS2D core (vm_asr_amd/csrc/ss2d.hip) ---------------------------------------------------------
  * One operator for  y = CrossMerge(selective_scan(CrossScan(x), dt_proj(x_proj(.)), A, B, C, D, dt_bias, softplus))
  * of SS2D.forward_corev2 (model/vmamba.py:1472-1497; kernels: model/csm_triton.py:7-154,
@@ -354,6 +365,7 @@ enum {
     VMASR_K_SS2D_PRE,           /* xz -> (x channel-first, SiLU(z)) and its backward          */
     VMASR_K_LN_GATE,            /* LayerNorm_D(y^T) * SiLU(z) and its backward                */
     VMASR_K_STACK_ROWS,         /* gradient of the stacked discriminator views: copy + zero pad  */
+    VMASR_K_FEAT_L1,            /* feature-matching loss over the stacked feature maps, fwd + bwd   */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

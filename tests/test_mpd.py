@@ -528,3 +528,29 @@ def test_batched_linear_fused_gelu_matches_float64(n, M, K, N):
     for name, got, want in (("y", y, y64), ("dcols", cols.grad, c64.grad), ("dW", W.grad, W64.grad), ("db", b.grad, b64.grad)):
         err = (got.double() - want).abs().max().item() / want.abs().max().item()
         assert err <= 2e-5, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rows_g,rows_r,N,valid", [(5, 512, 1024, 128, (500, 512, 1, 257, 300)), (2, 256, 256, 1, (255, 7)),
+                                                     (3, 256, 512, 36, (256, 100, 33))])
+def test_masked_l1_kernels_match_float64(n, rows_g, rows_r, N, valid):
+    """csrc/featloss.hip: sum_s scale_s * sum_{r < valid_s} |gen - real| and its gradient (scale * sign on the valid rows,
+    exact zeros on the padding) against the masked torch expression in float64."""
+    from vm_asr_amd.discriminator import _MaskedL1Fn
+    torch.manual_seed(n + N)
+    real = torch.randn(n, rows_r, N, device="cuda")
+    gen = torch.randn(n, rows_g, N, device="cuda")
+    gen[0, 0, 0] = real[0, 0, 0]                                              # sign(0) = 0
+    gen.requires_grad_()
+    scale = tuple(1.0 / (m * N * 7) for m in valid)
+    loss = _MaskedL1Fn.apply(real, gen, valid, scale)
+    (loss * 3.0).backward()
+    g64 = gen.detach().double().requires_grad_()
+    R = min(rows_g, rows_r)
+    mask = (torch.arange(R, device="cuda").unsqueeze(0) < torch.tensor(valid, device="cuda").unsqueeze(1)).double()
+    w = mask * torch.tensor(scale, device="cuda", dtype=torch.float64).unsqueeze(1)
+    want = ((g64[:, :R] - real.double()[:, :R]).abs() * w.unsqueeze(2)).sum()
+    (want * 3.0).backward()
+    assert abs(loss.item() - want.item()) <= 2e-6 * abs(want.item())
+    assert torch.allclose(gen.grad.double(), g64.grad, rtol=1e-6, atol=0)
+    assert gen.grad[0, 0, 0] == 0 and not gen.grad[1, valid[1]:].any()

@@ -35,3 +35,13 @@ tot = sum(r[0] for r in rows)
 print(f"total self device time {tot / 1e3:.2f} ms over {sum(r[1] for r in rows)} op calls")
 for dt, n, k, sh in rows[:top]:
     print(f"{dt / 1e3:8.3f} ms {n:5d}  {k:40s} {sh}")
+
+if os.environ.get("TAIL_BY_NAME"):
+    from collections import defaultdict
+    agg = defaultdict(lambda: [0.0, 0])
+    for dt, n, k, _ in rows:
+        agg[k[:90]][0] += dt
+        agg[k[:90]][1] += n
+    print("---- by name (all shapes) ----")
+    for k, (dt, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ["TAIL_BY_NAME"])]:
+        print(f"{n:6d} calls {dt / 1e3:8.3f} ms  {k}")

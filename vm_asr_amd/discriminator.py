@@ -717,6 +717,51 @@ class StackedFeatures(list):
 _FEAT_MASKS = {}
 
 
+class _MaskedL1Fn(torch.autograd.Function):
+    """sum_s scale[s] * sum_{r < valid[s]} |gen[s, r] - real[s, r]| over two stacked fp32 feature tensors in one pass
+    (csrc/featloss.hip), gradient with respect to `gen` only (the real-signal features are constants of the
+    generator phase); the forward leaves sign(gen - real) as int8 for the one-pass backward."""
+
+    @staticmethod
+    def forward(ctx, real, gen, valid, scale):
+        import ctypes
+        n, rows_g, N = gen.shape
+        lib, dev = _lib.lib(), gen.device
+        nb = lib.vmasr_masked_l1_blocks()
+        v = (ctypes.c_int64 * n)(*valid)
+        sc = (ctypes.c_float * n)(*scale)
+        with torch.cuda.device(dev):
+            partials = torch.empty(n * nb, dtype=torch.float64, device=dev)
+            sgn = torch.empty((n, rows_g, N), dtype=torch.int8, device=dev) if ctx.needs_input_grad[1] else None
+            _lib.check(lib.vmasr_masked_l1_fwd(real.data_ptr(), gen.data_ptr(), sgn.data_ptr() if sgn is not None else None,
+                                               partials.data_ptr(), v, sc, n, real.shape[1], rows_g, N, _lib.current_stream(dev)), "masked_l1_fwd")
+        ctx.meta = (valid, scale, gen.shape)
+        if sgn is not None:
+            ctx.save_for_backward(sgn)
+        return partials.sum().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        (sgn,) = ctx.saved_tensors
+        valid, scale, (n, rows_g, N) = ctx.meta
+        v = (ctypes.c_int64 * n)(*valid)
+        sc = (ctypes.c_float * n)(*scale)
+        g = g.float().contiguous()
+        with torch.cuda.device(sgn.device):
+            dgen = torch.empty((n, rows_g, N), dtype=torch.float32, device=sgn.device)
+            _lib.check(_lib.lib().vmasr_masked_l1_bwd(sgn.data_ptr(), g.data_ptr(), dgen.data_ptr(), v, sc, n, rows_g, N,
+                                                      _lib.current_stream(sgn.device)), "masked_l1_bwd")
+        return None, dgen, None, None
+
+
+def _masked_l1_ok(yr, yg):
+    return (yg.is_cuda and yr.is_cuda and yg.dtype == torch.float32 and yr.dtype == torch.float32 and yg.is_contiguous()
+            and yr.is_contiguous() and not yr.requires_grad and yg.shape[0] <= 8 and yg.shape[0] == yr.shape[0]
+            and (yg.shape[1] * yg.shape[2]) % 4 == 0 and (yr.shape[1] * yr.shape[2]) % 4 == 0
+            and os.environ.get("VMASR_FEAT_L1", "1") == "1")
+
+
 def feature_loss_stacked(real, gen):
     """HiFi-GAN feature-matching loss (model/loss.py:227-235: mean over feature maps of mean |r - g|) from two
     StackedFeatures with the same per-slot row counts; None if the inputs do not qualify."""
@@ -728,6 +773,10 @@ def feature_loss_stacked(real, gen):
         R, N = min(yr.shape[1], yg.shape[1]), yg.shape[2]
         if max(valid) > R:
             return None
+        if _masked_l1_ok(yr, yg):
+            term = _MaskedL1Fn.apply(yr, yg, tuple(valid), tuple(1.0 / (m * N * n_maps) for m in valid))
+            total = term if total is None else total + term
+            continue
         key = (yg.device, valid, R, N, n_maps)
         mask = _FEAT_MASKS.get(key)
         if mask is None:       # 1 / (elements of the feature map * number of maps) on its rows, 0 on padding rows
