@@ -21,6 +21,7 @@ and LayerNorm stay in PyTorch (hipBLASLt / MIOpen).
 the product default is always the HIP operator set.
 """
 import math
+import os
 from functools import partial
 from typing import Any
 
@@ -152,6 +153,13 @@ def _strip(tag: str, value: str):
     if value.endswith(tag):
         return True, value[: -len(tag)]
     return False, value
+
+
+# d_inner up to which x_proj / dt_proj run as the position-parallel HIP map (csrc/xproj.hip) rather than as einsums.
+# Measured on the headline workload (train step, ms): 32 -> 45.2, 64 -> 43.7, 128 -> 43.7, 512 -> 46.6: at d_inner 64 the
+# einsum path's weight gradients are (64 x 4) GEMMs over a 16384-long contraction that hipBLASLt runs on one CU each
+# (0.1 ms per call); at 256 the map has too few positions (1024) to fill the chip and the GEMMs win.
+_XPROJ_MAX_D = int(os.environ.get("VMASR_XPROJ_MAX_D", "128"))
 
 
 class SS2D(nn.Module):
@@ -286,9 +294,9 @@ class SS2D(nn.Module):
             # high-resolution stages (d_state 1, dt_rank 1, d_inner <= 32) — csrc/ss2d.hip
             y = _ss2d.ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
             return y if merged_only else self._merge_norm(y, x, B, H, W, to_dtype)
-        if (hip_default and _xproj.supported(N, R, D) and D <= 32):
-            # (D <= 32: the map is parallel over positions only; the deep stages have few positions and
-            #  D = 64..256 rows, where the batched-GEMM einsums below are the better fit)
+        if (hip_default and _xproj.supported(N, R, D) and D <= _XPROJ_MAX_D):
+            # (the map is parallel over positions only; the deepest stages have few positions and D >= 256 rows,
+            #  where the batched-GEMM einsums below are the better fit: see _XPROJ_MAX_D)
             # HIP fast path: the scan streams are produced in fp32 directly and x_proj/dt_proj are one
             # memory-bound kernel writing scan-ready fp32 tensors (no einsum / contiguous / cast passes)
             xs = CrossScanF32.apply(x)                                         # (B, K, D, L) fp32
