@@ -422,7 +422,9 @@ def test_small_linear_vs_torch(io):
 # x_proj / dt_proj map vs the reference einsums (model/vmamba.py:1473-1477) in fp64
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg", [(2, 2, 1, 1, 4096), (2, 32, 1, 1, 1024), (1, 256, 1, 8, 256), (2, 16, 4, 2, 300),
-                                 (1, 128, 1, 4, 1023)], ids=str)
+                                 (1, 128, 1, 4, 1023),
+                                 # row-parallel kernels of the deep stages (d_inner >= 64, L % 4 == 0): full / ragged tiles, odd D
+                                 (2, 64, 1, 2, 4096), (3, 128, 1, 4, 1000), (1, 100, 2, 3, 200), (2, 64, 1, 2, 16384)], ids=str)
 def test_xproj_vs_einsum(cfg):
     from vm_asr_amd.xproj import x_proj_dt
     Bn, D, N, R, L = cfg

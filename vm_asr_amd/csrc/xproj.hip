@@ -139,15 +139,177 @@ __global__ __launch_bounds__(256) void xproj_bwd_a_kernel(const float *__restric
     }
 }
 
+// ---- D-parallel variants for the deep stages (d_inner >= 64, a few thousand positions) ------------------------------
+// The position-parallel kernels above walk the D rows serially per thread: at D = 128, L = 1024 that is 16 workgroups
+// and 128 dependent loads per thread — 107 us forward / 119 us backward for 8 MB of traffic, independent of the batch.
+// Here a workgroup owns 64 positions (16 quads) x 16 row groups: thread (q, dg) reduces rows dg, dg+16, ... of its quad,
+// the four row groups of a wave fold by DPP-free lane shuffles (xor 16, 32), the four waves through LDS; the expansion
+// back over D (dts = W_dt dtr, dxs = W_x^T dx_dbl) is again split by row group.  L/64 x K x B workgroups.
+constexpr int kDpTL = 64;
+constexpr int kDparMinD = 64;
+
+template <int NACC>
+__device__ __forceinline__ void dpar_reduce(float (&acc)[NACC][4], int n, float *red, int w, int q, bool writer) {
+#pragma unroll
+    for (int c = 0; c < NACC; ++c)
+        if (c < n) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[c][i];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                acc[c][i] = v;
+            }
+            if (writer) *reinterpret_cast<float4 *>(red + (c * 4 + w) * kDpTL + q * 4) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+        }
+}
+
+__device__ __forceinline__ void dpar_fold(const float *red, int c, int q, float (&o)[4]) {
+    o[0] = o[1] = o[2] = o[3] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float4 t = *reinterpret_cast<const float4 *>(red + (c * 4 + w) * kDpTL + q * 4);
+        o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xproj_fwd_dpar_kernel(const T *__restrict__ xs, const float *__restrict__ Wx,
+                                                             const float *__restrict__ Wdt, float *__restrict__ dts,
+                                                             float *__restrict__ Bs, float *__restrict__ Cs,
+                                                             float *__restrict__ dtr, const XpGeom g) {
+    extern __shared__ float s_w[];  // Wx[k]: C*D, Wdt[k]: D*R, red: C*4*64
+    const int C = g.R + 2 * g.N;
+    const int k = blockIdx.y, b = blockIdx.z;
+    float *s_wx = s_w, *s_wdt = s_w + C * g.D, *red = s_wdt + g.D * g.R;
+    for (int i = threadIdx.x; i < C * g.D; i += blockDim.x) s_wx[i] = Wx[(size_t)k * C * g.D + i];
+    for (int i = threadIdx.x; i < g.D * g.R; i += blockDim.x) s_wdt[i] = Wdt[(size_t)k * g.D * g.R + i];
+    __syncthreads();
+    const int q = threadIdx.x & 15, dg = threadIdx.x >> 4, w = threadIdx.x >> 6;
+    const int l0 = blockIdx.x * kDpTL + q * 4;
+    const bool in = l0 < g.L;                               // L % 4 == 0: a quad is all in or all out
+    const size_t bk = (size_t)b * g.K + k;
+    const T *xp = xs + bk * g.D * g.L;
+    float acc[kMaxC][4];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f;
+    if (in)
+        for (int d = dg; d < g.D; d += 16) {
+            float v[4];
+            load4<T, true>(xp + (size_t)d * g.L, l0, g.L, v);
+#pragma unroll
+            for (int c = 0; c < kMaxC; ++c)
+                if (c < C) {
+                    const float wv = s_wx[c * g.D + d];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[c][i] = fmaf(wv, v[i], acc[c][i]);
+                }
+        }
+    dpar_reduce<kMaxC>(acc, C, red, w, q, (dg & 3) == 0);
+    __syncthreads();
+    if (!in) return;
+    if (dg < C) {   // row dg of x_dbl: dt rows (kept for the backward), then B and C
+        float o[4];
+        dpar_fold(red, dg, q, o);
+        float *dst;
+        if (dg < g.R) dst = dtr + (bk * g.R + dg) * g.L;
+        else if (dg < g.R + g.N) dst = Bs + (bk * g.N + (dg - g.R)) * g.L;
+        else dst = Cs + (bk * g.N + (dg - g.R - g.N)) * g.L;
+        store4<float, true>(dst, l0, g.L, o);
+    }
+    float xr[kMaxR][4];
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r)
+        if (r < g.R) dpar_fold(red, r, q, xr[r]);
+    float *dp = dts + bk * g.D * g.L;
+    for (int d = dg; d < g.D; d += 16) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r)
+            if (r < g.R) {
+                const float wv = s_wdt[d * g.R + r];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = fmaf(wv, xr[r][i], o[i]);
+            }
+        store4<float, true>(dp + (size_t)d * g.L, l0, g.L, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xproj_bwd_a_dpar_kernel(const float *__restrict__ ddts, const float *__restrict__ dBs,
+                                                               const float *__restrict__ dCs, const float *__restrict__ du,
+                                                               const float *__restrict__ Wx, const float *__restrict__ Wdt,
+                                                               T *__restrict__ dxs, float *__restrict__ dxdbl, const XpGeom g) {
+    extern __shared__ float s_w[];
+    const int C = g.R + 2 * g.N;
+    const int k = blockIdx.y, b = blockIdx.z;
+    float *s_wx = s_w, *s_wdt = s_w + C * g.D, *red = s_wdt + g.D * g.R;
+    for (int i = threadIdx.x; i < C * g.D; i += blockDim.x) s_wx[i] = Wx[(size_t)k * C * g.D + i];
+    for (int i = threadIdx.x; i < g.D * g.R; i += blockDim.x) s_wdt[i] = Wdt[(size_t)k * g.D * g.R + i];
+    __syncthreads();
+    const int q = threadIdx.x & 15, dg = threadIdx.x >> 4, w = threadIdx.x >> 6;
+    const int l0 = blockIdx.x * kDpTL + q * 4;
+    const bool in = l0 < g.L;
+    const size_t bk = (size_t)b * g.K + k, row0 = bk * g.D;
+    float ar[kMaxR][4];
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r) ar[r][0] = ar[r][1] = ar[r][2] = ar[r][3] = 0.f;
+    // d_dtr[r] = sum_d Wdt[d,r] * ddts[d]
+    if (in)
+        for (int d = dg; d < g.D; d += 16) {
+            float v[4];
+            load4<float, true>(ddts + (row0 + d) * g.L, l0, g.L, v);
+#pragma unroll
+            for (int r = 0; r < kMaxR; ++r)
+                if (r < g.R) {
+                    const float wv = s_wdt[d * g.R + r];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ar[r][i] = fmaf(wv, v[i], ar[r][i]);
+                }
+        }
+    dpar_reduce<kMaxR>(ar, g.R, red, w, q, (dg & 3) == 0);
+    __syncthreads();
+    if (!in) return;
+    // dx_dbl = [d_dtr, dBs, dCs] for this quad (every row group needs all C rows for the expansion)
+    float xd[kMaxC][4];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+        if (c < C) {
+            if (c < g.R) dpar_fold(red, c, q, xd[c]);
+            else {
+                const float *src = c < g.R + g.N ? dBs + (bk * g.N + (c - g.R)) * g.L : dCs + (bk * g.N + (c - g.R - g.N)) * g.L;
+                load4<float, true>(src, l0, g.L, xd[c]);
+            }
+        }
+    if (dg == 0) {
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) store4<float, true>(dxdbl + (bk * C + c) * g.L, l0, g.L, xd[c]);
+    }
+    // dxs[d] = sum_c Wx[c,d] * dx_dbl[c] (+ du[d])
+    for (int d = dg; d < g.D; d += 16) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (du) load4<float, true>(du + (row0 + d) * g.L, l0, g.L, o);
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < C) {
+                const float wv = s_wx[c * g.D + d];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = fmaf(wv, xd[c][i], o[i]);
+            }
+        store4<T, true>(dxs + (row0 + d) * g.L, l0, g.L, o);
+    }
+}
+
 // one wave per (k, 4 rows d, 4096-position chunk of one batch element): partial dWx[k, c, d] and
 // dWdt[k, d, r] -> float atomics (a few hundred adds per address at most; outputs zero-initialised)
-constexpr int kXpChunk = 4096;
+constexpr int kXpChunk = 4096;   // positions per wave; 1024 when that leaves the chip under-filled (deep stages)
 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void xproj_bwd_b_kernel(const T *__restrict__ xs, const float *__restrict__ ddts,
                                                           const float *__restrict__ dxdbl, const float *__restrict__ dtr,
                                                           float *__restrict__ dWx, float *__restrict__ dWdt,
-                                                          const XpGeom g) {
+                                                          const XpGeom g, const int chunk) {
     constexpr int RW = 4;  // rows per wave
     const int C = g.R + 2 * g.N;
     const int lane = threadIdx.x & 63;
@@ -156,7 +318,7 @@ __global__ __launch_bounds__(256) void xproj_bwd_b_kernel(const T *__restrict__ 
     if (wid >= g.K * nrb) return;
     const int k = wid / nrb, d0 = (wid % nrb) * RW;
     const int b = blockIdx.z;
-    const int l_begin = blockIdx.y * kXpChunk, l_end = min(g.L, l_begin + kXpChunk);
+    const int l_begin = blockIdx.y * chunk, l_end = min(g.L, l_begin + chunk);
     float ax[RW][kMaxC], at[RW][kMaxR];
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
@@ -249,6 +411,16 @@ VMASR_EXPORT int vmasr_xproj_fwd(const void *xs, const float *Wx, const float *W
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double es = dtype == VMASR_F32 ? 4 : 2;
     const double bytes = (double)B * K * L * (D * (es + 4.0) + (C + 0.0) * 4.0);
+    const size_t smd = sm + (size_t)C * 4 * kDpTL * sizeof(float);
+    if (vec && D >= kDparMinD && smd <= 64 * 1024) {   // deep stages: row-parallel workgroups (see xproj_fwd_dpar_kernel)
+        const dim3 gd((L + kDpTL - 1) / kDpTL, K, B);
+#define VMASR_XPD(TT) VMASR_LAUNCH(VMASR_K_XPROJ_FWD, bytes, (xproj_fwd_dpar_kernel<TT>), gd, dim3(256), smd, st, (const TT *)xs, Wx, Wdt, dts, Bs, Cs, dtr, g)
+        if (dtype == VMASR_F32) VMASR_XPD(float);
+        else if (dtype == VMASR_F16) VMASR_XPD(f16_t);
+        else VMASR_XPD(bf16_t);
+#undef VMASR_XPD
+        return check_launch("xproj_fwd");
+    }
 #define VMASR_XP(TT, V) VMASR_LAUNCH(VMASR_K_XPROJ_FWD, bytes, (xproj_fwd_kernel<TT, V>), grid, dim3(256), sm, st, (const TT *)xs, Wx, Wdt, dts, Bs, Cs, dtr, g)
     if (dtype == VMASR_F32) { if (vec) VMASR_XP(float, true); else VMASR_XP(float, false); }
     else if (dtype == VMASR_F16) { if (vec) VMASR_XP(f16_t, true); else VMASR_XP(f16_t, false); }
@@ -276,13 +448,20 @@ VMASR_EXPORT int vmasr_xproj_bwd(const void *xs, const float *Wx, const float *W
     const double bytes_a = (double)B * K * L * (D * (4.0 + es + (du ? 4.0 : 0.0)) + 2.0 * C * 4.0);
     const double bytes_b = (double)B * K * L * (D * (4.0 + es) + (double)(C + R) * 4.0);
     const int nwaves = K * ((D + 3) / 4);
+    const size_t smd = sm + (size_t)C * 4 * kDpTL * sizeof(float);
+    const bool dpar = vec && D >= kDparMinD && smd <= 64 * 1024;
+    const dim3 gd((L + kDpTL - 1) / kDpTL, K, B);
+    // weight gradients: one wave per (4 rows, chunk of positions); shorter chunks when 4096 leaves < 4 waves per CU
+    const int chunk = ((long)((nwaves + 3) / 4) * ((L + kXpChunk - 1) / kXpChunk) * B < 1024 && L > 1024) ? 1024 : kXpChunk;
 #define VMASR_XPB(TT, V)                                                                                                 \
     do {                                                                                                                 \
-        VMASR_LAUNCH(VMASR_K_XPROJ_BWD_A, bytes_a, (xproj_bwd_a_kernel<TT, V>), grid, dim3(256), sm, st, ddts, dBs, dCs, du, \
-                     Wx, Wdt, (TT *)dxs, ws, g);                                                                         \
+        if (dpar) VMASR_LAUNCH(VMASR_K_XPROJ_BWD_A, bytes_a, (xproj_bwd_a_dpar_kernel<TT>), gd, dim3(256), smd, st, ddts, dBs, dCs, du, \
+                               Wx, Wdt, (TT *)dxs, ws, g);                                                               \
+        else VMASR_LAUNCH(VMASR_K_XPROJ_BWD_A, bytes_a, (xproj_bwd_a_kernel<TT, V>), grid, dim3(256), sm, st, ddts, dBs, dCs, du, \
+                          Wx, Wdt, (TT *)dxs, ws, g);                                                                    \
         VMASR_LAUNCH(VMASR_K_XPROJ_BWD_B, bytes_b, (xproj_bwd_b_kernel<TT, V>),                                           \
-                     dim3((nwaves + 3) / 4, (L + kXpChunk - 1) / kXpChunk, B), dim3(256), 0, st,                          \
-                     (const TT *)xs, ddts, ws, dtr, dWx, dWdt, g);                                                       \
+                     dim3((nwaves + 3) / 4, (L + chunk - 1) / chunk, B), dim3(256), 0, st,                                \
+                     (const TT *)xs, ddts, ws, dtr, dWx, dWdt, g, chunk);                                                \
     } while (0)
     if (dtype == VMASR_F32) { if (vec) VMASR_XPB(float, true); else VMASR_XPB(float, false); }
     else if (dtype == VMASR_F16) { if (vec) VMASR_XPB(f16_t, true); else VMASR_XPB(f16_t, false); }

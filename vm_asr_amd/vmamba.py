@@ -155,11 +155,11 @@ def _strip(tag: str, value: str):
     return False, value
 
 
-# d_inner up to which x_proj / dt_proj run as the position-parallel HIP map (csrc/xproj.hip) rather than as einsums.
-# Measured on the headline workload (train step, ms): 32 -> 45.2, 64 -> 43.7, 128 -> 43.7, 512 -> 46.6: at d_inner 64 the
-# einsum path's weight gradients are (64 x 4) GEMMs over a 16384-long contraction that hipBLASLt runs on one CU each
-# (0.1 ms per call); at 256 the map has too few positions (1024) to fill the chip and the GEMMs win.
-_XPROJ_MAX_D = int(os.environ.get("VMASR_XPROJ_MAX_D", "128"))
+# d_inner up to which x_proj / dt_proj run as the HIP map (csrc/xproj.hip) rather than as einsums.  As batched GEMMs the
+# deep stages' weight gradients are (64 x 4) products over a 16384-long contraction that hipBLASLt runs on one CU per
+# direction (0.1 ms per call); the map's row-parallel kernels (d_inner >= 64) take 15-30 us per pass.  Train step of the
+# headline workload: einsums for d_inner >= 64: 45.2 ms; map up to 128: 41.8 ms; up to 256 (all it supports): 41.4 ms.
+_XPROJ_MAX_D = int(os.environ.get("VMASR_XPROJ_MAX_D", "512"))
 
 
 class SS2D(nn.Module):
@@ -295,8 +295,7 @@ class SS2D(nn.Module):
             y = _ss2d.ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
             return y if merged_only else self._merge_norm(y, x, B, H, W, to_dtype)
         if (hip_default and _xproj.supported(N, R, D) and D <= _XPROJ_MAX_D):
-            # (the map is parallel over positions only; the deepest stages have few positions and D >= 256 rows,
-            #  where the batched-GEMM einsums below are the better fit: see _XPROJ_MAX_D)
+            # (position-parallel kernels for d_inner <= 32, row-parallel ones above; see _XPROJ_MAX_D)
             # HIP fast path: the scan streams are produced in fp32 directly and x_proj/dt_proj are one
             # memory-bound kernel writing scan-ready fp32 tensors (no einsum / contiguous / cast passes)
             xs = CrossScanF32.apply(x)                                         # (B, K, D, L) fp32
