@@ -145,10 +145,22 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 }
 
 // wave64 all-reduce sum (result valid in every lane)
+// Sum over the 64 lanes of a wave, returned in every lane.  DPP only (4 in-row butterfly steps, 2 row broadcasts, one
+// v_readlane): `__shfl_xor` compiles to ds_bpermute_b32 on gfx9 — an LDS-pipe round trip per step, 6 per sum, and the
+// fused SS2D backward does 56 sums per wave-tile (336 of its 4 000 instructions were bpermutes, each followed by a wait).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {   // v + (v moved by CTRL); lanes without a source / masked rows add 0
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v = dpp_add<0xB1>(v);           // quad_perm [1,0,3,2]: lane ^ 1
+    v = dpp_add<0x4E>(v);           // quad_perm [2,3,0,1]: lane ^ 2
+    v = dpp_add<0x141>(v);          // row_half_mirror: the other quad of each 8 lanes
+    v = dpp_add<0x140>(v);          // row_mirror: the other half of each 16-lane row -> every lane holds its row's sum
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // XCD-aware block remap (blocks b and b+8 share an XCD under round-robin dispatch): give
