@@ -153,6 +153,50 @@ __device__ __forceinline__ float dpp_add(float v) {   // v + (v moved by CTRL); 
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
 
+// Several wave sums at once (butterfly with halving): NV values per lane -> every lane l ends up with the wave total of
+// value (l & (NV-1)).  Step k pairs the values (2j, 2j+1): lanes with bit k clear keep 2j and hand 2j+1 to their partner
+// (lane ^ 2^k) and vice versa, so the number of live values halves while the lane distance doubles: NV - 1 + log2(64/NV)
+// exchanges instead of 6 NV, and the exchanges of one step are independent of each other (no DPP wait states).
+// lane ^ 1, ^ 2: quad_perm; ^ 4, ^ 8: row_shl / row_shr under complementary bank masks; ^ 16, ^ 32: ds_bpermute.
+template <int CTRL_LO, int BANKS_LO, int CTRL_HI, int BANKS_HI>
+__device__ __forceinline__ float dpp_xor_row(float send) {   // value of the lane at distance 4 (or 8) across the bank pattern
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL_LO, 0xf, BANKS_LO, false);
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(send), CTRL_HI, 0xf, BANKS_HI, false);
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)); }
+__device__ __forceinline__ float xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)); }
+__device__ __forceinline__ float xor4(float v) { return dpp_xor_row<0x104, 0x5, 0x114, 0xA>(v); }   // row_shl:4 banks 0,2 | row_shr:4 banks 1,3
+__device__ __forceinline__ float xor8(float v) { return dpp_xor_row<0x108, 0x3, 0x118, 0xC>(v); }   // row_shl:8 banks 0,1 | row_shr:8 banks 2,3
+
+// lane l (any l) returns the wave total of v[l & 3]
+__device__ __forceinline__ float wave_sum4(const float (&v)[4], const int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float w0 = (b0 ? v[1] : v[0]) + xor1(b0 ? v[0] : v[1]);
+    const float w1 = (b0 ? v[3] : v[2]) + xor1(b0 ? v[2] : v[3]);
+    float y = (b1 ? w1 : w0) + xor2(b1 ? w0 : w1);
+    y += xor4(y);
+    y += xor8(y);
+    y += __shfl_xor(y, 16);
+    y += __shfl_xor(y, 32);
+    return y;
+}
+
+// lane l (any l) returns the wave total of v[l & 7]
+__device__ __forceinline__ float wave_sum8(const float (&v)[8], const int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (b0 ? v[2 * j + 1] : v[2 * j]) + xor1(b0 ? v[2 * j] : v[2 * j + 1]);
+    const float x0 = (b1 ? w[1] : w[0]) + xor2(b1 ? w[0] : w[1]);
+    const float x1 = (b1 ? w[3] : w[2]) + xor2(b1 ? w[2] : w[3]);
+    float y = (b2 ? x1 : x0) + xor4(b2 ? x0 : x1);
+    y += xor8(y);
+    y += __shfl_xor(y, 16);
+    y += __shfl_xor(y, 32);
+    return y;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0xB1>(v);           // quad_perm [1,0,3,2]: lane ^ 1
     v = dpp_add<0x4E>(v);           // quad_perm [2,3,0,1]: lane ^ 2

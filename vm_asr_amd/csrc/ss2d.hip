@@ -419,11 +419,10 @@ __global__ __launch_bounds__(64 * WPT * TPG, (64 * WPT * TPG) >= 512 ? 2 : 3) vo
                 G6[kk * 3 + 2][i] = fmaf(dout[r][i], hv[i], G6[kk * 3 + 2][i]);            // d C
             }
             // per-row parameter gradients of this tile (dWx comes after the cross-row reduction below)
-            const float sA = wave_sum(accA) * Araw, sD = wave_sum(accD), sDt = wave_sum(accDt), sB = wave_sum(accBias);
-            if (lane == 0) {
-                float *pp = part + ((size_t)kk * D + d0 + r) * kNPart;
-                pp[3] = sDt; pp[4] = sB; pp[5] = sA; pp[6] = sD;   // dA_log = dA * A (A = -exp(A_log))
-            }
+            // (one butterfly for the four sums: lane l < 4 ends with the total of value l)
+            const float four[4] = {accDt, accBias, accA * Araw, accD};   // dA_log = dA * A (A = -exp(A_log))
+            const float tot4 = wave_sum4(four, lane);
+            if (lane < 4) part[((size_t)kk * D + d0 + r) * kNPart + 3 + lane] = tot4;
         }
     }
     if constexpr (MODE == 1) {
@@ -431,19 +430,19 @@ __global__ __launch_bounds__(64 * WPT * TPG, (64 * WPT * TPG) >= 512 ? 2 : 3) vo
         float *dst = (pair ? q.dx13 : q.dx02) + off;
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kc = 0; kc < 6; ++kc) {
                 const int k = pair + 2 * (kc / 3), c = kc % 3;
                 const float w = a.Wx[((size_t)k * 3 + c) * D + d0 + r];
-                float acc = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     du[r][i] = fmaf(w, G6[kc][i], du[r][i]);
-                    acc = fmaf(G6[kc][i], u[r][i], acc);
+                    acc8[kc] = fmaf(G6[kc][i], u[r][i], acc8[kc]);
                 }
-                const float sW = wave_sum(acc);
-                if (lane == 0) part[((size_t)(kc / 3) * D + d0 + r) * kNPart + c] = sW;
             }
+            const float sW = wave_sum8(acc8, lane);   // lane kc < 6: dWx partial of (direction kc / 3, component kc % 3)
+            if (lane < 6) part[((size_t)(lane / 3) * D + d0 + r) * kNPart + lane % 3] = sW;
             *reinterpret_cast<float4 *>(dst + (size_t)r * L) = make_float4(du[r][0], du[r][1], du[r][2], du[r][3]);
         }
     }
