@@ -1,3 +1,4 @@
+# build: cd tools/lt_probe && hipcc --offload-arch=gfx950 -O2 -o lt_probe lt_probe.cpp -lhipblaslt
 # shapes (column-major as torch.bmm passes them): fwd4, dcols4, dW4 (S=3), fwd3, dcols3, dW3, fwd2, dcols2, dW2 (S=8)
 P=tools/lt_probe/lt_probe
 R=6144
