@@ -23,10 +23,16 @@ namespace {
 
 constexpr int kMaxVecPerLane = 4;  // C <= 64 lanes * 4 elems * 4 vectors = 1024
 
+// sum over the LPR adjacent lanes of a row group (LPR | 64), in every lane of the group: DPP for distances <= 8
+// (common.h: quad_perm / row shifts under bank masks), ds_bpermute only for 16 and 32
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if constexpr (LPR >= 2) v += xor1(v);
+    if constexpr (LPR >= 4) v += xor2(v);
+    if constexpr (LPR >= 8) v += xor4(v);
+    if constexpr (LPR >= 16) v += xor8(v);
+    if constexpr (LPR >= 32) v += __shfl_xor(v, 16);
+    if constexpr (LPR >= 64) v += __shfl_xor(v, 32);
     return v;
 }
 
