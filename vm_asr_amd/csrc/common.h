@@ -211,7 +211,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // each XCD a contiguous run of logical blocks so neighbours that share operand tiles hit
 // the same L2.  Pure speed: any placement is correct.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-    return (nblocks % 8 == 0) ? (bid % 8) * (nblocks / 8) + bid / 8 : bid;
+    const int x = bid % 8, q = nblocks / 8, r = nblocks % 8;   // XCD x runs blocks x, x + 8, ...: q (+1 if x < r) of them
+    return x * q + (x < r ? x : r) + bid / 8;
 }
 
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
