@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void stft_like_kernel(const float *__restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FftSmem s = carve(smem, n, true);
     const int F = n / 2 + 1, pad = n / 2;
-    const int b = blockIdx.y, m0 = blockIdx.x * kFR;
+    // neighbouring frame groups read overlapping samples and write the same 128-byte lines of the (B, F, M) outputs:
+    // keep them on one XCD (see istft_frames_kernel)
+    const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int b = lin / gridDim.x, m0 = (lin % gridDim.x) * kFR;
     const float *x = in + (size_t)b * T;
     setup_tables(s, n, win);
     __syncthreads();
