@@ -257,6 +257,25 @@ int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, v
 /* the same pass with the fp32 gradient as output (layers whose GEMMs stay fp32): gx = g * GELU'(pre), db += column sums */
 int vmasr_gelu_bwd(const float *pre, const float *g, float *gx, float *db, int32_t slots, int64_t M, int32_t N, vmasr_stream_t stream);
 
+/* AdamW step of many parameter tensors in one launch (torch.optim.AdamW semantics, utils/optimizer.py:16-50 of the
+ * reference; non-amsgrad, decoupled weight decay, bias correction).  `items` is a DEVICE array, one entry per tensor;
+ * `chunks` a DEVICE array of (item index, chunk index) int32 pairs, one per workgroup, chunk = vmasr_adamw_chunk() elements;
+ * lr and step (the step count AFTER this update, as float) are DEVICE scalars read at run time.  lp (may be NULL): bf16
+ * copy of the updated parameter, written in the same pass.  vec: set when p, g, m, v are 16-byte and lp 8-byte aligned. */
+typedef struct vmasr_adamw_item {
+    float *p;
+    const float *g;
+    float *m;
+    float *v;
+    void *lp;
+    int64_t n;
+    float weight_decay;
+    int32_t vec;
+} vmasr_adamw_item;
+int32_t vmasr_adamw_chunk(void);
+int vmasr_adamw_step(const vmasr_adamw_item *items, const int32_t *chunks, int32_t nchunks, int64_t total_elems, const float *lr,
+                     const float *step, float beta1, float beta2, float eps, vmasr_stream_t stream);
+
 /* Feature-matching loss of the stacked discriminator pass (model/loss.py:227-235: mean over maps of mean |r - g|):
  *   real (n, rows_r, N), gen (n, rows_g, N) fp32; slot s compares its first valid[s] rows (valid, scale: HOST arrays);
  *   fwd: partials[s * vmasr_masked_l1_blocks() + b] = scale[s] * partial sum of |gen - real| (fp64; the caller adds them),
@@ -366,6 +385,7 @@ enum {
     VMASR_K_LN_GATE,            /* LayerNorm_D(y^T) * SiLU(z) and its backward                */
     VMASR_K_STACK_ROWS,         /* gradient of the stacked discriminator views: copy + zero pad  */
     VMASR_K_FEAT_L1,            /* feature-matching loss over the stacked feature maps, fwd + bwd   */
+    VMASR_K_ADAMW,              /* AdamW step of all parameters (+ bf16 shadow refresh), one launch */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

@@ -2,6 +2,7 @@
 one train step of G+MPD runs, updates parameters, leaves the 129 never-used tensors untouched;
 world_size-2 gloo DDP gives both ranks identical parameters equal to a single-process step on
 the concatenated batch."""
+import numpy as np
 import os
 import sys
 
@@ -509,3 +510,51 @@ def test_wgan_gp_penalty_on_gpu_matches_cpu():
             continue
         assert torch.allclose(q.grad.cpu(), p.grad, rtol=5e-3, atol=1e-4 * p.grad.abs().max().item() + 1e-8), n
     assert sum(q.grad is not None and float(q.grad.abs().max()) > 0 for q in E.parameters()) >= 30
+
+
+@pytest.mark.gpu
+def test_hip_adamw_step_matches_torch_fused_adamw():
+    """fused_adamw.HipAdamWStep (csrc/adamw.hip: one launch for all tensors, bf16 shadows in the same pass) ==
+    torch.optim.AdamW(fused, capturable) on the same state, over several steps with a changing device learning rate:
+    parameters, exp_avg, exp_avg_sq, step counters; odd sizes, unaligned gradient views, two weight-decay groups."""
+    from vm_asr_amd.fused_adamw import HipAdamWStep
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    shapes = [(1024, 33), (7,), (4097,), (64, 5, 3, 1), (1,), (8192,), (3, 5)]
+    flat = torch.zeros(sum(int(np.prod(s)) for s in shapes) + 3, device=dev)
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+        off = 3                                                      # gradient views start at an odd offset: unaligned
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        lr = torch.tensor(1e-3, device=dev)
+        groups = [{"params": [p for p in ps if p.ndim > 1]}, {"params": [p for p in ps if p.ndim <= 1], "weight_decay": 0.0}]
+        return ps, lr, torch.optim.AdamW(groups, lr=lr, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.05, capturable=True, fused=True)
+    torch.manual_seed(4)
+    pa, lra, oa = make()
+    torch.manual_seed(4)
+    pb, lrb, ob = make()
+    flat.normal_()
+    oa.step(); ob.step()                                             # torch creates the state
+    with pytest.raises(ValueError):
+        HipAdamWStep(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(3, device=dev))], lr=1e-3))   # not capturable / host lr
+    shadows = {id(p): p.detach().to(torch.bfloat16) for p in pb if p.ndim > 1}
+    hip = HipAdamWStep(ob, shadows)
+    for it in range(4):
+        flat.normal_()
+        lra.fill_(1e-3 / (it + 1)); lrb.fill_(1e-3 / (it + 1))
+        oa.step()
+        hip.step()
+    assert hip.still_valid()
+    for x, y in zip(pa, pb):
+        sa, sb = oa.state[x], ob.state[y]
+        assert float(sa["step"]) == float(sb["step"]) == 5.0
+        for name, u, v in (("p", x, y), ("m", sa["exp_avg"], sb["exp_avg"]), ("v", sa["exp_avg_sq"], sb["exp_avg_sq"])):
+            err = (u - v).abs().max().item()
+            assert err <= 2e-6 * max(1e-3, u.abs().max().item()), (name, tuple(x.shape), err)
+        if id(y) in shadows:
+            assert torch.equal(shadows[id(y)], y.detach().to(torch.bfloat16))
+    pb[0].grad = torch.zeros_like(pb[0])
+    assert not hip.still_valid()

@@ -80,6 +80,8 @@ SYMBOLS = {
     "vmasr_split_bf16": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vmasr_bias_gelu_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_gelu_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "vmasr_adamw_chunk": (c_i32, []),
+    "vmasr_adamw_step": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp]),
     "vmasr_masked_l1_blocks": (c_i32, []),
     "vmasr_masked_l1_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "vmasr_masked_l1_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
@@ -155,7 +157,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 42
+K_COUNT = 43
 
 
 def zeros_f32(device, *shapes):

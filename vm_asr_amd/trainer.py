@@ -624,11 +624,43 @@ class Trainer(BaseTrainer):
         return ctx()
 
     def _optimizer_steps(self):
-        """AdamW for G (and D), then refresh the low-precision shadow weights (what graph B captures)."""
+        """AdamW for G (and D), then refresh the low-precision shadow weights (what graph B captures).
+        With flat gradient buffers and capturable AdamW the update of each model is ONE launch of the HIP library
+        (fused_adamw.HipAdamWStep: same state tensors, same arithmetic, bf16 shadows written in the same pass)."""
+        fused = self._hip_adamw_steps()
+        if fused is not None:
+            for f in fused:       # (the kernel also writes the bf16 shadow of every parameter it updates;
+                f.step()          #  parameters without a gradient do not change, their shadows stay valid)
+            return
         self.optimizer_G.step()
         if self.gan:
             self.optimizer_D.step()
         self._refresh_shadows()
+
+    def _hip_adamw_steps(self):
+        """The HipAdamWStep objects of this trainer's optimisers, built once the optimiser states exist (after the first
+        torch step) and the gradients live in the flat buffers; None -> use optimizer.step()."""
+        if self.device.type != "cuda" or self.dp_mode != "flat" or os.environ.get("VMASR_HIP_ADAMW", "1") != "1":
+            return None
+        cur = getattr(self, "_hip_adamw", None)
+        if cur is not None and all(f.still_valid() for f in cur):
+            return cur
+        if getattr(self, "_hip_adamw_failed", False):
+            return None
+        from .fused_adamw import HipAdamWStep
+        opts = [("generator", self.optimizer_G)] + ([("mpd", self.optimizer_D)] if self.gan else [])
+        if any(k not in self._flat for k, _ in opts):
+            return None
+        shadows = {id(src): dst for src, dst in zip(self._shadow_params, self._shadow_dst)}
+        try:
+            built = [HipAdamWStep(o, shadows) for _, o in opts]
+        except ValueError as e:
+            if "not initialised" in str(e):
+                return None                       # first step: torch creates the state, the next call builds the table
+            self._hip_adamw_failed = True
+            return None
+        self._hip_adamw = built
+        return built
 
     def _reduce_and_step(self):
         if self.gan:
@@ -643,20 +675,24 @@ class Trainer(BaseTrainer):
         vm_asr_amd.linear uses instead of casting the fp32 weight in every forward (300 cast kernels
         per step); the copies are refreshed by one multi-tensor copy after the optimiser steps."""
         from .linear import LP_ATTR
-        self._shadow_src, self._shadow_dst = [], []
+        self._shadow_src, self._shadow_dst, self._shadow_params = [], [], []
         if not (self.amp and self.device.type == "cuda") or os.environ.get("VMASR_LP_SHADOWS", "1") != "1":
             return
-        for m in self.models.values():
+        for key, m in self.models.items():
             if m is None:
                 continue
+            if key != "generator" and self.amp_scope != "step":
+                continue          # the discriminator runs outside autocast in the reference's AMP scope: no bf16 reader
             for p in unwrap(m).parameters():
                 if p.requires_grad and p.dtype == torch.float32:
                     lp = p.detach().to(torch.bfloat16)
                     setattr(p, LP_ATTR, lp)
                     self._shadow_src.append(p.detach())
                     self._shadow_dst.append(lp)
+                    self._shadow_params.append(p)
 
     def _refresh_shadows(self):
+        """bf16 shadows <- fp32 parameters (one multi-tensor copy): after optimizer.step() / load_state_dict."""
         if self._shadow_dst:
             torch._foreach_copy_(self._shadow_dst, self._shadow_src)
 
