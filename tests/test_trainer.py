@@ -556,5 +556,10 @@ def test_hip_adamw_step_matches_torch_fused_adamw():
             assert err <= 2e-6 * max(1e-3, u.abs().max().item()), (name, tuple(x.shape), err)
         if id(y) in shadows:
             assert torch.equal(shadows[id(y)], y.detach().to(torch.bfloat16))
+    import copy
+    ob.load_state_dict(copy.deepcopy(ob.state_dict()))               # a resume: new state tensors, the pointer table is stale
+    assert not hip.still_valid()
+    hip = HipAdamWStep(ob, shadows)
+    assert hip.still_valid()
     pb[0].grad = torch.zeros_like(pb[0])
     assert not hip.still_valid()

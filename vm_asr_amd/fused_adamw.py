@@ -68,12 +68,19 @@ class HipAdamWStep:
         self.items = torch.from_numpy(np.array(items, dtype=_ITEM).view(np.uint8).copy()).to(dev)
         self.chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
         self.nchunks, self.total = len(chunks), sum(it[5] for it in items)
-        self.steps, self._keep, self.grad_ptrs = steps, keep, [it[1] for it in items]
+        self.steps, self._keep, self._ptrs = steps, keep, [it[:4] for it in items]
         self.optimizer = optimizer
 
     def still_valid(self):
-        """The table holds raw pointers: it is stale if a parameter's .grad was re-bound (e.g. zero_grad(set_to_none))."""
-        return all(p.grad is not None and p.grad.data_ptr() == q for (p, *_), q in zip(self._keep, self.grad_ptrs))
+        """The table holds raw pointers: it is stale once a parameter's .grad was re-bound (zero_grad(set_to_none), a new
+        flat buffer) or the optimiser state was replaced (load_state_dict creates new exp_avg / exp_avg_sq / step tensors)."""
+        state = self.optimizer.state
+        for (p, _, _, _, _), (pp, gp, mp, vp), step in zip(self._keep, self._ptrs, self.steps):
+            st = state.get(p)
+            if (p.grad is None or not st or p.data_ptr() != pp or p.grad.data_ptr() != gp or st["exp_avg"].data_ptr() != mp
+                    or st["exp_avg_sq"].data_ptr() != vp or st["step"] is not step):
+                return False
+        return True
 
     @torch.no_grad()
     def step(self):
