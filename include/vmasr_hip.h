@@ -276,6 +276,17 @@ int32_t vmasr_adamw_chunk(void);
 int vmasr_adamw_step(const vmasr_adamw_item *items, const int32_t *chunks, int32_t nchunks, int64_t total_elems, const float *lr,
                      const float *step, float beta1, float beta2, float eps, vmasr_stream_t stream);
 
+/* Spectrally normalised weights of one discriminator layer, stacked for the batched pass (model/discriminator.py:26-45:
+ * spectral_norm around every convolution; sigma, u, v from the power iteration are constants for autograd):
+ *   fwd: out (n, N, k*Cin) with out[s, o, j*Cin + c] = W_s[o, c, j] / sigma_s   (W_s: (N, Cin, k) fp32, HOST array of n pointers)
+ *   bwd: gW_s[o, c, j] = (dW[s, o, j*Cin + c] - <dW_s, Wn_s> u_s[o] v_s[c*k + j]) / sigma_s, Wn = the forward's output;
+ *        partials: n * vmasr_sn_dot_blocks() doubles of scratch.  sigmas / us / vs / gws: HOST arrays of device pointers. */
+int32_t vmasr_sn_dot_blocks(void);
+int vmasr_sn_stack_fwd(const void *const *weights, const void *const *sigmas, int32_t n, float *out, int32_t N, int32_t Cin, int32_t k,
+                       vmasr_stream_t stream);
+int vmasr_sn_stack_bwd(const float *dW, const float *Wn, void *const *gws, const void *const *sigmas, const void *const *us,
+                       const void *const *vs, int32_t n, double *partials, int32_t N, int32_t Cin, int32_t k, vmasr_stream_t stream);
+
 /* Feature-matching loss of the stacked discriminator pass (model/loss.py:227-235: mean over maps of mean |r - g|):
  *   real (n, rows_r, N), gen (n, rows_g, N) fp32; slot s compares its first valid[s] rows (valid, scale: HOST arrays);
  *   fwd: partials[s * vmasr_masked_l1_blocks() + b] = scale[s] * partial sum of |gen - real| (fp64; the caller adds them),

@@ -80,6 +80,9 @@ SYMBOLS = {
     "vmasr_split_bf16": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vmasr_bias_gelu_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_gelu_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "vmasr_sn_dot_blocks": (c_i32, []),
+    "vmasr_sn_stack_fwd": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_sn_stack_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_adamw_chunk": (c_i32, []),
     "vmasr_adamw_step": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp]),
     "vmasr_masked_l1_blocks": (c_i32, []),

@@ -224,3 +224,126 @@ VMASR_EXPORT int vmasr_spectral_power_iter(const float *W, float *u, float *v, f
     }
     return check_launch("spectral_power_iter");
 }
+
+// ---- spectrally normalised, stacked GEMM weights of one discriminator layer (all n period discriminators) -----------
+// model/discriminator.py:26-45 wraps every convolution in spectral_norm: W / sigma, sigma = u^T W v with u, v from the
+// power iteration (constants for autograd).  The batched discriminator pass wants the n weights of a layer as ONE
+// (n, N, K) operand in (tap, channel) column order.  As ATen ops that is n divisions, a stack and — in the backward —
+// per weight a dot product, an outer-product update and a division (25+ launches per layer).  Here:
+//   fwd  : out[s, o, j*Cin + c] = W_s[o, c, j] / sigma_s                                   one launch per layer
+//   dot  : partial sums of <dW_s, out_s> (fp64 per workgroup)                              one launch
+//   bwd  : gW_s[o, c, j] = (dW[s, o, j*Cin + c] - <dW_s, out_s> u_s[o] v_s[c*k + j]) / sigma_s   one launch
+// One workgroup per (s, o) row; the (Cin x k) <-> (k x Cin) permutation of a row goes through LDS so that both the
+// read and the write are contiguous.  Pure streaming: 8 B per element forward, 8 + 8 B backward.
+namespace vmasr {
+namespace {
+
+constexpr int kSnMaxSlots = 8;
+constexpr int kSnDotBlocks = 64;
+
+struct SnSlots {
+    const float *w[kSnMaxSlots];       // fwd: original weights (N, Cin, k); bwd: unused
+    float *gw[kSnMaxSlots];            // bwd: gradient wrt the original weights
+    const float *sigma[kSnMaxSlots];   // device scalars
+    const float *u[kSnMaxSlots];       // (N)
+    const float *v[kSnMaxSlots];       // (Cin * k)
+};
+
+__global__ __launch_bounds__(256) void sn_stack_fwd_kernel(const SnSlots t, float *__restrict__ out, const int N, const int Cin, const int k) {
+    extern __shared__ float row[];
+    const int s = blockIdx.y, o = blockIdx.x, K = Cin * k;
+    const float inv = 1.f / t.sigma[s][0];
+    const float *src = t.w[s] + (size_t)o * K;
+    for (int i = threadIdx.x; i < K; i += 256) row[i] = src[i] * inv;          // (c, j) order
+    __syncthreads();
+    float *dst = out + ((size_t)s * N + o) * K;
+    for (int e = threadIdx.x; e < K; e += 256) dst[e] = row[(e % Cin) * k + e / Cin];   // (j, c) order
+}
+
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float *__restrict__ dW, const float *__restrict__ Wn, double *__restrict__ partials,
+                                                     const size_t per_slot) {
+    const int s = blockIdx.y;
+    const float4 *a = reinterpret_cast<const float4 *>(dW + (size_t)s * per_slot), *b = reinterpret_cast<const float4 *>(Wn + (size_t)s * per_slot);
+    const size_t n4 = per_slot / 4;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i];
+        acc += (double)((x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w));
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < per_slot; i += 256) acc += (double)dW[(size_t)s * per_slot + i] * Wn[(size_t)s * per_slot + i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)s * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void sn_stack_bwd_kernel(const SnSlots t, const float *__restrict__ dW, const double *__restrict__ partials,
+                                                           const int N, const int Cin, const int k) {
+    extern __shared__ float row[];
+    __shared__ float s_dot;
+    const int s = blockIdx.y, o = blockIdx.x, K = Cin * k;
+    if (threadIdx.x < 64) {
+        double d = threadIdx.x < kSnDotBlocks ? partials[(size_t)s * kSnDotBlocks + threadIdx.x] : 0.0;
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if (threadIdx.x == 0) s_dot = (float)d;
+    }
+    const float *src = dW + ((size_t)s * N + o) * K;
+    for (int e = threadIdx.x; e < K; e += 256) row[(e % Cin) * k + e / Cin] = src[e];   // (j, c) -> (c, j)
+    __syncthreads();
+    const float inv = 1.f / t.sigma[s][0], su = s_dot * t.u[s][o];
+    const float *v = t.v[s];
+    float *dst = t.gw[s] + (size_t)o * K;
+    for (int i = threadIdx.x; i < K; i += 256) dst[i] = (row[i] - su * v[i]) * inv;
+}
+
+int sn_fill(SnSlots &t, const void *const *w, void *const *gw, const void *const *sigma, const void *const *u, const void *const *v, int n,
+            const char *what) {
+    VMASR_REQUIRE(n > 0 && n <= kSnMaxSlots, VMASR_EINVAL, "%s: 1..%d slots (got %d)", what, kSnMaxSlots, n);
+    for (int s = 0; s < n; ++s) {
+        VMASR_REQUIRE(sigma[s] && (!w || w[s]) && (!gw || (gw[s] && u[s] && v[s])), VMASR_EINVAL, "%s: null pointer in slot %d", what, s);
+        t.w[s] = w ? static_cast<const float *>(w[s]) : nullptr;
+        t.gw[s] = gw ? static_cast<float *>(gw[s]) : nullptr;
+        t.sigma[s] = static_cast<const float *>(sigma[s]);
+        t.u[s] = u ? static_cast<const float *>(u[s]) : nullptr;
+        t.v[s] = v ? static_cast<const float *>(v[s]) : nullptr;
+    }
+    return 0;
+}
+
+}  // namespace
+}  // namespace vmasr
+
+using namespace vmasr;
+
+VMASR_EXPORT int32_t vmasr_sn_dot_blocks(void) { return kSnDotBlocks; }
+
+VMASR_EXPORT int vmasr_sn_stack_fwd(const void *const *weights, const void *const *sigmas, int32_t n, float *out, int32_t N, int32_t Cin,
+                                    int32_t k, vmasr_stream_t stream) {
+    VMASR_REQUIRE(weights && sigmas && out, VMASR_EINVAL, "sn_stack_fwd: null argument");
+    VMASR_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && k > 0 && (size_t)Cin * k * 4 <= 60 * 1024, VMASR_EINVAL, "sn_stack_fwd: bad shape");
+    SnSlots t{};
+    if (int e = sn_fill(t, weights, nullptr, sigmas, nullptr, nullptr, n, "sn_stack_fwd")) return e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VMASR_LAUNCH(VMASR_K_SPECTRAL, 8.0 * n * (double)N * Cin * k, sn_stack_fwd_kernel, dim3(N, n), dim3(256), (size_t)Cin * k * 4, st, t, out, N,
+                 Cin, k);
+    return check_launch("sn_stack_fwd");
+}
+
+VMASR_EXPORT int vmasr_sn_stack_bwd(const float *dW, const float *Wn, void *const *gws, const void *const *sigmas, const void *const *us,
+                                    const void *const *vs, int32_t n, double *partials, int32_t N, int32_t Cin, int32_t k,
+                                    vmasr_stream_t stream) {
+    VMASR_REQUIRE(dW && Wn && gws && sigmas && us && vs && partials, VMASR_EINVAL, "sn_stack_bwd: null argument");
+    VMASR_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && k > 0 && (size_t)Cin * k * 4 <= 60 * 1024, VMASR_EINVAL, "sn_stack_bwd: bad shape");
+    VMASR_REQUIRE(aligned_to(dW, 16) && aligned_to(Wn, 16), VMASR_EINVAL, "sn_stack_bwd: dW and Wn must be 16-byte aligned");
+    SnSlots t{};
+    if (int e = sn_fill(t, nullptr, gws, sigmas, us, vs, n, "sn_stack_bwd")) return e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t per_slot = (size_t)N * Cin * k;
+    VMASR_REQUIRE(per_slot % 4 == 0 || n == 1, VMASR_EINVAL, "sn_stack_bwd: N * Cin * k must be a multiple of 4 for stacked slots");
+    VMASR_LAUNCH(VMASR_K_SPECTRAL, 8.0 * n * (double)per_slot, sn_dot_kernel, dim3(kSnDotBlocks, n), dim3(256), 0, st, dW, Wn, partials, per_slot);
+    VMASR_LAUNCH(VMASR_K_SPECTRAL, 8.0 * n * (double)per_slot, sn_stack_bwd_kernel, dim3(N, n), dim3(256), (size_t)Cin * k * 4, st, t, dW, partials,
+                 N, Cin, k);
+    return check_launch("sn_stack_bwd");
+}

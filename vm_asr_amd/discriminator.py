@@ -121,6 +121,66 @@ class _SNDivFn(torch.autograd.Function):
         return gw.view_as(out), None, None, None
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[ctypes.c_void_p(t.data_ptr()) for t in tensors])
+
+
+class _SNStackFn(torch.autograd.Function):
+    """The spectrally normalised weights of one layer of all n period discriminators as ONE (n, N, k*Cin) GEMM operand in
+    (tap, channel) column order: out[s] = permute(W_s / sigma_s) with sigma_s, u_s, v_s from the batched power iteration
+    (constants, as in torch's spectral_norm).  One launch forward, two backward (csrc/spectral.hip) instead of n divisions +
+    a stack and, per weight, a dot product, an outer-product update and a division."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        sig, us, vs, ws = args[:n], args[n:2 * n], args[2 * n:3 * n], args[3 * n:]
+        N, Cin, k = ws[0].shape[0], ws[0].shape[1], ws[0].shape[2]
+        dev = ws[0].device
+        wc = [w.detach().contiguous() for w in ws]
+        with torch.cuda.device(dev):
+            out = torch.empty((n, N, k * Cin), dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().vmasr_sn_stack_fwd(_ptr_array(wc), _ptr_array(sig), n, out.data_ptr(), N, Cin, k,
+                                                     _lib.current_stream(dev)), "sn_stack_fwd")
+        ctx.save_for_backward(out, *sig, *us, *vs)
+        ctx.geom = (n, N, Cin, k, [w.shape for w in ws])
+        return out
+
+    @staticmethod
+    def backward(ctx, dW):
+        n, N, Cin, k, shapes = ctx.geom
+        out, *rest = ctx.saved_tensors
+        sig, us, vs = rest[:n], rest[n:2 * n], rest[2 * n:3 * n]
+        dW = dW.float().contiguous()
+        lib, dev = _lib.lib(), dW.device
+        with torch.cuda.device(dev):
+            gws = [torch.empty(shp, dtype=torch.float32, device=dev) for shp in shapes]
+            partials = torch.empty(n * lib.vmasr_sn_dot_blocks(), dtype=torch.float64, device=dev)
+            _lib.check(lib.vmasr_sn_stack_bwd(dW.data_ptr(), out.data_ptr(), _ptr_array(gws), _ptr_array(sig), _ptr_array(us), _ptr_array(vs),
+                                              n, partials.data_ptr(), N, Cin, k, _lib.current_stream(dev)), "sn_stack_bwd")
+        return (None, *([None] * (3 * n)), *gws)
+
+
+def _sn_stack(layers):
+    """_SNStackFn over the n same-shaped spectrally normalised convolutions `layers`, or None when they do not qualify
+    (sigmas not precomputed by SpectralBatch.run, eval mode, other dtypes / devices): the caller then stacks `l.weight`."""
+    sns, origs = [], []
+    for l in layers:
+        if not (isinstance(l, nn.Conv2d) and parametrize.is_parametrized(l, "weight")):
+            return None
+        sn, w = l.parametrizations.weight[0], l.parametrizations.weight.original
+        if not (isinstance(sn, _SpectralNorm) and getattr(sn, "_sigma_pre", None) is not None and sn.training and sn.n_power_iterations == 0
+                and w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and w.shape[3] == 1):
+            return None
+        sns.append(sn); origs.append(w)
+    n = len(layers)
+    if n > 8 or any(w.shape != origs[0].shape for w in origs) or origs[0].shape[1] * origs[0].shape[2] * 4 > 60 * 1024:
+        return None
+    if n > 1 and (origs[0].numel() % 4):
+        return None
+    return _SNStackFn.apply(n, *[sn._sigma_pre for sn in sns], *[sn._u for sn in sns], *[sn._v for sn in sns], *origs)
+
+
 class SpectralBatch:
     """Power iteration of MANY _SpectralNorm modules in one launch per phase
     (vmasr_spectral_power_iter_batched): the descriptor table (pointers to the fp32 weights, u, v and
@@ -839,6 +899,22 @@ class MultiPeriodDiscriminator(nn.Module):
     def __init__(self, hidden=32, periods=(2, 3, 5, 7, 11)):
         super().__init__()
         self.discriminators = nn.ModuleList([PeriodDiscriminator(p, hidden=hidden) for p in periods])
+        self._frozen = None      # per-layer stacked weights while frozen_weights() is active
+
+    def frozen_weights(self):
+        """Context in which the caller guarantees that the (normalised) weights do not change — inside
+        torch.nn.utils.parametrize.cached() within one training step: the batched passes then share the stacked
+        weight of each layer instead of rebuilding it per pass."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            object.__setattr__(self, "_frozen", {})
+            try:
+                yield
+            finally:
+                object.__setattr__(self, "_frozen", None)
+        return ctx()
 
     def _forward_batched(self, x, detach_weights=False):
         """All discriminators layer by layer on stacked GEMM operands (GPU path).  Same scores and feature maps
@@ -859,10 +935,25 @@ class MultiPeriodDiscriminator(nn.Module):
             P = [c.shape[1] for c in cur]
             H1 = [(c.shape[2] + 2 * pad - k) // stride + 1 for c in cur]
             Ms = [B * p * h for p, h in zip(P, H1)]
-            ws = [(l.weight.detach(), l.bias.detach()) if detach_weights else (l.weight, l.bias) for l in layers]
-            # (n, Cout, k, Cin) -> (n, Cout, k*Cin): (tap, c) column order, gathered by the stack's own copy
-            W = torch.stack([w.squeeze(3).transpose(1, 2) for w, _ in ws])
-            W = W.reshape(n, W.shape[1], -1)
+            W = None
+            if os.environ.get("VMASR_SN_STACK", "1") == "1":
+                # normalisation, stack and (tap, c) permutation of the layer's n weights in one launch; while the trainer
+                # holds the weights fixed for the step (frozen_weights()) the passes share it — one gradient path back
+                key = (li, bool(detach_weights))
+                W = self._frozen.get(key) if self._frozen is not None else None
+                if W is None:
+                    W = _sn_stack(layers)
+                    if W is not None and detach_weights:
+                        W = W.detach()
+                    if W is not None and self._frozen is not None:
+                        self._frozen[key] = W
+            if W is not None:
+                ws = [(None, l.bias.detach() if detach_weights else l.bias) for l in layers]
+            else:
+                ws = [(l.weight.detach(), l.bias.detach()) if detach_weights else (l.weight, l.bias) for l in layers]
+                # (n, Cout, k, Cin) -> (n, Cout, k*Cin): (tap, c) column order, gathered by the stack's own copy
+                W = torch.stack([w.squeeze(3).transpose(1, 2) for w, _ in ws])
+                W = W.reshape(n, W.shape[1], -1)
             act = li < len(discs[0].layers)
             if _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
                 y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, W, torch.stack([b for _, b in ws]), *cur)

@@ -614,7 +614,7 @@ class Trainer(BaseTrainer):
             for m in sns:
                 m.n_power_iterations = 0 if batched else n_it
             try:
-                with parametrize.cached():
+                with parametrize.cached(), (mpd.frozen_weights() if hasattr(mpd, "frozen_weights") else contextlib.nullcontext()):
                     yield
             finally:
                 for m, n in zip(sns, saved):
