@@ -252,6 +252,8 @@ int vmasr_bias_gelu_fwd(float *acc, const float *bias, float *act, int32_t slots
 /* w (n, N, K) fp32 -> out (n, K, 3N) bf16 = [hi^T | hi^T | lo^T] of the bf16 split of w: the B operands of the
  * forward GEMM triple (column blocks 0 and 2) and of the concatenated-contraction column-gradient GEMM (all of it) */
 int vmasr_weight_prep_split(const float *w, void *out, int32_t n, int32_t N, int32_t K, vmasr_stream_t stream);
+/* out (n, NK) = sum over p < P, s < S of parts (P, n, S, NK): the partial products of a split weight-gradient GEMM triple */
+int vmasr_sum_parts(const float *parts, float *out, int32_t P, int32_t n, int32_t S, int64_t NK, vmasr_stream_t stream);
 int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, void *cat3, float *db, int32_t slots, int64_t M,
                          int32_t N, vmasr_stream_t stream);
 /* the same pass with the fp32 gradient as output (layers whose GEMMs stay fp32): gx = g * GELU'(pre), db += column sums */

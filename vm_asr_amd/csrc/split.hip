@@ -182,6 +182,40 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
 }  // namespace
 }  // namespace vmasr
 
+namespace vmasr {
+namespace {
+// out[i, e] = sum_{p < P} sum_{s < S} parts[((p * n + i) * S + s) * NK + e]: the three products x S contraction slabs of a
+// weight-gradient GEMM triple (discriminator.py: _dw3) in one streaming pass (ATen's strided two-axis reduction runs
+// this shape at 2.3 TB/s).  grid (blocks, n); NK % 4 == 0.
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float *__restrict__ parts, float *__restrict__ out, const int P, const int n,
+                                                        const int S, const size_t NK4) {
+    const int i = blockIdx.y;
+    float4 *o = reinterpret_cast<float4 *>(out) + (size_t)i * NK4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < NK4; e += (size_t)gridDim.x * 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < P; ++p)
+            for (int s = 0; s < S; ++s) {
+                const float4 v = reinterpret_cast<const float4 *>(parts)[(((size_t)p * n + i) * S + s) * NK4 + e];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        o[e] = acc;
+    }
+}
+}  // namespace
+}  // namespace vmasr
+
+VMASR_EXPORT int vmasr_sum_parts(const float *parts, float *out, int32_t P, int32_t n, int32_t S, int64_t NK, vmasr_stream_t stream) {
+    using namespace vmasr;
+    VMASR_REQUIRE(parts && out, VMASR_EINVAL, "sum_parts: null tensor");
+    VMASR_REQUIRE(P > 0 && n > 0 && n <= 65535 && S > 0 && NK > 0 && NK % 4 == 0 && aligned_to(parts, 16) && aligned_to(out, 16), VMASR_EINVAL,
+                  "sum_parts: bad shape / alignment (NK must be a multiple of 4)");
+    const size_t NK4 = (size_t)NK / 4;
+    const int blocks = (int)std::min<size_t>((NK4 + 255) / 256, 256 * 8);
+    VMASR_LAUNCH(VMASR_K_SPLIT_BF16, 4.0 * ((double)P * S + 1.0) * n * (double)NK, sum_parts_kernel, dim3(blocks, n), dim3(256), 0,
+                 static_cast<hipStream_t>(stream), parts, out, P, n, S, NK4);
+    return check_launch("sum_parts");
+}
+
 VMASR_EXPORT int vmasr_weight_prep_split(const float *w, void *out, int32_t n, int32_t N, int32_t K, vmasr_stream_t stream) {
     VMASR_REQUIRE(w && out, VMASR_EINVAL, "weight_prep_split: null tensor");
     VMASR_REQUIRE(n > 0 && n <= 65535 && N > 0 && K > 0, VMASR_EINVAL, "weight_prep_split: bad shape (n=%d N=%d K=%d)", n, N, K);

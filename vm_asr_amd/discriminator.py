@@ -577,6 +577,11 @@ def _dw3(gh, gl, ch, cl, wdt):
     torch.bmm(ght, v(ch), out_dtype=torch.float32, out=parts[0])
     torch.bmm(glt, v(ch), out_dtype=torch.float32, out=parts[1])
     torch.bmm(ght, v(cl), out_dtype=torch.float32, out=parts[2])
+    if (N * K) % 4 == 0 and n <= 65535:
+        with torch.cuda.device(gh.device):
+            dw = torch.empty((n, N, K), dtype=torch.float32, device=gh.device)
+            _lib.check(_lib.lib().vmasr_sum_parts(parts.data_ptr(), dw.data_ptr(), 3, n, S, N * K, _lib.current_stream(gh.device)), "sum_parts")
+        return dw.to(wdt)
     return parts.view(3, n, S, N, K).sum((0, 2)).to(wdt)
 
 
