@@ -289,6 +289,17 @@ int vmasr_sn_stack_fwd(const void *const *weights, const void *const *sigmas, in
 int vmasr_sn_stack_bwd(const float *dW, const float *Wn, void *const *gws, const void *const *sigmas, const void *const *us,
                        const void *const *vs, int32_t n, double *partials, int32_t N, int32_t Cin, int32_t k, vmasr_stream_t stream);
 
+/* conv_post of the period discriminators (model/discriminator.py:45,106-109: Conv2d(C, 1, (3,1), 1, padding (1,0))) directly on
+ * the previous layer's stacked output x (n, rows, C) fp32: slot s holds Ms[s] valid rows = whole sequences of Hs[s] positions
+ * (zero padding at the sequence ends), w (n, 3, C) in (tap, channel) order, b (n); y (n, rows) (0 on the padding rows).
+ * bwd: dx (n, rows, C) (zeros on the padding rows), dw (n, 3, C) and db (n) ACCUMULATED (zero-initialised by the caller);
+ * each may be NULL.  Ms / Hs: HOST arrays.  C in {256, 512, 768, 1024}, kernel 3 (vmasr_conv_post_supported). */
+int vmasr_conv_post_supported(int32_t C, int32_t k);
+int vmasr_conv_post_fwd(const float *x, const float *w, const float *b, float *y, const int64_t *Ms, const int32_t *Hs, int32_t n, int64_t rows,
+                        int32_t C, int32_t k, vmasr_stream_t stream);
+int vmasr_conv_post_bwd(const float *x, const float *w, const float *gy, float *dx, float *dw, float *db, const int64_t *Ms, const int32_t *Hs,
+                        int32_t n, int64_t rows, int32_t C, int32_t k, vmasr_stream_t stream);
+
 /* Feature-matching loss of the stacked discriminator pass (model/loss.py:227-235: mean over maps of mean |r - g|):
  *   real (n, rows_r, N), gen (n, rows_g, N) fp32; slot s compares its first valid[s] rows (valid, scale: HOST arrays);
  *   fwd: partials[s * vmasr_masked_l1_blocks() + b] = scale[s] * partial sum of |gen - real| (fp64; the caller adds them),
@@ -399,6 +410,7 @@ enum {
     VMASR_K_STACK_ROWS,         /* gradient of the stacked discriminator views: copy + zero pad  */
     VMASR_K_FEAT_L1,            /* feature-matching loss over the stacked feature maps, fwd + bwd   */
     VMASR_K_ADAMW,              /* AdamW step of all parameters (+ bf16 shadow refresh), one launch */
+    VMASR_K_CONV_POST,          /* the discriminators' 1024 -> 1 output convolution on the stacked maps */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

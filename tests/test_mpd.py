@@ -582,3 +582,41 @@ def test_sn_stack_matches_per_weight_normalisation(n, N, Cin, k):
         gw = (g64 - dot * u.unsqueeze(1) * v.unsqueeze(0)) / sg
         err = (ws[s].grad.double().flatten(1) - gw).abs().max().item()
         assert err <= 2e-6 * gw.abs().max().item() + 1e-7 * abs(dot.item()), (s, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [256, 1024])
+def test_conv_post_direct_matches_float64_conv(C):
+    """_StackedConvPostFn (csrc/convpost.hip: the C -> 1 channel, kernel 3 output convolution directly on the stacked feature
+    maps) == torch conv1d per sequence in float64: scores, and the gradients wrt the maps (zeros on the padding rows), the
+    weights and the biases; ragged slots (different sequence counts / lengths, a slot that fills all rows, an empty one)."""
+    from vm_asr_amd.discriminator import _StackedConvPostFn
+    torch.manual_seed(C)
+    dev = "cuda"
+    geoms = [(6, 37), (4, 64), (0, 5), (9, 28), (1, 256)]                      # (sequences, positions) per slot
+    n, rows = len(geoms), 256
+    Ms, Hs = tuple(N * H for N, H in geoms), tuple(H for _, H in geoms)
+    assert max(Ms) <= rows
+    x = torch.randn(n, rows, C, device=dev)                                   # padding rows hold garbage on purpose
+    W = (torch.randn(n, 1, 3 * C, device=dev) / (3 * C) ** 0.5).requires_grad_()
+    b = torch.randn(n, 1, device=dev, requires_grad=True)
+    xr = x.clone().requires_grad_()
+    y = _StackedConvPostFn.apply(Ms, Hs, W, b, xr)
+    g = torch.randn_like(y)
+    y.backward(g)
+    for s, (N, H) in enumerate(geoms):
+        M = N * H
+        assert not y[s, M:].any() and not xr.grad[s, M:].any()
+        if M == 0:
+            assert not W.grad[s].any() and b.grad[s].item() == 0
+            continue
+        x64 = x[s, :M].double().view(N, H, C).transpose(1, 2).clone().requires_grad_()      # (N, C, H)
+        w64 = W[s, 0].detach().double().view(3, C).t().reshape(1, C, 3).clone().requires_grad_()   # (1, C, 3)
+        b64 = b[s].detach().double().clone().requires_grad_()
+        ref = torch.nn.functional.conv1d(x64, w64, b64, padding=1)                            # (N, 1, H)
+        ref.backward(g[s, :M, 0].double().view(N, 1, H))
+        assert torch.allclose(y[s, :M, 0].double(), ref.view(-1), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(xr.grad[s, :M].double(), x64.grad.transpose(1, 2).reshape(M, C), rtol=1e-5, atol=1e-6)
+        gw = w64.grad[0].t().reshape(3 * C)                                                   # back to (tap, c) order
+        assert (W.grad[s, 0].double() - gw).abs().max() <= 2e-5 * gw.abs().max()
+        assert abs(b.grad[s].item() - b64.grad.item()) <= 1e-5 * max(1.0, abs(b64.grad.item()))

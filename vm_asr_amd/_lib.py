@@ -83,6 +83,9 @@ SYMBOLS = {
     "vmasr_sn_dot_blocks": (c_i32, []),
     "vmasr_sn_stack_fwd": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_sn_stack_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_conv_post_supported": (ctypes.c_int, [c_i32, c_i32]),
+    "vmasr_conv_post_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
+    "vmasr_conv_post_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_adamw_chunk": (c_i32, []),
     "vmasr_adamw_step": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp]),
     "vmasr_masked_l1_blocks": (c_i32, []),
@@ -161,7 +164,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 43
+K_COUNT = 44
 
 
 def zeros_f32(device, *shapes):

@@ -733,6 +733,48 @@ class _StackedConvSplitFn(torch.autograd.Function):
         return (None, None, None, None, None, dw, db, *dxs)
 
 
+class _StackedConvPostFn(torch.autograd.Function):
+    """conv_post (C -> 1 channels, kernel (3,1), stride 1, padding 1) of all n period discriminators directly on the previous
+    layer's stacked output x (n, rows, C) — csrc/convpost.hip: one streaming pass forward, one backward, instead of a
+    (rows, 3C) im2col operand feeding a GEMV.  W (n, 1, 3C) in (tap, channel) order, bias (n, 1); Ms[i] valid rows =
+    whole sequences of Hs[i] positions.  Returns (n, rows, 1)."""
+
+    @staticmethod
+    def forward(ctx, Ms, Hs, W, bias, x):
+        import ctypes
+        n, rows, C = x.shape
+        lib, dev = _lib.lib(), x.device
+        xc, w32, b32 = x.contiguous(), W.detach().float().contiguous(), bias.detach().float().contiguous()
+        ms, hs = (ctypes.c_int64 * n)(*Ms), (ctypes.c_int32 * n)(*Hs)
+        with torch.cuda.device(dev):
+            y = torch.empty((n, rows, 1), dtype=torch.float32, device=dev)
+            _lib.check(lib.vmasr_conv_post_fwd(xc.data_ptr(), w32.data_ptr(), b32.data_ptr(), y.data_ptr(), ms, hs, n, rows, C, 3,
+                                               _lib.current_stream(dev)), "conv_post_fwd")
+        ctx.save_for_backward(xc, w32)
+        ctx.meta = (tuple(Ms), tuple(Hs), W.dtype, bias.dtype, tuple(bias.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes
+        xc, w32 = ctx.saved_tensors
+        Ms, Hs, wdt, bdt, bshape = ctx.meta
+        n, rows, C = xc.shape
+        lib, dev = _lib.lib(), xc.device
+        gy = gy.float().contiguous()
+        skip_w = _PHASE["skip_weight_grads"]
+        want_dx, want_dw, want_db = ctx.needs_input_grad[4], ctx.needs_input_grad[2] and not skip_w, ctx.needs_input_grad[3] and not skip_w
+        ms, hs = (ctypes.c_int64 * n)(*Ms), (ctypes.c_int32 * n)(*Hs)
+        with torch.cuda.device(dev):
+            dx = torch.empty_like(xc) if want_dx else None
+            dw = torch.zeros((n, 1, 3 * C), dtype=torch.float32, device=dev) if want_dw else None
+            db = torch.zeros(n, dtype=torch.float32, device=dev) if want_db else None
+            _lib.check(lib.vmasr_conv_post_bwd(xc.data_ptr(), w32.data_ptr(), gy.data_ptr(), dx.data_ptr() if want_dx else None,
+                                               dw.data_ptr() if want_dw else None, db.data_ptr() if want_db else None, ms, hs, n, rows, C, 3,
+                                               _lib.current_stream(dev)), "conv_post_bwd")
+        return (None, None, dw.to(wdt) if want_dw else None, db.view(bshape).to(bdt) if want_db else None, dx)
+
+
 class _UnstackRowsFn(torch.autograd.Function):
     """(n, rows, N) -> n views y[i, :M_i]; the backward assembles the stacked gradient with one copy per slot
     (autograd's own select/slice backward would zero-fill a full-size tensor per slot)."""
@@ -960,11 +1002,17 @@ class MultiPeriodDiscriminator(nn.Module):
                 W = torch.stack([w.squeeze(3).transpose(1, 2) for w, _ in ws])
                 W = W.reshape(n, W.shape[1], -1)
             act = li < len(discs[0].layers)
-            if _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
-                y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, W, torch.stack([b for _, b in ws]), *cur)
+            bstack = torch.stack([b for _, b in ws])
+            if (not act and stacks and cdt == torch.float32 and k == 3 and stride == 1 and pad == 1 and W.shape[1] == 1
+                    and stacks[-1].dtype == torch.float32 and os.environ.get("VMASR_CONV_POST", "1") == "1"
+                    and _lib.lib().vmasr_conv_post_supported(stacks[-1].shape[2], k)):
+                # the 1-channel output convolution straight on the previous layer's stacked maps (no column operand)
+                y = _StackedConvPostFn.apply(tuple(valid[-1]), tuple(c.shape[2] for c in cur), W, bstack, stacks[-1])
+            elif _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
+                y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, W, bstack, *cur)
             else:
                 cols = _StackedIm2ColFn.apply(k, stride, pad, _round_up(max(Ms), 256), *cur)
-                y = _BatchedLinearFn.apply(cols, W, torch.stack([b for _, b in ws]), cdt, act)
+                y = _BatchedLinearFn.apply(cols, W, bstack, cdt, act)
             outs = _UnstackRowsFn.apply(y, *Ms)
             cur = [o.view(B, p, h, -1) for o, p, h in zip(outs, P, H1)]
             for f, c in zip(fmaps, cur):
