@@ -300,6 +300,16 @@ int vmasr_conv_post_fwd(const float *x, const float *w, const float *b, float *y
 int vmasr_conv_post_bwd(const float *x, const float *w, const float *gy, float *dx, float *dw, float *db, const int64_t *Ms, const int32_t *Hs,
                         int32_t n, int64_t rows, int32_t C, int32_t k, vmasr_stream_t stream);
 
+/* First convolution of the period discriminators (model/discriminator.py:26-40,100-104: Conv2d(1, 32, (5,1), (3,1), padding
+ * (2,0)) + GELU) for all n discriminators in one launch: xs[s] (Ns[s] sequences x Hs[s] samples, fp32; HOST arrays),
+ * w (n, 32, 5), b (n, 32) -> pre, act (n, rows, 32) (zeros on the padding rows).  bwd: g = d loss / d act ->
+ * dcols (n, rows, 5) = gradient of the (rows, 5) column operand (scatter it with vmasr_col2im_kx1_multi), dw (n, 32, 5) and
+ * db (n, 32) ACCUMULATED (zero-initialised by the caller); each may be NULL. */
+int vmasr_conv_first_fwd(const void *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, const float *w, const float *b, float *pre,
+                         float *act, int64_t rows, vmasr_stream_t stream);
+int vmasr_conv_first_bwd(const void *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, const float *w, const float *pre,
+                         const float *g, float *dcols, float *dw, float *db, int64_t rows, vmasr_stream_t stream);
+
 /* Feature-matching loss of the stacked discriminator pass (model/loss.py:227-235: mean over maps of mean |r - g|):
  *   real (n, rows_r, N), gen (n, rows_g, N) fp32; slot s compares its first valid[s] rows (valid, scale: HOST arrays);
  *   fwd: partials[s * vmasr_masked_l1_blocks() + b] = scale[s] * partial sum of |gen - real| (fp64; the caller adds them),

@@ -620,3 +620,38 @@ def test_conv_post_direct_matches_float64_conv(C):
         gw = w64.grad[0].t().reshape(3 * C)                                                   # back to (tap, c) order
         assert (W.grad[s, 0].double() - gw).abs().max() <= 2e-5 * gw.abs().max()
         assert abs(b.grad[s].item() - b64.grad.item()) <= 1e-5 * max(1.0, abs(b64.grad.item()))
+
+
+@pytest.mark.gpu
+def test_conv_first_direct_matches_float64_conv():
+    """_StackedConvFirstFn (csrc/convfirst.hip: Conv2d(1, 32, (5,1), (3,1), padding 2) + GELU of all period discriminators in one
+    launch) == torch conv1d + GELU per sequence in float64: activations and the gradients wrt signals, weights, biases."""
+    from vm_asr_amd.discriminator import _StackedConvFirstFn, _round_up
+    torch.manual_seed(11)
+    dev = "cuda"
+    B = 2
+    geoms = [(2, 301), (3, 200), (5, 121), (7, 86), (11, 55)]                   # (period, folded length)
+    xs = [torch.randn(B, p, H, 1, device=dev, requires_grad=True) for p, H in geoms]
+    n = len(xs)
+    H1 = [(H + 4 - 5) // 3 + 1 for _, H in geoms]
+    Ms = [B * p * h for (p, _), h in zip(geoms, H1)]
+    rows = _round_up(max(Ms), 256)
+    W = (torch.randn(n, 32, 5, device=dev) / 5 ** 0.5).requires_grad_()
+    b = torch.randn(n, 32, device=dev, requires_grad=True)
+    act = _StackedConvFirstFn.apply(rows, W, b, *xs)
+    g = torch.randn_like(act)
+    for s, m in enumerate(Ms):
+        g[s, m:] = 0                                     # what the real graph delivers on the padding rows
+    act.backward(g)
+    for s, ((p, H), h1, m) in enumerate(zip(geoms, H1, Ms)):
+        assert not act[s, m:].any()
+        x64 = xs[s].detach().double().view(B * p, 1, H).clone().requires_grad_()
+        w64 = W[s].detach().double().view(32, 1, 5).clone().requires_grad_()
+        b64 = b[s].detach().double().clone().requires_grad_()
+        ref = torch.nn.functional.gelu(torch.nn.functional.conv1d(x64, w64, b64, stride=3, padding=2))     # (N, 32, H1)
+        ref.backward(g[s, :m].double().view(B * p, h1, 32).transpose(1, 2))
+        got = act[s, :m].double().view(B * p, h1, 32).transpose(1, 2)
+        assert torch.allclose(got, ref, rtol=1e-5, atol=2e-6)
+        assert torch.allclose(xs[s].grad.double().view(B * p, 1, H), x64.grad, rtol=1e-5, atol=2e-6)
+        assert (W.grad[s].double().view(32, 1, 5) - w64.grad).abs().max() <= 2e-5 * w64.grad.abs().max()
+        assert (b.grad[s].double() - b64.grad).abs().max() <= 2e-5 * b64.grad.abs().max()

@@ -86,6 +86,8 @@ SYMBOLS = {
     "vmasr_conv_post_supported": (ctypes.c_int, [c_i32, c_i32]),
     "vmasr_conv_post_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_conv_post_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
+    "vmasr_conv_first_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "vmasr_conv_first_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vmasr_adamw_chunk": (c_i32, []),
     "vmasr_adamw_step": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp]),
     "vmasr_masked_l1_blocks": (c_i32, []),

@@ -733,6 +733,56 @@ class _StackedConvSplitFn(torch.autograd.Function):
         return (None, None, None, None, None, dw, db, *dxs)
 
 
+class _StackedConvFirstFn(torch.autograd.Function):
+    """The first convolution (1 -> 32 channels, kernel (5,1), stride (3,1), padding 2) + GELU of all n period discriminators
+    in one launch on the folded signals xs[i] (B, p, H, 1) — csrc/convfirst.hip — instead of a 5-column im2col operand, a
+    K = 5 GEMM and an epilogue pass.  W (n, 32, 5), bias (n, 32).  Returns the stacked activations (n, rows, 32)."""
+
+    @staticmethod
+    def forward(ctx, rows, W, bias, *xs):
+        n, dev = len(xs), xs[0].device
+        lib = _lib.lib()
+        xcs = [x.float().contiguous() for x in xs]
+        w32, b32 = W.detach().float().contiguous(), bias.detach().float().contiguous()
+        ptrs, Ns, Hs = _slot_arrays([x.data_ptr() for x in xcs], [x.shape[0] * x.shape[1] for x in xcs], [x.shape[2] for x in xcs])
+        with torch.cuda.device(dev):
+            pre = torch.empty((n, rows, 32), dtype=torch.float32, device=dev)
+            act = torch.empty((n, rows, 32), dtype=torch.float32, device=dev)
+            _lib.check(lib.vmasr_conv_first_fwd(ptrs, Ns, Hs, n, w32.data_ptr(), b32.data_ptr(), pre.data_ptr(), act.data_ptr(), rows,
+                                                _lib.current_stream(dev)), "conv_first_fwd")
+        ctx.save_for_backward(pre, w32, *xcs)
+        ctx.meta = (W.dtype, bias.dtype, [x.dtype for x in xs], [tuple(x.shape) for x in xs])
+        return act
+
+    @staticmethod
+    def backward(ctx, gy):
+        pre, w32, *xcs = ctx.saved_tensors
+        wdt, bdt, xdts, shapes = ctx.meta
+        n, rows, _ = pre.shape
+        lib, dev = _lib.lib(), pre.device
+        gy = gy.float().contiguous()
+        skip_w = _PHASE["skip_weight_grads"]
+        want_dw, want_db = ctx.needs_input_grad[1] and not skip_w, ctx.needs_input_grad[2] and not skip_w
+        want_dx = any(ctx.needs_input_grad[3:])
+        ptrs, Ns, Hs = _slot_arrays([x.data_ptr() for x in xcs], [x.shape[0] * x.shape[1] for x in xcs], [x.shape[2] for x in xcs])
+        dxs = [None] * n
+        with torch.cuda.device(dev):
+            dcols = torch.empty((n, rows, 5), dtype=torch.float32, device=dev) if want_dx else None
+            dw = torch.zeros((n, 32, 5), dtype=torch.float32, device=dev) if want_dw else None
+            db = torch.zeros((n, 32), dtype=torch.float32, device=dev) if want_db else None
+            _lib.check(lib.vmasr_conv_first_bwd(ptrs, Ns, Hs, n, w32.data_ptr(), pre.data_ptr(), gy.data_ptr(),
+                                                dcols.data_ptr() if want_dx else None, dw.data_ptr() if want_dw else None,
+                                                db.data_ptr() if want_db else None, rows, _lib.current_stream(dev)), "conv_first_bwd")
+            if want_dx:
+                outs = [torch.empty(shp, dtype=torch.float32, device=dev) if ctx.needs_input_grad[3 + i] else None for i, shp in enumerate(shapes)]
+                optrs, Ns2, Hs2 = _slot_arrays([o.data_ptr() if o is not None else 0 for o in outs], [B * P for B, P, _, _ in shapes],
+                                               [H for _, _, H, _ in shapes])
+                _lib.check(lib.vmasr_col2im_kx1_multi(dcols.data_ptr(), optrs, Ns2, Hs2, n, 1, 5, 3, 2, rows, _lib.F32,
+                                                      _lib.current_stream(dev)), "col2im_kx1_multi")
+                dxs = [o.to(xdts[i]) if o is not None else None for i, o in enumerate(outs)]
+        return (None, dw.to(wdt) if want_dw else None, db.to(bdt) if want_db else None, *dxs)
+
+
 class _StackedConvPostFn(torch.autograd.Function):
     """conv_post (C -> 1 channels, kernel (3,1), stride 1, padding 1) of all n period discriminators directly on the previous
     layer's stacked output x (n, rows, C) — csrc/convpost.hip: one streaming pass forward, one backward, instead of a
@@ -1008,6 +1058,10 @@ class MultiPeriodDiscriminator(nn.Module):
                     and _lib.lib().vmasr_conv_post_supported(stacks[-1].shape[2], k)):
                 # the 1-channel output convolution straight on the previous layer's stacked maps (no column operand)
                 y = _StackedConvPostFn.apply(tuple(valid[-1]), tuple(c.shape[2] for c in cur), W, bstack, stacks[-1])
+            elif (act and li == 0 and cdt == torch.float32 and k == 5 and stride == 3 and pad == 2 and W.shape[1] == 32 and W.shape[2] == 5
+                  and all(c.shape[3] == 1 for c in cur) and os.environ.get("VMASR_CONV_FIRST", "1") == "1"):
+                # the 1 -> 32 channel input convolution + GELU straight from the folded signals (no 5-column operand / K = 5 GEMM)
+                y = _StackedConvFirstFn.apply(_round_up(max(Ms), 256), W, bstack, *cur)
             elif _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
                 y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, W, bstack, *cur)
             else:
