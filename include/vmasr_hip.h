@@ -236,6 +236,10 @@ int vmasr_im2col_kx1_split_multi(const float *const *xs, const int64_t *Ns, cons
                                  int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows_out, vmasr_stream_t stream);
 int vmasr_col2im_kx1_multi(const void *dcols, void *const *dxs, const int64_t *Ns, const int32_t *Hs, int32_t n, int32_t C,
                            int32_t k, int32_t stride, int32_t pad, int64_t rows, int32_t dtype, vmasr_stream_t stream);
+/* col2im_multi into ONE stacked destination dx (n, dx_rows, C): slot s = gradient of its N_s * H_s rows, zeros below (the
+ * gradient of the previous layer's stacked output, without the per-slot tensors + stack_rows in between) */
+int vmasr_col2im_kx1_stacked(const void *dcols, void *dx, const int64_t *Ns, const int32_t *Hs, int32_t n, int32_t C, int32_t k, int32_t stride,
+                             int32_t pad, int64_t rows, int64_t dx_rows, int32_t dtype, vmasr_stream_t stream);
 int vmasr_stack_rows(const void *const *srcs, const int64_t *Ms, int32_t n, void *full, int64_t rows, int64_t row_bytes,
                      vmasr_stream_t stream);
 

@@ -376,7 +376,7 @@ def test_stacked_conv_split_matches_float64_conv(stride, k, pad, act):
     Ms = [B * x.shape[1] * h for x, h in zip(xs, H1)]
     xr = [x.clone().requires_grad_() for x in xs]
     Wr, br = W.clone().requires_grad_(), b.clone().requires_grad_()
-    y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, Wr, br, *xr)
+    y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, None, Wr, br, *xr)
     outs = _UnstackRowsFn.apply(y, *Ms)
     gys = [torch.randn_like(o) for o in outs]
     sum((o * g).sum() for o, g in zip(outs, gys)).backward()
@@ -655,3 +655,39 @@ def test_conv_first_direct_matches_float64_conv():
         assert torch.allclose(xs[s].grad.double().view(B * p, 1, H), x64.grad, rtol=1e-5, atol=2e-6)
         assert (W.grad[s].double().view(32, 1, 5) - w64.grad).abs().max() <= 2e-5 * w64.grad.abs().max()
         assert (b.grad[s].double() - b64.grad).abs().max() <= 2e-5 * b64.grad.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [True, False])
+def test_stacked_input_variants_equal_per_slot_inputs(split):
+    """_StackedConvSplitFn / _StackedIm2ColFn fed with ONE stacked input (n, rows_in, C) + per-slot geometry == the same
+    functions fed with the per-slot views: identical outputs, and the stacked input gradient == the per-slot gradients in its
+    slots with exact zeros on the padding rows (csrc/im2col.hip: vmasr_col2im_kx1_stacked)."""
+    from vm_asr_amd.discriminator import _StackedConvSplitFn, _StackedIm2ColFn, _round_up
+    torch.manual_seed(21)
+    dev, B, C, k, stride, pad, N = "cuda", 2, 128, 5, 3, 2, 512
+    geoms = [(2, 301), (3, 200), (5, 121)]
+    n = len(geoms)
+    rows_in = _round_up(max(B * p * H for p, H in geoms), 256)
+    stack = torch.randn(n, rows_in, C, device=dev)
+    views = lambda t: [t[i, :B * p * H].view(B, p, H, C) for i, (p, H) in enumerate(geoms)]     # noqa: E731
+    H1 = [(H + 2 * pad - k) // stride + 1 for _, H in geoms]
+    rows = _round_up(max(B * p * h for (p, _), h in zip(geoms, H1)), 256)
+    W = torch.randn(n, N, k * C, device=dev) / (k * C) ** 0.5
+    b = torch.randn(n, N, device=dev)
+    sgeom = tuple((B * p, H) for p, H in geoms)
+    res = []
+    for stacked in (True, False):
+        st = stack.clone().requires_grad_()
+        src = (st,) if stacked else views(st)
+        if split:
+            y = _StackedConvSplitFn.apply(k, stride, pad, rows, True, sgeom if stacked else None, W, b, *src)
+        else:
+            y = _StackedIm2ColFn.apply(k, stride, pad, rows, sgeom if stacked else None, *src)
+        torch.manual_seed(5)
+        y.backward(torch.randn_like(y))
+        res.append((y.detach(), st.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    for i, (p, H) in enumerate(geoms):
+        assert not res[0][1][i, B * p * H:].any()

@@ -76,6 +76,7 @@ SYMBOLS = {
     "vmasr_col2im_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_im2col_kx1_split_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "vmasr_col2im_kx1_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
+    "vmasr_col2im_kx1_stacked": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "vmasr_stack_rows": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp]),
     "vmasr_split_bf16": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vmasr_bias_gelu_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void col2im_multi_kernel(const T *__restrict__
     const int N = t.N[s], H = t.H[s], H1 = t.H1[s];
     const T *__restrict__ dcols = dcols_all + (size_t)s * g0.rows_out * g0.k * g0.C;
     const int cv = g0.C / V;
-    const long total = (long)N * H * cv;
+    const long valid = (long)N * H * cv;
+    const long total = t.rows[s] ? t.rows[s] * cv : valid;      // rows[s]: rows of the destination slot (zero-filled past N*H), 0 = exact
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % cv);
         const long r = i / cv;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void col2im_multi_kernel(const T *__restrict__
         float acc[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
-        for (int j = (h + g0.pad) % g0.stride; j < g0.k; j += g0.stride) {
+        for (int j = (h + g0.pad) % g0.stride; j < g0.k && i < valid; j += g0.stride) {
             const int q = h + g0.pad - j;
             if (q < 0) break;
             const int h1 = q / g0.stride;
@@ -332,9 +333,8 @@ VMASR_EXPORT int vmasr_im2col_kx1_split_multi(const float *const *xs, const int6
     return check_launch("im2col_kx1_split_multi");
 }
 
-VMASR_EXPORT int vmasr_col2im_kx1_multi(const void *dcols, void *const *dxs, const int64_t *Ns, const int32_t *Hs, int32_t n,
-                                        int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows, int32_t dtype,
-                                        vmasr_stream_t stream) {
+static int col2im_multi_impl(const void *dcols, void *const *dxs, const int64_t *Ns, const int32_t *Hs, int32_t n, int32_t C, int32_t k,
+                             int32_t stride, int32_t pad, int64_t rows, int64_t dx_rows, int32_t dtype, vmasr_stream_t stream) {
     VMASR_REQUIRE(dcols && dxs && Ns && Hs, VMASR_EINVAL, "col2im_kx1_multi: null argument");
     VMASR_REQUIRE(n > 0 && n <= kMaxSlots, VMASR_EINVAL, "col2im_kx1_multi: 1..%d slots (got %d)", kMaxSlots, n);
     VMASR_REQUIRE(C > 0 && k > 0 && stride > 0 && pad >= 0 && rows > 0, VMASR_EINVAL,
@@ -351,13 +351,15 @@ VMASR_EXPORT int vmasr_col2im_kx1_multi(const void *dcols, void *const *dxs, con
         const int H1 = (Hs[s] + 2 * pad - k) / stride + 1;
         VMASR_REQUIRE(rows >= Ns[s] * H1, VMASR_EINVAL, "col2im_kx1_multi: rows smaller than N*H1 of slot %d", s);
         t.dst[s] = dxs[s];
+        t.rows[s] = dx_rows;
+        VMASR_REQUIRE(dx_rows == 0 || dx_rows >= Ns[s] * Hs[s], VMASR_EINVAL, "col2im_kx1_multi: destination slot %d has fewer rows than N*H", s);
         t.N[s] = (int)Ns[s];
         t.H[s] = Hs[s];
         t.H1[s] = H1;
         if (!dxs[s]) continue;
         any = true;
         vec_ok = vec_ok && aligned_to(dxs[s], 16);
-        max_total = std::max(max_total, (long)Ns[s] * Hs[s] * C);
+        max_total = std::max(max_total, (dx_rows ? (long)dx_rows : (long)Ns[s] * Hs[s]) * C);
         bytes += ((double)Ns[s] * Hs[s] * C + (double)Ns[s] * H1 * k * C) * esz;
     }
     if (!any) return VMASR_OK;
@@ -370,6 +372,23 @@ VMASR_EXPORT int vmasr_col2im_kx1_multi(const void *dcols, void *const *dxs, con
     }
     set_error("col2im_kx1_multi: unsupported dtype %d", dtype);
     return VMASR_EINVAL;
+}
+
+
+VMASR_EXPORT int vmasr_col2im_kx1_multi(const void *dcols, void *const *dxs, const int64_t *Ns, const int32_t *Hs, int32_t n,
+                                        int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows, int32_t dtype,
+                                        vmasr_stream_t stream) {
+    return col2im_multi_impl(dcols, dxs, Ns, Hs, n, C, k, stride, pad, rows, 0, dtype, stream);
+}
+
+// the same into ONE stacked destination dx (n, dx_rows, C): slot s = the gradient of its N_s * H_s rows, zeros below
+VMASR_EXPORT int vmasr_col2im_kx1_stacked(const void *dcols, void *dx, const int64_t *Ns, const int32_t *Hs, int32_t n, int32_t C, int32_t k,
+                                          int32_t stride, int32_t pad, int64_t rows, int64_t dx_rows, int32_t dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(dx && n > 0 && n <= kMaxSlots && dx_rows > 0 && C > 0, VMASR_EINVAL, "col2im_kx1_stacked: bad arguments");
+    void *ptrs[kMaxSlots];
+    const size_t esz = dtype == VMASR_F32 ? 4 : 2;
+    for (int s = 0; s < n; ++s) ptrs[s] = static_cast<char *>(dx) + (size_t)s * dx_rows * C * esz;
+    return col2im_multi_impl(dcols, ptrs, Ns, Hs, n, C, k, stride, pad, rows, dx_rows, dtype, stream);
 }
 
 VMASR_EXPORT int vmasr_stack_rows(const void *const *srcs, const int64_t *Ms, int32_t n, void *full, int64_t rows, int64_t row_bytes,

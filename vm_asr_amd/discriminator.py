@@ -411,33 +411,50 @@ def _slot_arrays(ptrs, Ns, Hs=None):
 
 class _StackedIm2ColFn(torch.autograd.Function):
     """n channel-last inputs (B, P_i, H_i, C) -> one (n, rows, k*C) column tensor, slot i holding the im2col
-    of input i in its first B*P_i*H1_i rows and zeros below (vmasr_im2col_kx1 with rows_out)."""
+    of input i in its first B*P_i*H1_i rows and zeros below (vmasr_im2col_kx1 with rows_out).
+    geom = ((N_i, H_i), ...) : the n inputs are the slots of ONE stacked tensor xs[0] (n, rows_in, C), slot i holding N_i
+    sequences of H_i positions in its first rows (the previous layer's stacked output); the backward then writes the
+    stacked gradient directly (no per-slot tensors, no re-stacking)."""
 
     @staticmethod
-    def forward(ctx, k, stride, pad, rows, *xs):
-        C, dt, dev = xs[0].shape[3], xs[0].dtype, xs[0].device
+    def forward(ctx, k, stride, pad, rows, geom, *xs):
         lib = _lib.lib()
+        if geom is not None:
+            x = xs[0].contiguous()
+            n, rows_in, C = x.shape
+            dt, dev, step = x.dtype, x.device, rows_in * C * x.element_size()
+            srcs = [(x.data_ptr() + i * step, N, H) for i, (N, H) in enumerate(geom)]
+            ctx.geom = (k, stride, pad, None, tuple(geom), (n, rows_in, C))
+        else:
+            C, dt, dev = xs[0].shape[3], xs[0].dtype, xs[0].device
+            xcs = [x.contiguous() for x in xs]
+            srcs = [(x.data_ptr(), x.shape[0] * x.shape[1], x.shape[2]) for x in xcs]
+            ctx.geom = (k, stride, pad, [tuple(x.shape) for x in xs], None, None)
         with torch.cuda.device(dev):
-            cols = torch.empty((len(xs), rows, k * C), dtype=dt, device=dev)
-            for i, x in enumerate(xs):
-                B, P, H, _ = x.shape
-                xc = x.contiguous()
-                _lib.check(lib.vmasr_im2col_kx1(xc.data_ptr(), cols[i].data_ptr(), B * P, H, C, k, stride, pad, rows,
+            cols = torch.empty((len(srcs), rows, k * C), dtype=dt, device=dev)
+            for i, (ptr, N, H) in enumerate(srcs):
+                _lib.check(lib.vmasr_im2col_kx1(ptr, cols[i].data_ptr(), N, H, C, k, stride, pad, rows,
                                                 _lib.torch_dtype_code(dt), _lib.current_stream(dev)), "im2col_kx1")
-        ctx.geom = (k, stride, pad, [tuple(x.shape) for x in xs])
         return cols
 
     @staticmethod
     def backward(ctx, g):
-        k, stride, pad, shapes = ctx.geom
+        k, stride, pad, shapes, geom, sshape = ctx.geom
         g = g.contiguous()
         lib = _lib.lib()
         with torch.cuda.device(g.device):
+            if geom is not None:
+                n, rows_in, C = sshape
+                dx = torch.empty(sshape, dtype=g.dtype, device=g.device)
+                _, Ns, Hs = _slot_arrays([0] * n, [N for N, _ in geom], [H for _, H in geom])
+                _lib.check(lib.vmasr_col2im_kx1_stacked(g.data_ptr(), dx.data_ptr(), Ns, Hs, n, C, k, stride, pad, g.shape[1], rows_in,
+                                                        _lib.torch_dtype_code(g.dtype), _lib.current_stream(g.device)), "col2im_kx1_stacked")
+                return (None, None, None, None, None, dx)
             dxs = [torch.empty(shp, dtype=g.dtype, device=g.device) for shp in shapes]
             ptrs, Ns, Hs = _slot_arrays([d.data_ptr() for d in dxs], [B * P for B, P, _, _ in shapes], [H for _, _, H, _ in shapes])
             _lib.check(lib.vmasr_col2im_kx1_multi(g.data_ptr(), ptrs, Ns, Hs, len(shapes), shapes[0][3], k, stride, pad, g.shape[1],
                                                   _lib.torch_dtype_code(g.dtype), _lib.current_stream(g.device)), "col2im_kx1_multi")
-        return (None, None, None, None, *dxs)
+        return (None, None, None, None, None, *dxs)
 
 
 # Backward-phase switch of the trainer's shared fake pass: while the GENERATOR loss is back-propagated through
@@ -634,17 +651,26 @@ class _StackedConvSplitFn(torch.autograd.Function):
     instead of two read-modify-write passes over the (rows, k*C) gradient), then col2im per slot."""
 
     @staticmethod
-    def forward(ctx, k, stride, pad, rows, act, weight, bias, *xs):
+    def forward(ctx, k, stride, pad, rows, act, geom, weight, bias, *xs):
         """act: apply GELU to the output inside (epilogue kernel; the backward then fuses GELU', the bias gradient
-        and the bf16 split of the incoming gradient into one pass, csrc/split.hip)."""
-        C, dev = xs[0].shape[3], xs[0].device
-        n, K = len(xs), k * C
+        and the bf16 split of the incoming gradient into one pass, csrc/split.hip).
+        geom = ((N_i, H_i), ...): the inputs are the slots of ONE stacked fp32 tensor xs[0] (n, rows_in, C) — the previous
+        layer's stacked output — and the backward returns its stacked gradient (see _StackedIm2ColFn)."""
         lib = _lib.lib()
+        if geom is not None:
+            xs0 = xs[0].float().contiguous()
+            n, rows_in, C = xs0.shape
+            dev, K = xs0.device, k * C
+            xcs = [xs0]
+            ptrs, Ns, Hs = _slot_arrays([xs0.data_ptr() + i * rows_in * C * 4 for i in range(n)], [N for N, _ in geom], [H for _, H in geom])
+        else:
+            C, dev = xs[0].shape[3], xs[0].device
+            n, K = len(xs), k * C
+            xcs = [x.float().contiguous() for x in xs]
+            ptrs, Ns, Hs = _slot_arrays([x.data_ptr() for x in xcs], [x.shape[0] * x.shape[1] for x in xcs], [x.shape[2] for x in xcs])
         with torch.cuda.device(dev):
             ch = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
             cl = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
-            xcs = [x.float().contiguous() for x in xs]
-            ptrs, Ns, Hs = _slot_arrays([x.data_ptr() for x in xcs], [x.shape[0] * x.shape[1] for x in xcs], [x.shape[2] for x in xcs])
             _lib.check(lib.vmasr_im2col_kx1_split_multi(ptrs, Ns, Hs, n, ch.data_ptr(), cl.data_ptr(), C, k, stride, pad, rows,
                                                         _lib.current_stream(dev)), "im2col_kx1_split_multi")
         # weights: one pass to the (n, K, 3N) bf16 operand [hi^T | hi^T | lo^T] (csrc/split.hip): column blocks 0 and 2 are
@@ -678,19 +704,20 @@ class _StackedConvSplitFn(torch.autograd.Function):
                 pre = y
                 y = F.gelu(pre)
         ctx.save_for_backward(ch, cl, wcat, *([pre] if pre is not None else []))
-        ctx.geom = (k, stride, pad, [tuple(x.shape) for x in xs], weight.dtype, bias.dtype, [x.dtype for x in xs], act, fused)
+        ctx.geom = (k, stride, pad, [tuple(x.shape) for x in xs], weight.dtype, bias.dtype, [x.dtype for x in xs], act, fused,
+                    tuple(geom) if geom is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         ch, cl, wcat, *rest = ctx.saved_tensors
-        k, stride, pad, shapes, wdt, bdt, xdts, act, fused = ctx.geom
+        k, stride, pad, shapes, wdt, bdt, xdts, act, fused, sgeom = ctx.geom
         gy = gy.float().contiguous()
         n, M, N = gy.shape
         K = ch.shape[2]
         lib = _lib.lib()
-        want_db = ctx.needs_input_grad[6] and not _PHASE["skip_weight_grads"]
-        want_dx = any(ctx.needs_input_grad[7:])
+        want_db = ctx.needs_input_grad[7] and not _PHASE["skip_weight_grads"]
+        want_dx = any(ctx.needs_input_grad[8:])
         db32 = gcat = None
         if N % 4 == 0 and N <= 1024:
             # one pass: (GELU' *) gradient -> bf16 split (+ bias gradient); the fp32 gradient is never written
@@ -716,8 +743,16 @@ class _StackedConvSplitFn(torch.autograd.Function):
             if gcat is None:
                 gcat = torch.cat((gh, gl, gh), dim=2)
             dcols = torch.bmm(gcat, wcat.transpose(1, 2), out_dtype=torch.float32)
+            if sgeom is not None:      # stacked input: its stacked gradient in one launch (zero rows below each slot's data)
+                with torch.cuda.device(gy.device):
+                    dxs_ = torch.empty(shapes[0], dtype=torch.float32, device=gy.device)
+                    _, Ns, Hs = _slot_arrays([0] * n, [N for N, _ in sgeom], [H for _, H in sgeom])
+                    _lib.check(lib.vmasr_col2im_kx1_stacked(dcols.data_ptr(), dxs_.data_ptr(), Ns, Hs, n, shapes[0][2], k, stride, pad, M,
+                                                            shapes[0][1], _lib.F32, _lib.current_stream(gy.device)), "col2im_kx1_stacked")
+                dxs = [dxs_.to(xdts[0])]
+        if want_dx and sgeom is None:
             with torch.cuda.device(gy.device):
-                outs = [torch.empty(shp, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[7 + i] else None
+                outs = [torch.empty(shp, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[8 + i] else None
                         for i, shp in enumerate(shapes)]
                 ptrs, Ns, Hs = _slot_arrays([o.data_ptr() if o is not None else 0 for o in outs],
                                             [B * P for B, P, _, _ in shapes], [H for _, _, H, _ in shapes])
@@ -726,11 +761,11 @@ class _StackedConvSplitFn(torch.autograd.Function):
                 dxs = [o.to(xdts[i]) if o is not None else None for i, o in enumerate(outs)]
         dw = db = None
         if not _PHASE["skip_weight_grads"]:
-            if ctx.needs_input_grad[5]:
-                dw = _dw3(gh, gl, ch, cl, wdt)
             if ctx.needs_input_grad[6]:
+                dw = _dw3(gh, gl, ch, cl, wdt)
+            if ctx.needs_input_grad[7]:
                 db = db32.to(bdt)
-        return (None, None, None, None, None, dw, db, *dxs)
+        return (None, None, None, None, None, None, dw, db, *dxs)
 
 
 class _StackedConvFirstFn(torch.autograd.Function):
@@ -1053,6 +1088,11 @@ class MultiPeriodDiscriminator(nn.Module):
                 W = W.reshape(n, W.shape[1], -1)
             act = li < len(discs[0].layers)
             bstack = torch.stack([b for _, b in ws])
+            # from the second layer on the inputs are the slots of the previous layer's stacked output: hand that tensor over
+            # (slot i = B*p_i sequences of H_i positions) so that its gradient comes back stacked, in one launch
+            sgeom, src = None, cur
+            if stacks and stacks[-1].dtype == cdt and os.environ.get("VMASR_STACK_INPUT", "1") == "1":
+                sgeom, src = tuple((B * p, c.shape[2]) for c, p in zip(cur, P)), (stacks[-1],)
             if (not act and stacks and cdt == torch.float32 and k == 3 and stride == 1 and pad == 1 and W.shape[1] == 1
                     and stacks[-1].dtype == torch.float32 and os.environ.get("VMASR_CONV_POST", "1") == "1"
                     and _lib.lib().vmasr_conv_post_supported(stacks[-1].shape[2], k)):
@@ -1063,9 +1103,9 @@ class MultiPeriodDiscriminator(nn.Module):
                 # the 1 -> 32 channel input convolution + GELU straight from the folded signals (no 5-column operand / K = 5 GEMM)
                 y = _StackedConvFirstFn.apply(_round_up(max(Ms), 256), W, bstack, *cur)
             elif _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
-                y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, W, bstack, *cur)
+                y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, sgeom, W, bstack, *src)
             else:
-                cols = _StackedIm2ColFn.apply(k, stride, pad, _round_up(max(Ms), 256), *cur)
+                cols = _StackedIm2ColFn.apply(k, stride, pad, _round_up(max(Ms), 256), sgeom, *src)
                 y = _BatchedLinearFn.apply(cols, W, bstack, cdt, act)
             outs = _UnstackRowsFn.apply(y, *Ms)
             cur = [o.view(B, p, h, -1) for o, p, h in zip(outs, P, H1)]
