@@ -11,6 +11,8 @@ pad)`.  `--inference` (file I/O, wav decoding) is not built; `--throughput` runs
 """
 import argparse
 import os
+
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # vm_asr_amd/hip_env.py: before the GPU is initialised
 import sys
 import time
 

@@ -1,4 +1,6 @@
 import os
+
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # vm_asr_amd/hip_env.py: before the GPU is initialised
 import sys
 
 import pytest

@@ -1,35 +1,33 @@
-"""Do eager and graph-replayed training agree? (dev tool)  Compares weights after 6 steps: eager vs eager,
-eager vs graphs, on the tiny test config."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+"""Loss values and gradients of the replayed graphs vs the eager step on the same weights and batch (dev tool)."""
+import os
+import sys
+
 import torch
-import test_trainer as tt
 
-def run(graphs, amp=False, steps=6):
-    cfg = tt._tiny_config()
-    batch = [t.cuda() for t in tt._batch(cfg, 2)]
-    tr = tt._gpu_trainer(cfg, amp=amp, capturable=True)
-    for m in tr.models.values():
-        m.train()
-    hist = []
-    if graphs:
-        assert tr.enable_graphs(batch, warmup=3)
-        n = steps - 3
-    else:
-        n = steps
-    for _ in range(n):
-        out, logs = tr.train_step(*batch)
-        hist.append(float(logs["total_loss"]))
-    torch.cuda.synchronize()
-    return {k: v.detach().float().clone() for k, v in tr.models["generator"].state_dict().items()}, hist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
 
-def cmp(a, b, tag):
-    d = torch.cat([(a[k] - b[k]).abs().flatten() for k in a])
-    print(f"{tag}: max {d.max().item():.3e}  frac>5e-4 {(d > 5e-4).float().mean().item():.4f}  frac>1e-5 {(d > 1e-5).float().mean().item():.4f}")
-
-e1, h1 = run(False); e2, h2 = run(False); g1, h3 = run(True)
-print("eager losses", h1); print("eager2 losses", h2); print("graph losses", h3)
-cmp(e1, e2, "eager vs eager"); cmp(e1, g1, "eager vs graph")
-e1s, _ = run(False, steps=1); e2s, _ = run(False, steps=1)
-cmp(e1s, e2s, "eager vs eager, 1 step")
+cfg = bench.make_config("vm_asr_48k_MPD", 0)
+cfg.defrost() if hasattr(cfg, "defrost") else None
+dev = torch.device("cuda", 0)
+tr = bench.build_trainer(cfg, dev, amp=True, capturable=True)
+for m in tr.models.values():
+    m.train()
+batch = bench.synth_batch(cfg, dev, 0)
+for _ in range(2):
+    out, logs = tr.train_step(*batch)
+print("eager :", {k: round(float(v), 4) for k, v in logs.items()})
+ok = tr.enable_graphs(batch, warmup=2)
+print("graphs:", ok)
+for i in range(3):
+    out, logs = tr.train_step(*batch)
+    print(f"graph {i}:", {k: round(float(v), 4) for k, v in logs.items()})
+for i in range(3):
+    b2 = bench.synth_batch(cfg, dev, 100 + i)          # a different batch every step (what a data loader delivers)
+    out, logs = tr.train_step(*b2)
+    print(f"graph new batch {i}:", {k: round(float(v), 4) for k, v in logs.items()})
+    if os.environ.get("WITH_METRICS"):
+        print("   metrics:", {k: round(float(v), 4) for k, v in tr._metrics(out, b2[1], b2[2]).items()})
+tr._graphed = None
+out, logs = tr.train_step(*batch)
+print("eager :", {k: round(float(v), 4) for k, v in logs.items()})

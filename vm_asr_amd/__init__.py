@@ -9,6 +9,8 @@ There is NO CPU fallback in this package: ops raise if the HIP library is missin
 """
 __version__ = "0.1.0"
 
+from . import hip_env  # noqa: F401,E402  (runtime settings, before anything touches the GPU)
+
 
 def get_model(config):
     """Build the models a config asks for — same contract as the reference's

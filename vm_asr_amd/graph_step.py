@@ -19,7 +19,49 @@ graph A like any ATen kernel; the in-library event profiler must be off during c
 """
 import torch
 
-__all__ = ["GraphedTrainStep"]
+__all__ = ["GraphedTrainStep", "replay_selftest"]
+
+_SELFTEST = {}
+
+
+def replay_selftest(device):
+    """Does this runtime replay a captured graph faithfully?  Captures a graph of ten multi-block ATen reductions (each zeroes
+    its semaphores with a memset node), replays it four times on NEW data and compares every result with the eager value.
+    False on the ROCm 7.2 AQL-packet replay path (vm_asr_amd/hip_env.py), where the memset nodes lose their order; cached per
+    device."""
+    key = str(device)
+    if key in _SELFTEST:
+        return _SELFTEST[key]
+    n = 1 << 21
+
+    def fn(a, b):
+        return [a.min(), a.max(), b.min(), b.max(), a.sum(), b.sum(), (a - b).abs().sum(), a.log().min(), b.log().max(), (a * b).mean()]
+
+    gen = torch.Generator(device=device).manual_seed(1234)
+    mk = lambda: [torch.rand(n, device=device, generator=gen) + 0.5, torch.rand(n, device=device, generator=gen) + 0.5]   # noqa: E731
+    ins = mk()
+    cur = torch.cuda.current_stream(device)
+    side = torch.cuda.Stream(device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fn(*ins)
+    cur.wait_stream(side)
+    torch.cuda.synchronize(device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = fn(*ins)
+    ok = True
+    for _ in range(4):
+        for t, new in zip(ins, mk()):
+            t.copy_(new)
+        g.replay()
+        torch.cuda.synchronize(device)
+        ref = fn(*ins)
+        ok = ok and all(abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))) for a, b in zip(outs, ref))
+    del g, outs
+    _SELFTEST[key] = ok
+    return ok
 
 
 class GraphedTrainStep:
@@ -34,6 +76,10 @@ class GraphedTrainStep:
         for opt in [tr.optimizer_G] + ([tr.optimizer_D] if tr.gan else []):
             if not opt.defaults.get("capturable", False):
                 raise RuntimeError("graph capture needs capturable=True optimisers (build_optimizer(..., capturable=True))")
+        if not replay_selftest(tr.device):
+            raise RuntimeError("this HIP runtime does not replay captured graphs faithfully (memset nodes lose their order: "
+                               "ATen reductions return stale results from the second replay on); set "
+                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the process initialises the GPU (vm_asr_amd/hip_env.py)")
         from . import _lib
         _lib.prof_enable(False)
         self.static_in = [t.clone() for t in example_batch]
