@@ -189,7 +189,8 @@ def main():
                                f"AdamW); DIMS 16, d_state 1, clip 122640 @48 kHz, n_fft 1024 hop 240",
                    "per_gpu_batch": B, "global_batch": B * world,
                    "parallelism": f"dp{world} (clip-sharded; one RCCL all-reduce per flat gradient buffer)",
-                   "execution": "HIP graph replay (forward + D-backward graph, G-backward graph, optimiser graph)" if graphed else "eager"},
+                   "execution": ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
+                                 "optimiser graph)") if graphed else "eager"},
     }
     if rank == 0 and timing:
         prof = _lib.prof_collect()
