@@ -49,7 +49,7 @@ def replay_selftest(device):
     cur.wait_stream(side)
     torch.cuda.synchronize(device)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         outs = fn(*ins)
     ok = True
     for _ in range(4):
@@ -101,16 +101,18 @@ class GraphedTrainStep:
             if any(torch.is_tensor(g["lr"]) and not g["lr"].is_cuda for g in opt.param_groups):
                 lr_to_device(opt, tr.device)      # a host lr would be frozen into graph B at capture
         self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb):
+        # thread_local: only THIS thread's calls are checked during capture — RCCL's watchdog thread polls its events
+        # (hipEventQuery) at any time, which in the default global mode would invalidate a capture in progress
+        with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
             st = tr._forward_losses(*self.static_in)
             tr._backward_d(st)
         self.graph_g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_g, pool=self.graph_fb.pool()):
+        with torch.cuda.graph(self.graph_g, pool=self.graph_fb.pool(), capture_error_mode="thread_local"):
             tr._backward_g(st)
         self.static_out, self.static_logs = st["wave_out"].detach(), st["logs"]
         del st
         self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool()):
+        with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool(), capture_error_mode="thread_local"):
             tr._optimizer_steps()
 
     def __call__(self, wave_input, wave_target, highcut):
