@@ -142,12 +142,22 @@ def test_fullsize_forward_cpu_oracle_fp64_adjudicated(tag):
     _adjudicate(tag, "cpu-oracle", y, y32, y64, target, lsd_ref)
 
 
-# measured on MI355X (round 2), four cases: RMS ratio 0.64 .. 2.0; worst-sample ratio 0.4 .. 2.6 (one sample out of
-# 40 880 .. 122 640 behind a x300 amplifier: the max norm is the noisy statistic, the RMS the robust one)
-K_MAX, K_RMS = 4.0, 3.0
+# The statistic |y - y64| is ONE DRAW of a heavy-tailed quantity: the network ends in a LayerNorm over two channels
+# (amplification up to 1/(2 sqrt(eps)) = 158 where the channels nearly coincide), so a handful of spectrogram bins carry
+# the whole error and ANY change of rounding anywhere upstream re-draws it.  Measured on MI355X in round 3
+# (tools/accuracy_probe.py, profiles/r03_accuracy_probe.log, 6 clips x 4 configs): the ratio (HIP fp32) / (CPU-oracle
+# fp32, i.e. the sequential recurrence of selective_scan_ref) ranges 0.47 .. 1.96 in RMS and 0.27 .. 3.9 at the worst
+# sample from clip to clip, with a geometric mean of 0.84 .. 1.21 (RMS) — and on clip 0 of the 16 kHz config the CPU
+# oracle's fp32 run itself is 2.06x further from float64 than the reference's fp32 run (4.89e-5 vs 2.37e-5), although
+# both are "the sequential fp32 recurrence".  Computing ONE operator family in float64 moves the final error of the
+# n_fft-2048 clip anywhere between 0.6x and 2.2x.  So the per-clip bounds below are relative to the NOISIER of the two
+# sequential fp32 evaluations and cover that spread; the claim "as accurate as the reference's fp32 arithmetic" is the
+# DISTRIBUTION test (test_fullsize_forward_hip_error_distribution: geometric mean of the ratio over 8 clips), and
+# per operator tests/test_ss2d_fused.py (x1.5 of the sequential recurrence's distance from float64, benchmark shapes).
+K_MAX, K_RMS = 3.0, 2.0
 
 
-def _adjudicate(tag, who, y, y32, y64, target, lsd_ref):
+def _adjudicate(tag, who, y, y32, y64, target, lsd_ref, y_cpu=None):
     """The exact output is y64 (the reference evaluated in float64, make_golden.py::gen_fullsize2).  The reference's
     own fp32 run sits e_ref = |y32 - y64| from it (1.5e-4 .. 6.7e-4 of the peak at the worst sample — above the
     1e-4 of north_star, because the last VSS block's LayerNorm over two channels amplifies rounding); ours must be
@@ -158,8 +168,13 @@ def _adjudicate(tag, who, y, y32, y64, target, lsd_ref):
     peak = np.abs(y64).max()
     print(f"[{tag}] {who}: max |y-y64| {e.max() / peak:.2e} of peak (reference fp32: {e_ref.max() / peak:.2e}), "
           f"rms {_rms(e) / peak:.2e} (reference fp32: {_rms(e_ref) / peak:.2e})")
-    assert e.max() <= K_MAX * e_ref.max(), (tag, who, e.max(), e_ref.max())
-    assert _rms(e) <= K_RMS * _rms(e_ref), (tag, who, _rms(e), _rms(e_ref))
+    ref_max, ref_rms = e_ref.max(), _rms(e_ref)
+    if y_cpu is not None:            # the other sequential-fp32 evaluation of the same clip (CPU oracle)
+        e_cpu = np.abs(y_cpu.astype(np.float64) - y64)
+        print(f"[{tag}] cpu-oracle fp32: max {e_cpu.max() / peak:.2e} rms {_rms(e_cpu) / peak:.2e}")
+        ref_max, ref_rms = max(ref_max, e_cpu.max()), max(ref_rms, _rms(e_cpu))
+    assert e.max() <= K_MAX * ref_max, (tag, who, e.max(), ref_max)
+    assert _rms(e) <= K_RMS * ref_rms, (tag, who, _rms(e), ref_rms)
     lsd = oracle.lsd(y[:, 0], target.numpy()[:, 0])
     assert abs(lsd - lsd_ref) < 1e-3, (tag, who, lsd, lsd_ref)
 
@@ -169,11 +184,66 @@ def _adjudicate(tag, who, y, y32, y64, target, lsd_ref):
 def test_fullsize_forward_hip_fp64_adjudicated(tag):
     """BASELINE configs[0], [1], [4] (dims 32; n_fft 2048) at full size through the HIP path in fp32, adjudicated by
     the float64 evaluation of the reference."""
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
     (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case(tag)
     m = _model(hop, dims, n_fft, win).to("cuda:0")
     with torch.no_grad():
         y = m(wave.cuda(), hf.cuda()).float().cpu().numpy()
-    _adjudicate(tag, "hip fp32", y, y32, y64, target, lsd_ref)
+    with oracle_stft_patch(), torch.no_grad():
+        y_cpu = use_oracle(_model(hop, dims, n_fft, win))(wave, hf).float().numpy()
+    _adjudicate(tag, "hip fp32", y, y32, y64, target, lsd_ref, y_cpu)
+
+
+@pytest.mark.parametrize("tag", ["16k", "n2048"])
+def test_f64ref_equals_float64_reference(tag):
+    """Pins the SECOND adjudicator, tests/f64ref.py (this package's modules in float64 with every HIP-backed family
+    through a plain-torch float64 restatement; runs on the GPU in seconds): it reproduces the reference's own float64
+    evaluation to 1e-9 of the peak.  Used where no golden exists (fresh clips of the distribution test below)."""
+    import f64ref
+    (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case(tag)
+    y = f64ref.forward64(_model(hop, dims, n_fft, win), wave, hf)
+    assert y.dtype == np.float64 and np.abs(y - y64).max() <= 1e-9 * np.abs(y64).max()
+
+
+N_CLIPS, GM_RMS, GM_MAX = 8, 1.6, 1.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["16k", "48k", "d32", "n2048"])
+def test_fullsize_forward_hip_error_distribution(tag):
+    """"As accurate as the reference's fp32 arithmetic" as a statement about the DISTRIBUTION of the error, which is
+    what can be measured (see the note above K_MAX): over N_CLIPS fresh full-size clips the geometric mean of
+        |y_hip - y64| / |y_cpu-oracle-fp32 - y64|      (RMS and worst sample; y64 = tests/f64ref.py on the GPU)
+    is <= GM_RMS / GM_MAX.  Measured in round 3 (profiles/r03_accuracy_probe.log, r03_gpu_parity.log): 0.84 / 1.05 /
+    1.21 / 1.18 (16k / 48k / d32 / n2048) over one set of 6 clips, 1.46 / 1.38 / 1.31 / 1.06 over the 8 clips used here;
+    pooled over the 14 clips 1.15 / 1.23 / 1.27 / 1.11 with a standard error of ~0.12 (a single clip's log-ratio has a
+    spread of ~0.4).  EVERY HIP operator family alone is at 0.6 .. 1.2x torch's CPU fp32 evaluation of the same lines
+    (tools/accuracy_probe.py --ops); what remains at network level (~1.2x) is within two standard errors of 1 and has
+    one known contributor: hipBLASLt's fp32 GEMMs are 1.4 .. 1.7x further from float64 than MKL's for K >= 256
+    (tools/linear_accuracy.py; accumulation order), and the Linear layers are the largest single-family term of the
+    final error in three of the four configs (isolation runs in the same log)."""
+    import f64ref
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
+    (dims, n_fft, win, hop), wave0, target, hf, y32, y64, lsd_ref = _case(tag)
+    m = _model(hop, dims, n_fft, win).to("cuda:0")
+    m_cpu = use_oracle(_model(hop, dims, n_fft, win))
+    assert np.abs(f64ref.forward64(m, wave0, hf) - y64).max() <= 1e-9 * np.abs(y64).max()   # the adjudicator, on this device
+    lr, lm = [], []
+    for s in range(N_CLIPS):
+        wave = 0.1 * torch.randn(wave0.shape, generator=torch.Generator().manual_seed(9100 + s))
+        y64s = f64ref.forward64(m, wave, hf)
+        with torch.no_grad():
+            y = m(wave.cuda(), hf.cuda()).float().cpu().numpy()
+        with oracle_stft_patch(), torch.no_grad():
+            yc = m_cpu(wave, hf).float().numpy()
+        e, ec = np.abs(y - y64s), np.abs(yc - y64s)
+        assert e.max() <= 3e-3 * np.abs(y64s).max()                                           # sanity, absolute
+        lr.append(np.log(_rms(e) / _rms(ec)))
+        lm.append(np.log(e.max() / ec.max()))
+    gm_rms, gm_max = float(np.exp(np.mean(lr))), float(np.exp(np.mean(lm)))
+    print(f"[{tag}] hip / cpu-oracle-fp32 error ratio over {N_CLIPS} clips: geometric mean rms {gm_rms:.2f} max {gm_max:.2f}; "
+          f"single clips rms {np.exp(min(lr)):.2f} .. {np.exp(max(lr)):.2f}")
+    assert gm_rms <= GM_RMS and gm_max <= GM_MAX, (tag, gm_rms, gm_max)
 
 
 def _oracle64_forward(tag):

@@ -7,6 +7,8 @@ import pytest
 import torch
 
 SHAPES = [(2, 32, 16, 16), (1, 16, 32, 32), (2, 8, 16, 32), (1, 4, 32, 32), (2, 2, 64, 64), (1, 32, 64, 128), (1, 16, 128, 64)]
+# the three fused call shapes of vm_asr_48k at B = 1 (enc0/out0, out1, out2) — the oracle chain does them in seconds
+BENCH_SHAPES = [(1, 32, 128, 128), (1, 16, 256, 256), (1, 2, 512, 512)]
 
 
 def _params(D, seed, dtype=torch.float32):
@@ -47,8 +49,15 @@ NAMES = ["y", "dx", "dWx", "dWdt", "ddtb", "dA_logs", "dDs"]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("shape", SHAPES + BENCH_SHAPES)
 def test_fused_core_matches_oracle_chain_fp32(shape):
+    """Fused HIP core vs the oracle's chain of the reference steps, adjudicated by the float64 build of the same chain —
+    at small shapes AND at the benchmark call shapes.  Bounds (round 3, after the decay exp stopped being v_exp_f32 —
+    csrc/scan_prims.h decay_f): the output and dx are as close to float64 as the sequential fp32 recurrence of
+    selective_scan_ref (y: x1.5 in the max norm and in RMS, + 2e-8 of scale; dx: x2.5 / x2); parameter gradients (fp32 sums over up to
+    262 144 positions per row) within 6x its distance + 2e-6 of scale.  Measured on MI355X
+    (profiles/r03_accuracy_probe.log): y 8e-9 RMS / 8e-8..1.6e-7 max of scale for both; with v_exp_f32 the HIP output
+    was 1.7x and d(A_logs), d(dt_bias) 10-40x further from float64 than the oracle chain."""
     import oracle
     from vm_asr_amd.ss2d_core import ss2d_core, supported
     B, D, H, W = shape
@@ -65,13 +74,16 @@ def test_fused_core_matches_oracle_chain_fp32(shape):
         a, b = a.double().cpu(), b.double()
         scale = max(c.abs().max().item(), 1e-12)
         e_hip, e_cpu = (a - c).abs().max().item() / scale, (b - c).abs().max().item() / scale
-        # north_star: 1e-4 (fp32) on the output; gradients: as close to float64 as the fp32 oracle chain (x4 + floor)
+        r_hip, r_cpu = (a - c).pow(2).mean().sqrt().item() / scale, (b - c).pow(2).mean().sqrt().item() / scale
         assert a.shape == c.shape, n
+        print(f"{shape} {n}: |hip - f64| max {e_hip:.2e} rms {r_hip:.2e}  |oracle fp32 chain - f64| max {e_cpu:.2e} rms {r_cpu:.2e}")
         if n in ("y", "dx"):
-            print(f"{shape} {n}: |hip - f64| {e_hip:.2e}  |oracle fp32 chain - f64| {e_cpu:.2e}")
-        if n == "y":
-            assert e_hip <= 1e-4, (shape, n, e_hip, e_cpu)
-        assert e_hip <= 4 * e_cpu + 2e-5, (shape, n, e_hip, e_cpu)
+            k_max, k_rms = (1.5, 1.5) if n == "y" else (2.5, 2.0)            # dx measured: 1.5-1.6x in RMS, <= 2.3x max
+            assert e_hip <= 1e-4, (shape, n, e_hip, e_cpu)                    # north_star (fp32)
+            assert e_hip <= k_max * e_cpu + 2e-8, (shape, n, e_hip, e_cpu)
+            assert r_hip <= k_rms * r_cpu + 2e-9, (shape, n, r_hip, r_cpu)
+        else:
+            assert e_hip <= 6 * e_cpu + 2e-6, (shape, n, e_hip, e_cpu)
 
 
 @pytest.mark.gpu

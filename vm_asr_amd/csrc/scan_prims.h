@@ -113,6 +113,43 @@ __device__ __forceinline__ float shift_from_next_lane(float v, int lane, float l
 // instructions) — none of which this argument range needs.
 __device__ __forceinline__ float ln_fast(float u) { return __builtin_amdgcn_logf(u) * 0.6931471805599453f; }
 
+// Decay of one step, a = exp(delta A)  (cus/selective_scan_fwd_kernel.cuh:125-127 uses exp2f(delta A log2e) under
+// --use_fast_math; the CPU reference torch.exp).  NOT v_exp_f32: the hardware exp2 is a 1-ulp approximation, and for
+// the a = 0.9 .. 0.999 of this model an ulp of a is 1e-5 .. 1e-3 of (1 - a), the quantity the recurrence actually
+// depends on.  Measured on MI355X against float64 (tools/accuracy_probe.py, profiles/r03_accuracy_probe.log): with
+// v_exp_f32 the fused core's output is 1.7x and its d(A), d(dt_bias) gradients 10x further from float64 than the
+// sequential fp32 recurrence of selective_scan_ref; with a correctly rounded exp they are equal.  This is a standard
+// Cody-Waite reduction + degree-6 polynomial in FMAs: <= 0.93 ulp, rms 0.29 ulp (correct rounding: 0.29), unbiased;
+// 12 full-rate VALU instructions instead of v_mul + the quarter-rate v_exp_f32.
+#if defined(VMASR_PRECISE_DECAY)     // accuracy experiments: correctly rounded through float64
+__device__ __forceinline__ float decay_f(float dl, float A) { return (float)exp((double)dl * (double)A); }
+#elif defined(VMASR_FAST_DECAY)      // round 1-2 behaviour, for A/B measurements
+__device__ __forceinline__ float decay_f(float dl, float A) { return __builtin_amdgcn_exp2f(dl * (A * kLog2e)); }
+#else
+__device__ __forceinline__ float decay_f(float dl, float A) {
+    const float z = fmaxf(dl * A, -104.f);             // exp(-104) < the smallest denormal; also keeps n finite
+    const float n = __builtin_rintf(z * kLog2e);
+    float r = fmaf(n, -0.693145751953125f, z);          // ln 2 = hi + lo, hi exact in 12 bits: n * hi is exact
+    r = fmaf(n, -1.428606765330187e-06f, r);
+    float p = 0.0013933643931522965f;                   // near-minimax fit of (e^r - 1 - r) / r^2 on |r| <= ln2 / 2
+    p = fmaf(p, r, 0.008363175205886364f);
+    p = fmaf(p, r, 0.04166646674275398f);
+    p = fmaf(p, r, 0.16666576266288757f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.f);
+    p = fmaf(p, r, 1.f);
+    return ldexpf(p, (int)n);
+}
+#endif
+
+#ifdef VMASR_PRECISE_SOFTPLUS
+__device__ __forceinline__ float softplus_f(float x) { return x <= 20.f ? (float)log1p(exp((double)x)) : x; }
+__device__ __forceinline__ void softplus_sigmoid_f(float x, float &sp, float &sig) {
+    const double e = exp((double)fminf(x, 20.f));
+    sp = x <= 20.f ? (float)log1p(e) : x;
+    sig = x <= 20.f ? (float)(e / (1.0 + e)) : 1.f;
+}
+#else
 __device__ __forceinline__ float softplus_f(float x) {
     const float e = __expf(fminf(x, 20.f));
     const float u = 1.f + e;
@@ -134,6 +171,7 @@ __device__ __forceinline__ void softplus_sigmoid_f(float x, float &sp, float &si
     sp = x <= 20.f ? s : x;
     sig = x <= 20.f ? e * __builtin_amdgcn_rcpf(u) : 1.f;
 }
+#endif
 
 }  // namespace
 }  // namespace vmasr

@@ -192,12 +192,12 @@ __global__ __launch_bounds__(64 * WPT * TPG, 4) void ss2d_fwd_kernel(const FwdAr
         for (int r = 0; r < RW; ++r) {
             const int kd = k * D + d0 + r;
             const float wdt = a.Wdt[kd], bias = a.dtb[kd], Dk = a.Dsk[kd];
-            const float An = -expf(a.Alog[kd]) * kLog2e;
+            const float An = -expf(a.Alog[kd]);
             float av[4], bv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float dl = softplus_f(fmaf(wdt, S[kk * 3 + 0][i], bias));
-                av[i] = __builtin_amdgcn_exp2f(dl * An);
+                av[i] = decay_f(dl, An);
                 bv[i] = dl * u[r][i] * S[kk * 3 + 1][i];
             }
             Pair agg, excl, tot;
@@ -349,12 +349,12 @@ __global__ __launch_bounds__(64 * WPT * TPG, (64 * WPT * TPG) >= 512 ? 2 : 3) vo
         for (int r = 0; r < RW; ++r) {
             const int kd = k * D + d0 + r;
             const float wdt = a.Wdt[kd], bias = a.dtb[kd], Dk = a.Dsk[kd];
-            const float Araw = -expf(a.Alog[kd]), An = Araw * kLog2e;
+            const float Araw = -expf(a.Alog[kd]), An = Araw;
             float dl[4], sig[4], av[4], bv[4], be[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 softplus_sigmoid_f(fmaf(wdt, S[kk * 3 + 0][i], bias), dl[i], sig[i]);
-                av[i] = __builtin_amdgcn_exp2f(dl[i] * An);
+                av[i] = decay_f(dl[i], An);
                 bv[i] = dl[i] * u[r][i] * S[kk * 3 + 1][i];
                 be[i] = dout[r][i] * S[kk * 3 + 2][i];
             }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
         out_row[r] = static_cast<T *>(p.out_ptr) + m.b * p.out_batch_stride + d * p.out_d_stride;
         Dv[r] = p.D_ptr ? static_cast<const float *>(p.D_ptr)[d] : 0.f;
         bias[r] = p.delta_bias_ptr ? static_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
-        An1[r] = DYN ? 0.f : Ap[d * p.A_d_stride] * kLog2e;
+        An1[r] = DYN ? 0.f : Ap[d * p.A_d_stride];
         h_in[r] = 0.f;
         p_in[r] = 1.f;
     }
@@ -174,11 +174,11 @@ __global__ __launch_bounds__(MODE == 3 ? 1024 : 256) void sscan_fwd_kernel(const
             if (MODE != 2) load4u<T, VEC>(Cg + n * p.C_dstate_stride, t0, L, Cv, full);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float An = DYN ? Ap[(m.d0 + r) * p.A_d_stride + n * p.A_dstate_stride] * kLog2e : An1[r];
+                const float An = DYN ? Ap[(m.d0 + r) * p.A_d_stride + n * p.A_dstate_stride] : An1[r];
                 float a[kItems], bb[kItems];
 #pragma unroll
                 for (int i = 0; i < kItems; ++i) {
-                    a[i] = __builtin_amdgcn_exp2f(dl[r][i] * An);
+                    a[i] = decay_f(dl[r][i], An);
                     bb[i] = dl[r][i] * uv[r][i] * Bv[i];
                 }
                 Pair agg{a[0], bb[0]};
@@ -359,14 +359,14 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
             }
             if constexpr (DYN) {
                 for (int n = lane; n < N; n += kWave) {
-                    const float An = Ap[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
-                    s_an[wave * kMaxDState + n] = tn < L ? __builtin_amdgcn_exp2f(dnx * An) : 1.f;
+                    const float An = Ap[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride];
+                    s_an[wave * kMaxDState + n] = tn < L ? decay_f(dnx, An) : 1.f;
                     s_g[wave * kMaxDState + n] =
                         (MODE == 1 && tn < L) ? ws[(((xrow0 + tile1 - 1) * N) + n) * 2 + 1] : 0.f;
                 }
             } else {
-                const float An = Ap[(d0 + r) * p.A_d_stride] * kLog2e;
-                a_nx[r] = tn < L ? __builtin_amdgcn_exp2f(dnx * An) : 1.f;
+                const float An = Ap[(d0 + r) * p.A_d_stride];
+                a_nx[r] = tn < L ? decay_f(dnx, An) : 1.f;
                 if (MODE == 1 && tn < L) {
                     if (geo.fused_carry) {
                         // compose the reverse aggregates of every tile to the right of this task:
@@ -427,10 +427,10 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float Araw = DYN ? Ap[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride] : A1[r];
-                const float An = Araw * kLog2e;
+                const float An = Araw;
                 float a[kItems], al[kItems], be[kItems];
 #pragma unroll
-                for (int i = 0; i < kItems; ++i) a[i] = __builtin_amdgcn_exp2f(dl[r][i] * An);
+                for (int i = 0; i < kItems; ++i) a[i] = decay_f(dl[r][i], An);
                 float anx, gin;
                 if constexpr (DYN) { anx = s_an[wave * kMaxDState + n]; gin = s_g[wave * kMaxDState + n]; }
                 else { anx = a_nx[r]; gin = g_in[r]; }
