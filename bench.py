@@ -70,12 +70,11 @@ def build_trainer(config, device, amp=True, capturable=False, amp_scope="generat
 
 
 def synth_batch(config, device, rank):
-    B, T = config.DATA.BATCH_SIZE, int(config.DATA.SEGMENT * config.DATA.TARGET_SR)
-    g = torch.Generator().manual_seed(123 + 1000 * rank)
-    tgt = 0.1 * torch.randn(B, 1, T, generator=g)
-    g2 = torch.Generator().manual_seed(124 + 1000 * rank)
-    inp = 0.1 * torch.randn(B, 1, T, generator=g2)
-    hc = torch.full((B,), int((config.DATA.STFT.N_FFT // 2 + 1) * 16000 / config.DATA.TARGET_SR), dtype=torch.int64)
+    """One batch of the trainer's own synthetic VCTK-shaped dataset (vm_asr_amd.trainer.SyntheticVCTK: the batch contract of
+    data_loader/data_loaders.py:482-513 — (wave_in, wave_target, highcut int64, name, pad)), default-collated, rank-seeded."""
+    from vm_asr_amd.trainer import SyntheticVCTK
+    ds = SyntheticVCTK(config, length=config.DATA.BATCH_SIZE, sr_in=16000, seed=123 + 1000 * rank)
+    inp, tgt, hc = next(iter(torch.utils.data.DataLoader(ds, batch_size=config.DATA.BATCH_SIZE, shuffle=False)))[:3]
     return inp.to(device), tgt.to(device), hc.to(device)
 
 
@@ -143,22 +142,38 @@ def main():
     graphed = False
     if not args.no_graphs:
         graphed = trainer.enable_graphs(batch, warmup=max(2, min(3, args.warmup)))
+        if not graphed:
+            # never report the host-bound eager step (2x slower) as if it were the product's number: fail loudly
+            print(json.dumps({"error": "HIP graph capture / replay self-test failed; rerun with --no-graphs to measure the eager step",
+                              "detail": getattr(trainer, "graph_error", None), "rank": rank}), flush=True)
+            sys.exit(3)
     for _ in range(args.warmup):
         trainer.train_step(*batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    trainer.time_reduces = world > 1
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.train_step(*batch)
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own time to finish its K steps
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
+        trainer.time_reduces = False
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        mine = torch.tensor([dt_own / args.steps * 1e3, trainer.reduce_exposed_ms() / args.steps], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(float(v[0]), 3) for v in allr],
+                    "allreduce_exposed_ms_per_step": [round(float(v[1]), 3) for v in allr],
+                    "note": "exposed = time the compute stream waits at the join of the two asynchronous gradient all-reduces "
+                            "(MPD 164 MB launched before the generator backward, generator 9 MB after it)"}
 
     # per-kernel device time: HIP events recorded by the library around each of its launches, on the
     # launch stream.  Events cannot be read inside a replayed graph, so this is a second pass of the
@@ -192,6 +207,8 @@ def main():
                    "execution": ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
                                  "optimiser graph)") if graphed else "eager"},
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     if rank == 0 and timing:
         prof = _lib.prof_collect()
         kern = {k: dict(v, avg_us=v["ms"] / v["launches"] * 1e3,

@@ -641,3 +641,239 @@ def test_fullsize_graph_replay_matches_eager_on_new_batches():
     for i, (a, b) in enumerate(zip(logs["eager"], logs["graph"])):
         for k in a:
             assert abs(a[k] - b[k]) <= (5e-3 if i == 0 else 5e-2) * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+
+
+@pytest.mark.gpu
+def test_fullsize_b4_train_step_pinned_to_cpu_oracle():
+    """BASELINE configs[2] at FULL size and the yaml's batch (vm_asr_48k_MPD: B = 4, dims 16, 48 kHz clips, MPD hidden 32):
+    one G+MPD train step — forward, MR-STFT + LSGAN + feature-matching losses, both backwards — on the GPU against the
+    SAME trainer on the host with the oracle's C kernels in the generator's operator hooks (torch-CPU modules elsewhere),
+    i.e. against the CPU restatement of the reference, not against another HIP run.  No stochastic depth (different RNG
+    streams on the two devices).  Checked: the five loss values; the whole gradient vector of each model (relative L2 and
+    cosine) and, as checksums, sum and L1 norm.
+      fp32 GPU step (MPD GEMMs as bf16x3 triples, the default): losses to 1e-4 relative (north_star, fp32); whole gradient
+      vector within 1e-3 (generator; measured 2.4e-5) / 1e-4 (MPD; measured 1.4e-6) relative L2 of the oracle run's;
+      bf16-autocast GPU step (the benchmark's dtype): losses to 1e-2 relative (north_star, bf16), gradient cosine
+      >= 0.995 (generator; measured 0.9993, relative L2 3.8e-2) / 0.9999 (MPD, which runs outside autocast)."""
+    import bench
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
+    from vm_asr_amd.trainer import unwrap
+    cfg = bench.make_config("vm_asr_48k_MPD", 4)
+    cfg.defrost()
+    cfg.MODEL.VSSM.DROP_PATH_RATE = 0.0
+    cfg.freeze()
+
+    def grads(tr):
+        out = {}
+        for key in ("generator", "mpd"):
+            gs = [p.grad.detach().double().flatten().cpu() for p in unwrap(tr.models[key]).parameters() if p.grad is not None]
+            out[key] = torch.cat(gs)
+        return out
+
+    def step(device, amp):
+        tr = bench.build_trainer(cfg, device, amp=amp)
+        if device.type == "cpu":
+            use_oracle(tr.models["generator"])
+        for m in tr.models.values():
+            m.train()
+        batch = bench.synth_batch(cfg, device, 0)
+        _, logs = tr._forward_backward(*batch)
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        return {k: float(v) for k, v in logs.items()}, grads(tr)
+
+    with oracle_stft_patch():
+        l_cpu, g_cpu = step(torch.device("cpu"), False)
+    assert g_cpu["generator"].numel() == 3_010_352 - 764_288 and g_cpu["mpd"].numel() == 41_092_165   # SURVEY.md 0.2-1, 2 #17
+    for amp, tol_loss, tol_g, tol_d, cos_g, cos_d in ((False, 1e-4, 1e-3, 1e-4, 0.999999, 0.999999), (True, 1e-2, None, None, 0.995, 0.9999)):
+        l_gpu, g_gpu = step(torch.device("cuda", 0), amp)
+        torch.cuda.empty_cache()
+        assert set(l_gpu) == set(l_cpu)
+        for k in l_cpu:
+            assert abs(l_gpu[k] - l_cpu[k]) <= tol_loss * max(abs(l_cpu[k]), 1e-3), (amp, k, l_gpu[k], l_cpu[k])
+        for key, tol, cmin in (("generator", tol_g, cos_g), ("mpd", tol_d, cos_d)):
+            a, b = g_gpu[key], g_cpu[key]
+            assert a.shape == b.shape and torch.isfinite(a).all()
+            rel = ((a - b).norm() / b.norm()).item()
+            cos = (torch.dot(a, b) / (a.norm() * b.norm())).item()
+            print(f"amp={amp} {key}: losses ok; gradient rel L2 {rel:.2e} cosine {cos:.6f}; checksums sum {a.sum().item():.6e} vs {b.sum().item():.6e}, "
+                  f"L1 {a.abs().sum().item():.6e} vs {b.abs().sum().item():.6e}")
+            assert cos >= cmin, (amp, key, cos)
+            if tol is not None:
+                assert rel <= tol, (amp, key, rel)
+                assert abs(a.abs().sum() - b.abs().sum()).item() <= tol * b.abs().sum().item(), (amp, key)
+
+
+def _flat8_worker(rank, world, port, ret):
+    """World-size-8 leg of the flat-buffer path: rank r trains on clip r of an 8-clip batch (torch.set_num_threads(1):
+    eight processes share this container's cores)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)          # (the parent exports OMP_NUM_THREADS=1 for the children: libgomp reads it when it loads)
+    from oracle.torch_backend import oracle_stft_patch
+    from vm_asr_amd.trainer import init_distributed, unwrap
+    init_distributed()
+    cfg = _tiny_config(gan=True, batch=1)
+    tr = _make_trainer(cfg, dp_mode="flat")
+    for m in tr.models.values():
+        m.train()
+    full = _batch(cfg, world, seed=11)
+    with oracle_stft_patch():
+        _, logs = tr._forward_backward(*(t[rank:rank + 1] for t in full))
+        local = {k: tr._flat[k].clone() if k in tr._flat else None for k in ("generator", "mpd")}
+        if local["generator"] is None:      # flat buffers are set up lazily by the first reduce
+            tr._setup_flat("generator", tr.optimizer_G); tr._setup_flat("mpd", tr.optimizer_D)
+            local = {k: tr._flat[k].clone() for k in ("generator", "mpd")}
+        tr._reduce_and_step()
+    ret[rank] = dict(local={k: v for k, v in local.items()}, reduced={k: tr._flat[k].clone() for k in local},
+                     sd={k: v.detach().clone() for k, v in unwrap(tr.models["generator"]).state_dict().items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_gloo_world8():
+    """configs[3]'s process layout (8 ranks, one clip shard each) on the CPU: after the step every rank holds the MEAN of
+    the eight local flat gradient buffers (generator and MPD: one all-reduce each) and identical weights."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + (os.getpid() + 29) % 2000
+    procs = [ctx.Process(target=_flat8_worker, args=(r, 8, port, ret)) for r in range(8)]
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "GOMP_SPINCOUNT")}
+    os.environ.update(OMP_NUM_THREADS="1", GOMP_SPINCOUNT="0")     # eight processes share this machine's cores
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = {r: ret[r] for r in range(8)}          # ONE transfer per rank (every access to the manager's dict pickles the whole entry)
+    for key in ("generator", "mpd"):
+        mean = torch.stack([res[r]["local"][key].double() for r in range(8)]).mean(0)
+        assert float(mean.abs().max()) > 0
+        for r in range(8):
+            got = res[r]["reduced"][key].double()
+            assert torch.allclose(got, mean, rtol=1e-5, atol=1e-7 * float(mean.abs().max())), (key, r)
+    for r in range(1, 8):
+        for k, v in res[0]["sd"].items():
+            assert torch.equal(v, res[r]["sd"][k]), (r, k)
+
+
+def test_epoch_decisions_gloo_world8():
+    """The epoch-decision logic (mean of the ranks' epoch scalars -> best / early stop / NaN abort) with 8 ranks."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + (os.getpid() + 41) % 2000
+    procs = [ctx.Process(target=_sync_worker, args=(r, 8, port, ret)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret[(r, "exit")] == "nan-abort" and ret[(r, "epochs")] == 4 for r in range(8))
+    for e in (1, 2, 3):
+        assert all(ret[(r, e)] == ret[(0, e)] for r in range(8))
+        assert ret[(0, e)][0] is True and abs(ret[(0, e)][1] - (5.0 - e / 8)) < 1e-12      # one of eight ranks improves by e
+
+
+def test_checkpoint_optimizer_state_loads_into_a_plain_adamw(tmp_path):
+    """The direction the reference needs: a torch.optim.AdamW built the way the reference builds it (main.py:168-201:
+    float lr, not fused, not capturable) loads the optimiser state of a checkpoint written by this trainer — whose own
+    optimisers may be capturable / fused with a device lr tensor — and steps.  The saved param_groups carry no runtime flag."""
+    from oracle.torch_backend import oracle_stft_patch
+    from vm_asr_amd.config import yacs_pickle_compat
+    from vm_asr_amd.trainer import load_optimizer_state, portable_optimizer_state, set_weight_decay
+    cfg = _tiny_config()
+    cfg.defrost(); cfg.OUTPUT = str(tmp_path); cfg.freeze()
+    with oracle_stft_patch():
+        a = _resumable(cfg, tmp_path, "cpu")
+        a.train_step(*_batch(cfg, 2))
+        for o in (a.optimizer_G, a.optimizer_D):     # what a GPU run's optimisers look like (capturable needs a GPU to STEP)
+            for g in o.param_groups:
+                g.update(lr=torch.tensor(float(g["lr"])), capturable=True, fused=True, foreach=None)
+        a._save_checkpoint(1, save_best=True)
+        for o in (a.optimizer_G, a.optimizer_D):
+            for g in o.param_groups:
+                g.update(lr=float(g["lr"]), capturable=False, fused=None)
+    with yacs_pickle_compat():
+        ck = torch.load(os.path.join(tmp_path, "checkpoint-best-G.pth"), map_location="cpu", weights_only=False)
+    for g in ck["optimizer"]["param_groups"]:
+        assert isinstance(g["lr"], float) and g.get("capturable", False) is False and g.get("fused") is None and g.get("foreach") is None
+    assert all(st["step"].device.type == "cpu" for st in ck["optimizer"]["state"].values())
+    gen = a.models["generator"]
+    plain = torch.optim.AdamW(set_weight_decay([gen]), lr=cfg.TRAIN.BASE_LR, eps=cfg.TRAIN.OPTIMIZER.EPS,
+                              betas=tuple(cfg.TRAIN.OPTIMIZER.BETAS), weight_decay=cfg.TRAIN.WEIGHT_DECAY)
+    plain.load_state_dict(ck["optimizer"])
+    assert all(isinstance(g["lr"], float) and not g["capturable"] for g in plain.param_groups)
+    before = [p.detach().clone() for p in gen.parameters()]
+    plain.step()                                                       # gradients of the last train_step are still there
+    assert any(not torch.equal(b, p) for b, p in zip(before, gen.parameters()))
+    # and back: an optimiser of this package keeps ITS runtime flags when it loads a state written by another one
+    for g in a.optimizer_G.param_groups:
+        g["foreach"] = True
+    sd = portable_optimizer_state(plain)
+    assert all(g["foreach"] is None for g in sd["param_groups"])
+    load_optimizer_state(a.optimizer_G, sd, torch.device("cpu"))
+    assert all(g["foreach"] is True and g["capturable"] is False for g in a.optimizer_G.param_groups)
+
+
+def test_resume_config_comes_from_the_generator_checkpoint(tmp_path):
+    """utils/utils.py:141-145: the stored config replaces the CLI config BEFORE anything is built (resume_config, called
+    first in main.py); the trainer itself no longer swaps its config after construction."""
+    from oracle.torch_backend import oracle_stft_patch
+    from vm_asr_amd.trainer import resume_config
+    cfg = _tiny_config()
+    cfg.defrost(); cfg.OUTPUT = str(tmp_path); cfg.TRAIN.EPOCHS = 7; cfg.freeze()
+    with oracle_stft_patch():
+        a = _resumable(cfg, tmp_path, "cpu")
+        a._save_checkpoint(2, save_best=True)
+    cli = _tiny_config()
+    cli.defrost(); cli.MODEL.RESUME_PATH = str(tmp_path); cli.TRAIN.EPOCHS = 99; cli.freeze()
+    got = resume_config(cli)
+    assert got.TRAIN.EPOCHS == 7 and got.MODEL.RESUME_PATH == str(tmp_path) and got.is_frozen()
+    b = _resumable(got, tmp_path, "cpu")
+    assert b.config is got and b.epochs == 7 and b.start_epoch == 3 and b.checkpoint_config.TRAIN.EPOCHS == 7
+    nothing = _tiny_config()
+    assert resume_config(nothing) is nothing
+
+
+@pytest.mark.gpu
+def test_graph_warmup_leaves_the_training_state_untouched():
+    """Trainer.enable_graphs runs real optimiser steps while warming up and capturing; with preserve_state (default) the
+    weights, spectral-norm buffers, Adam moments and step counters afterwards equal what they were before — for a fresh
+    trainer (no optimiser state yet: moments and steps are zero afterwards) and for one that has already stepped — and the
+    first replayed step equals the eager step from the same state."""
+    from vm_asr_amd.trainer import unwrap
+    cfg = _tiny_config()
+    batch = [t.cuda() for t in _batch(cfg, 2)]
+    other = [t.cuda() for t in _batch(cfg, 2, seed=3)]
+
+    def state(tr):
+        out = {f"{k}.{n}": v.detach().clone() for k, m in tr.models.items() for n, v in unwrap(m).state_dict().items()}
+        for name, o in (("G", tr.optimizer_G), ("D", tr.optimizer_D)):
+            for i, p in enumerate(q for g in o.param_groups for q in g["params"]):
+                for kk, v in o.state.get(p, {}).items():
+                    out[f"opt{name}.{i}.{kk}"] = v.detach().clone().float()
+        return out
+    for presteps in (0, 2):
+        tr = _gpu_trainer(cfg, amp=True, capturable=True)
+        ref = _gpu_trainer(cfg, amp=True, capturable=True)
+        for t in (tr, ref):
+            for m in t.models.values():
+                m.train()
+            for _ in range(presteps):
+                t.train_step(*batch)
+        before = state(tr)
+        assert tr.enable_graphs(other, warmup=2) and tr.global_step == presteps
+        after = state(tr)
+        for k, v in after.items():
+            if k in before:
+                assert torch.equal(v, before[k]), (presteps, k)
+            else:
+                assert float(v.abs().max()) == 0.0, (presteps, k)      # state created by the warm-up, reset to "fresh"
+        _, lg = tr.train_step(*batch)
+        _, le = ref.train_step(*batch)
+        for k in le:
+            assert abs(float(lg[k]) - float(le[k])) <= 2e-3 * max(1.0, abs(float(le[k]))), (presteps, k, float(lg[k]), float(le[k]))

@@ -28,7 +28,6 @@ from torch.nn.utils.parametrizations import weight_norm
 
 from . import _lib
 from .linear import _mm_acc, linear as _linear, weight_grad as _weight_grad
-from .streams import parallel as _parallel
 
 __all__ = ["PeriodDiscriminator", "MultiPeriodDiscriminator", "spectral_norm", "plain_torch_ops"]
 
@@ -1124,7 +1123,7 @@ class MultiPeriodDiscriminator(nn.Module):
         real-signal features of the discriminator pass are reused instead of recomputed)."""
         if self._use_batched(x):
             return self._forward_batched(x, detach_weights)
-        res = _parallel([(lambda d=d: d(x, detach_weights)) for d in self.discriminators], x.device, "d")
+        res = [d(x, detach_weights) for d in self.discriminators]
         return [r[0] for r in res], [r[1] for r in res]
 
     def forward_pair(self, y, y_hat):
@@ -1141,7 +1140,7 @@ class MultiPeriodDiscriminator(nn.Module):
             fmap_real = StackedFeatures([[t[:n] for t in f] for f in feats], feats.stacks, [tuple(m // 2 for m in v) for v in feats.valid])
             return y_real, y_gen, fmap_real, [[t[n:] for t in f] for f in feats]
         else:
-            res = _parallel([(lambda d=d: d(both)) for d in self.discriminators], y.device, "d")
+            res = [d(both) for d in self.discriminators]
         for s, f in res:
             y_real.append(s[:n]); y_gen.append(s[n:])
             fmap_real.append([t[:n] for t in f]); fmap_gen.append([t[n:] for t in f])

@@ -64,6 +64,13 @@ class HipAdamWStep:
                 keep.append((p, p.grad, m, v, lp))
         if not items:
             raise ValueError("no parameter with a gradient")
+        # the kernel takes ONE step count for the bias corrections (torch uses each tensor's own): every state must be at
+        # the same step (one-off host sync at build time, outside any capture).  A checkpoint whose parameters skipped
+        # steps (grad None in some of them) does not qualify: the caller keeps optimizer.step().
+        sv = torch.stack([s_.reshape(()) for s_ in steps])
+        if not bool((sv == sv[0]).all()):
+            raise ValueError("optimizer state holds different step counts per parameter")
+        self._skipped = [p for g in groups for p in g["params"] if p.grad is None]
         dev = self.lr.device
         self.items = torch.from_numpy(np.array(items, dtype=_ITEM).view(np.uint8).copy()).to(dev)
         self.chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
@@ -75,6 +82,10 @@ class HipAdamWStep:
         """The table holds raw pointers: it is stale once a parameter's .grad was re-bound (zero_grad(set_to_none), a new
         flat buffer) or the optimiser state was replaced (load_state_dict creates new exp_avg / exp_avg_sq / step tensors)."""
         state = self.optimizer.state
+        if any(g["lr"] is not self.lr for g in self.optimizer.param_groups):
+            return False                                  # the learning-rate tensor was replaced (scheduler / load_state_dict)
+        if any(p.grad is not None for p in self._skipped):
+            return False                                  # a parameter that had no gradient at build time has one now
         for (p, _, _, _, _), (pp, gp, mp, vp), step in zip(self._keep, self._ptrs, self.steps):
             st = state.get(p)
             if (p.grad is None or not st or p.data_ptr() != pp or p.grad.data_ptr() != gp or st["exp_avg"].data_ptr() != mp

@@ -31,7 +31,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .stft import spectro2wav, wav2spectro
-from .streams import parallel as _parallel
 from .layernorm import LayerNorm
 from .linear import Linear as _Linear, linear as _linear
 from .vmamba import PatchMerging2D, Permute, VSSBlock, attach_drop_path_pool
@@ -241,12 +240,10 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
         if self.training and self._dp_pool is not None:
             self._dp_pool.refresh(2 * x.shape[0], dev)     # 2B: the shared decoders run both streams stacked
         if not single:
-            # the two streams are independent between interaction points: fork them onto two HIP streams
-            mag, phase = _parallel([lambda: self.patch_embed_mag(mag), lambda: self.patch_embed_phase(phase)], dev, "g")
+            mag, phase = self.patch_embed_mag(mag), self.patch_embed_phase(phase)
             skips_m, skips_p = [mag], [phase]
             for i in range(self.num_layers):
-                mag, phase = _parallel([lambda: self.layers_encoder_mag[i](mag),
-                                        lambda: self.layers_encoder_phase[i](phase)], dev, "g")
+                mag, phase = self.layers_encoder_mag[i](mag), self.layers_encoder_phase[i](phase)
                 if i < self.num_layers - 1:
                     skips_m.append(mag)
                     skips_p.append(phase)
@@ -268,11 +265,10 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
                 mag, phase = self._interact(mag, phase)
             ms, ps = skips_m.pop(), skips_p.pop()
             if self.concat_skip:
-                mag, phase = _parallel([lambda: self.output_layer_mag(torch.cat((mag, ms), dim=-1)),
-                                        lambda: self.output_layer_phase(torch.cat((phase, ps), dim=-1))], dev, "g")
+                mag = self.output_layer_mag(torch.cat((mag, ms), dim=-1))
+                phase = self.output_layer_phase(torch.cat((phase, ps), dim=-1))
             else:
-                mag, phase = _parallel([lambda: self.output_layer_mag(mag + ms),
-                                        lambda: self.output_layer_phase(phase + ps)], dev, "g")
+                mag, phase = self.output_layer_mag(mag + ms), self.output_layer_phase(phase + ps)
         else:
             mag = self.patch_embed_mag(mag)
             skips_m = [mag]

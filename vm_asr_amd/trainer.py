@@ -161,6 +161,73 @@ def lr_to_device(optimizer, device):
         g["lr"] = shared[v]
 
 
+_RUNTIME_GROUP_KEYS = ("capturable", "fused", "foreach", "differentiable")
+
+
+def portable_optimizer_state(optimizer):
+    """optimizer.state_dict() in the form ANY torch.optim.AdamW accepts — in particular the reference's plain one
+    (main.py:168-201 builds it non-fused, non-capturable, float lr): `lr` as a Python float, the runtime flags of this
+    package's optimisers (capturable / fused / foreach) reset to their defaults, `step` counters as CPU tensors.
+    `load_optimizer_state` below is the inverse for an optimiser built by build_optimizer()."""
+    sd = optimizer.state_dict()
+    groups = []
+    for g in sd["param_groups"]:
+        g = dict(g)
+        g["lr"] = float(g["lr"])
+        if "capturable" in g:
+            g["capturable"] = False
+        for k in ("fused", "foreach"):
+            if k in g:
+                g[k] = None
+        groups.append(g)
+    state = {pid: {k: (v.detach().cpu() if (k == "step" and torch.is_tensor(v)) else v) for k, v in st.items()}
+             for pid, st in sd["state"].items()}
+    return {"state": state, "param_groups": groups}
+
+
+def load_optimizer_state(optimizer, state_dict, device):
+    """optimizer.load_state_dict that keeps THIS optimiser's runtime flags (a checkpoint — ours or the reference's —
+    carries its writer's), puts the step counters where a capturable optimiser needs them and re-creates the shared
+    device learning-rate tensor."""
+    keep = [{k: g[k] for k in _RUNTIME_GROUP_KEYS if k in g} for g in optimizer.param_groups]
+    optimizer.load_state_dict(state_dict)
+    for g, k in zip(optimizer.param_groups, keep):
+        g.update(k)
+    if optimizer.defaults.get("capturable", False):
+        for st in optimizer.state.values():
+            if "step" in st:
+                st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(device)
+    lr_to_device(optimizer, device)
+
+
+def resume_config(config, logger=None):
+    """The run's config as the reference resumes it: utils/utils.py:112-178 (`load_from_path`) replaces the CLI config
+    by the one stored in the GENERATOR's checkpoint BEFORE models, optimisers, schedulers or the trainer are built
+    (main.py calls this first).  Returns `config` unchanged when there is nothing to resume."""
+    from .config import from_yacs, yacs_pickle_compat
+    path = config.MODEL.RESUME_PATH
+    if not path:
+        return config
+    for kind in ("best", "latest"):
+        f = os.path.join(path, f"checkpoint-{kind}-G.pth")
+        if os.path.exists(f):
+            with yacs_pickle_compat():
+                ck = torch.load(f, map_location="cpu", weights_only=False)
+            if ck.get("config") is None:
+                return config
+            cfg = from_yacs(ck["config"]).clone()
+            cfg.defrost()
+            cfg.MODEL.RESUME_PATH = path
+            for k in ("EVAL_MODE", "INFERENCE_MODE", "THROUGHPUT_MODE"):      # what this invocation was asked to do
+                if hasattr(config, k):
+                    setattr(cfg, k, getattr(config, k))
+            cfg.freeze()
+            if logger is not None:
+                logger.info(f"Config restored from {f}")
+            return cfg
+    return config
+
+
 class _Logger:
     """stderr only: stdout belongs to callers that print machine-readable results (bench.py)."""
 
@@ -256,7 +323,7 @@ class BaseTrainer:
             name = "G" if key == "generator" else key
             mtype = "generator" if key == "generator" else "discriminator"
             state = {"name": name, "epoch": epoch, "state_dict": unwrap(model).state_dict(),
-                     "optimizer": self.optimizer[mtype].state_dict(), "monitor_best": self.mnt_best,
+                     "optimizer": portable_optimizer_state(self.optimizer[mtype]), "monitor_best": self.mnt_best,
                      "config": cfg_obj}
             with yacs_pickle_compat():
                 torch.save(state, os.path.join(self.log_dir, f"checkpoint-latest-{name}.pth"))
@@ -268,7 +335,7 @@ class BaseTrainer:
     def _resume_checkpoint(self):
         """Loads `checkpoint-best-*.pth` (falls back to latest) from MODEL.RESUME_PATH
         (utils/utils.py:112-178): state_dict strict, optimizer state, epoch, monitor_best; the generator's
-        checkpoint also restores the run's config, as the reference does (:141-145).  Reads the reference's own
+        config restore of the reference (:141-145) happens before construction, in `resume_config()`.  Reads the reference's own
         files too (their pickled yacs CfgNode resolves through config.yacs_pickle_compat)."""
         from .config import from_yacs, yacs_pickle_compat
         path = self.config.MODEL.RESUME_PATH
@@ -284,17 +351,16 @@ class BaseTrainer:
                         ck = torch.load(f, map_location="cpu", weights_only=False)
                     unwrap(model).load_state_dict(ck["state_dict"], strict=True)
                     if self.optimizer and mtype in self.optimizer and "optimizer" in ck:
-                        opt = self.optimizer[mtype]
-                        opt.load_state_dict(ck["optimizer"])     # state tensors follow their parameter's device
-                        lr_to_device(opt, next(unwrap(model).parameters()).device)
+                        # state tensors follow their parameter's device; this optimiser's runtime flags are kept
+                        load_optimizer_state(self.optimizer[mtype], ck["optimizer"], next(unwrap(model).parameters()).device)
                     if key == "generator":
                         self.start_epoch = ck["epoch"] + 1
                         self.mnt_best = ck.get("monitor_best", self.mnt_best)
-                        if ck.get("config") is not None:
-                            cfg = from_yacs(ck["config"]).clone()
-                            cfg.MODEL.RESUME_PATH = path
-                            cfg.freeze()
-                            self.config = cfg
+                        # The checkpoint's config is NOT swapped in here: everything this trainer derived (epochs, losses,
+                        # schedulers, log dir) came from the config it was constructed with.  The reference restores the
+                        # stored config BEFORE building anything (utils/utils.py:141-145) — that is `resume_config()`,
+                        # which main.py calls first; the stored one is kept for inspection.
+                        self.checkpoint_config = from_yacs(ck["config"]) if ck.get("config") is not None else None
                     self.logger.info(f"Resumed {name} from {f} (epoch {ck['epoch']})")
                     break
         if getattr(self, "_shadow_dst", None):
@@ -330,6 +396,7 @@ class Trainer(BaseTrainer):
         self._micro = 0                 # micro-batches seen (gradient accumulation)
         self._pending = []              # in-flight gradient all-reduces (async work handles)
         self._graphed = None
+        self.time_reduces, self._reduce_events = False, []
         self.device = device[0] if isinstance(device, (tuple, list)) else device
         self.data_loader, self.data_loader_val = data_loader_train, data_loader_val
         self.len_epoch = len_epoch if len_epoch is not None else (len(data_loader_train) if data_loader_train is not None else 0)
@@ -502,12 +569,29 @@ class Trainer(BaseTrainer):
                 self._wait_reduces()
 
     def _wait_reduces(self):
+        """Join the pending collectives.  With `time_reduces` (bench.py, N > 1) an event pair brackets the join on the
+        compute stream: the time between them is what the collectives cost the step AFTER the overlap with the
+        generator backward — the EXPOSED all-reduce time (`reduce_exposed_ms()`)."""
+        timed = getattr(self, "time_reduces", False) and self.device.type == "cuda" and bool(self._pending)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for work, flat in self._pending:
             if work is not None:
                 work.wait()                # the current stream waits for the collective (no host block on RCCL)
             if flat is not None:
                 flat.div_(self.world)
+        if timed:
+            e1.record()
+            self._reduce_events.append((e0, e1))
         self._pending = []
+
+    def reduce_exposed_ms(self):
+        """Sum of the bracketed join times since the last call (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        ms = sum(a.elapsed_time(b) for a, b in self._reduce_events)
+        self._reduce_events = []
+        return ms
 
     # ---- one optimisation step (the unit bench.py times) ------------------------------------
     def _forward_losses(self, wave_input, wave_target, highcut):
@@ -720,18 +804,60 @@ class Trainer(BaseTrainer):
             self.global_step += 1
         return st["wave_out"].detach(), st["logs"]
 
-    def enable_graphs(self, example_batch, warmup=3):
+    def _snapshot_training_state(self):
+        """Copies of everything a training step changes: parameters and buffers (spectral-norm u / v) of every model and
+        the optimisers' per-parameter state.  (None for a parameter whose optimiser state does not exist yet.)"""
+        tensors = []
+        for m in self.models.values():
+            if m is not None:
+                tensors += [(t, t.detach().clone()) for t in list(unwrap(m).parameters()) + list(unwrap(m).buffers())]
+        opt = []
+        for o in [self.optimizer_G] + ([self.optimizer_D] if self.gan else []):
+            for g in o.param_groups:
+                for p in g["params"]:
+                    st = o.state.get(p)
+                    opt.append((o, p, None if not st else {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}))
+        return tensors, opt, self.global_step, self._micro
+
+    @torch.no_grad()
+    def _restore_training_state(self, snap):
+        """In place (copy_ / zero_): the pointers captured into the HIP graphs and the AdamW table stay valid."""
+        tensors, opt, self.global_step, self._micro = snap
+        for t, c in tensors:
+            t.copy_(c)
+        for o, p, saved in opt:
+            st = o.state.get(p)
+            if not st:
+                continue
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    v.zero_() if saved is None else v.copy_(saved[k])     # no state before == a fresh optimiser: m = v = step = 0
+        self._refresh_shadows()
+
+    def enable_graphs(self, example_batch, warmup=3, preserve_state=True):
         """Capture forward+backward (one HIP graph) and the optimiser steps (a second one); the
         gradient all-reduce stays an eager RCCL call between them.  Returns True if capture worked;
-        on any failure the trainer stays in eager mode."""
+        on any failure the trainer stays in eager mode.
+
+        The warm-up iterations and the capture run REAL optimiser steps on `example_batch` (the caching allocator, the
+        flat gradient buffers and the optimiser states have to exist before anything is captured).  With
+        `preserve_state` (default) weights, buffers, Adam moments and step counters are copied back in place afterwards,
+        so that training — fresh or resumed — starts from exactly the state it was given and `global_step` / the LR
+        schedule count only real training steps."""
         from .graph_step import GraphedTrainStep
+        snap = self._snapshot_training_state() if preserve_state else None
         try:
             self._graphed = GraphedTrainStep(self, example_batch, warmup)
-            return True
+            ok = True
         except Exception as e:  # pragma: no cover - depends on the runtime
             self._graphed = None
-            self.logger.warning(f"HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly")
-            return False
+            self.graph_error = f"{type(e).__name__}: {e}"
+            self.logger.warning(f"HIP graph capture unavailable ({self.graph_error}); running eagerly")
+            ok = False
+        if snap is not None:
+            torch.cuda.synchronize(self.device)
+            self._restore_training_state(snap)
+        return ok
 
     def _to_dev(self, batch):
         wave_input, wave_target, highcut = batch[0], batch[1], batch[2]
@@ -749,9 +875,12 @@ class Trainer(BaseTrainer):
             if m is not None:
                 m.train()
         sums, count, t0 = {}, 0, time.time()
+        self._micro = 0            # accumulation is keyed on the per-epoch batch index, as in the reference (trainer/trainer.py:146-156)
+        last_idx = 0
         for batch_idx, batch in enumerate(self.data_loader):
             if batch_idx >= self.len_epoch:
                 break
+            last_idx = batch_idx   # index of the last PROCESSED batch (the loop variable is one past it after a `break`)
             wave_input, wave_target, highcut = self._to_dev(batch)
             wave_out, logs = self.train_step(wave_input, wave_target, highcut)
             if batch_idx % self.config.PRINT_FREQ == 0 or batch_idx == self.len_epoch - 1:
@@ -767,7 +896,7 @@ class Trainer(BaseTrainer):
         # (trainer/trainer.py:196-218: `(epoch * num_steps + batch_idx) // ACCUMULATION_STEPS` after the batch loop)
         if count:
             num_steps = self.len_epoch // self._acc
-            upd = (epoch * num_steps + batch_idx) // self._acc
+            upd = (epoch * num_steps + last_idx) // self._acc
             if self.lr_scheduler_G is not None:
                 self.lr_scheduler_G.step_update(upd)
             if self.gan and getattr(self, "lr_scheduler_D", None) is not None:
