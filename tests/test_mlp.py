@@ -1,0 +1,92 @@
+"""The fused Mlp branch (vm_asr_amd/csrc/mlp.hip: LayerNorm + fc1 + GELU + fc2 + residual as one MFMA kernel, and its
+backward) against the reference's composition of the same steps (model/vmamba.py:1832-1837, 483-509) — evaluated in
+float64 as the adjudicator and, as the yardstick for "bf16 accuracy", by torch's own bf16 autocast on the GPU."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _ref(x, norm, mlp, scale, dtype):
+    """x + scale * fc2(GELU(fc1(LN(x)))) in `dtype` (float64: the exact answer)."""
+    c = lambda t: t.detach().to(dtype).requires_grad_()      # noqa: E731
+    p = [c(t) for t in (x, norm.weight, norm.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias)]
+    xn = F.layer_norm(p[0], (x.shape[-1],), p[1], p[2], norm.eps)
+    y = F.linear(F.gelu(F.linear(xn, p[3], p[4])), p[5], p[6])
+    if scale is not None:
+        y = y * scale.to(dtype).view(-1, *([1] * (x.dim() - 1)))
+    return p[0] + y, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,shape,use_scale", [(8, (2, 16, 16), True), (16, (2, 5, 7), True), (16, (1, 64, 64), False), (32, (3, 8, 8), True),
+                                               (64, (2, 9, 5), False), (128, (2, 4, 4), True), (128, (1, 16, 16), False)])
+def test_fused_mlp_matches_float64_as_well_as_torch_autocast(d, shape, use_scale):
+    from vm_asr_amd.layernorm import LayerNorm
+    from vm_asr_amd.mlp import fused_mlp_residual, supported
+    from vm_asr_amd.vmamba import Mlp
+    torch.manual_seed(d + shape[1])
+    dev = "cuda"
+    norm, mlp = LayerNorm(d).to(dev), Mlp(d, 4 * d).to(dev)
+    with torch.no_grad():
+        norm.weight.add_(0.1 * torch.randn_like(norm.weight)); norm.bias.add_(0.1 * torch.randn_like(norm.bias))
+        mlp.fc1.bias.add_(0.1 * torch.randn_like(mlp.fc1.bias)); mlp.fc2.bias.add_(0.1 * torch.randn_like(mlp.fc2.bias))
+    x = torch.randn(*shape, d, device=dev)
+    gy = torch.randn(*shape, d, device=dev)
+    scale = (torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9][: shape[0]], device=dev) if use_scale else None)
+    params = [norm.weight, norm.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias]
+
+    y64, p64 = _ref(x, norm, mlp, scale, torch.float64)
+    y64.backward(gy.double())
+    want = [y64.detach()] + [t.grad for t in p64]
+
+    def run(fn):
+        xi = x.clone().requires_grad_()
+        for p in params:
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fn(xi)
+        y.backward(gy)
+        return [y.detach().double(), xi.grad.double()] + [p.grad.double() for p in params]
+
+    def plain(xi):
+        y = mlp(norm(xi))
+        return xi + (y if scale is None else y * scale.view(-1, 1, 1, 1))
+
+    def fused(xi):
+        assert supported(xi, norm, mlp)
+        return fused_mlp_residual(xi, norm, mlp, None if scale is None else scale.view(-1, 1, 1, 1))
+    got, auto = run(fused), run(plain)
+    names = ["y", "dx", "dgamma", "dbeta", "dW1", "db1", "dW2", "db2"]
+    for n, a, b, c in zip(names, got, auto, want):
+        sc = max(c.abs().max().item(), 1e-12)
+        e_f, e_a = (a - c).abs().max().item() / sc, (b - c).abs().max().item() / sc
+        print(f"d={d} {shape} {n}: fused {e_f:.2e}  torch autocast {e_a:.2e}")
+        assert a.shape == c.shape and torch.isfinite(a).all(), n
+        # north_star: 1e-2 for bf16; and no worse than torch's own bf16 autocast of the same lines (x1.5 + a floor)
+        assert e_f <= 1e-2, (n, e_f)
+        assert e_f <= 1.5 * e_a + 2e-3, (n, e_f, e_a)
+    if use_scale:       # a dropped sample (scale 0) passes through untouched, forward and backward
+        assert torch.equal(got[0][0].float(), x[0].float().double().float()) and torch.equal(got[1][0].float(), gy[0])
+
+
+@pytest.mark.gpu
+def test_vssblock_uses_the_fused_mlp_under_autocast_only():
+    """Under bf16 autocast VSSBlock runs its Mlp branch through the fused kernel (same result as the unfused module path
+    within bf16 accuracy); in fp32 it does not (the fused kernel is a bf16 operator)."""
+    from vm_asr_amd import mlp as M
+    from vm_asr_amd.vmamba import VSSBlock
+    torch.manual_seed(0)
+    blk = VSSBlock(hidden_dim=16, drop_path=0.0, ssm_d_state=1, ssm_dt_rank="auto", forward_type="v5").cuda()
+    x = torch.randn(2, 32, 32, 16, device="cuda")
+    assert not M.supported(x, blk.norm2, blk.mlp)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert M.supported(x, blk.norm2, blk.mlp)
+        y1 = blk(x)
+        import os
+        os.environ["VMASR_FUSED_MLP"] = "0"
+        try:
+            y0 = blk(x)
+        finally:
+            os.environ.pop("VMASR_FUSED_MLP")
+    assert y1.dtype == torch.float32 and (y1 - y0).abs().max() <= 2e-2 * y0.abs().max()

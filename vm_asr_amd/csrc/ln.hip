@@ -18,6 +18,9 @@
 // (deterministic, no atomics).
 #include "common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace vmasr {
 namespace {
 
@@ -102,11 +105,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T *__restrict__ x, co
     }
 }
 
+// Tickets of the "last workgroup reduces" epilogue of ln_bwd_kernel: one counter per stream slot (launches on one stream
+// never overlap; the host maps every stream it sees to its own slot), zero at load time and reset by the workgroup that
+// takes the last ticket — so no zero-fill launch and nothing to allocate (graph-capturable).
+constexpr int kTicketSlots = 64;
+__device__ unsigned int g_ln_ticket[kTicketSlots];
+
+struct LnFinish {
+    float *dgamma, *dbeta;   // written by the last workgroup when slot >= 0
+    int slot;                // < 0: leave the per-workgroup partials to ln_bwd_reduce_kernel
+    const float *residual;   // optional (rows, C) fp32 added to dx (the gradient arriving over a residual connection)
+};
+
 template <typename T, typename TG, int LPR, bool VEC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, const TG *__restrict__ gy,
                                                      const float *__restrict__ gamma, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, T *__restrict__ dx,
-                                                     float *__restrict__ part, const LnGeom g) {
+                                                     float *__restrict__ part, const LnGeom g, const LnFinish fin) {
     constexpr int RPB = 256 / LPR;
     __shared__ float s_acc[2][1024];  // reused per vector slot
     const int sub = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
@@ -149,6 +164,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
                     float o[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = rs * (gv[k][i] * gm[k][i] - s1 - v[k][i] * s2);
+                    if (fin.residual) {
+                        float rv[4];
+                        load4<float, VEC>(fin.residual + r * g.C, (k * LPR + sub) * 4, g.C, rv);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] += rv[i];
+                    }
                     store4<T, VEC>(dx + r * g.C, (k * LPR + sub) * 4, g.C, o);
                 }
         }
@@ -178,6 +199,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
                 if (c < g.C) { pg[c] = a; pb[c] = bsum; }
             }
         }
+        if (fin.slot >= 0) {
+            // the workgroup that takes the last ticket sums everybody's partials (release: fence + barrier before the
+            // ticket; acquire: fence after it) — replaces a 9 us launch per LayerNorm backward (65 per training step)
+            __shared__ bool s_last;
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned int t = atomicAdd(&g_ln_ticket[fin.slot], 1u);
+                s_last = t == gridDim.x - 1;
+            }
+            __syncthreads();
+            if (s_last) {
+                __threadfence();
+                const int nblk = gridDim.x, C2 = 2 * g.C;
+                for (int c = threadIdx.x; c < C2; c += 256) {
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four independent chains: the loads pipeline
+                    int k = 0;
+                    for (; k + 4 <= nblk; k += 4) {
+                        a0 += part[(size_t)k * C2 + c];
+                        a1 += part[(size_t)(k + 1) * C2 + c];
+                        a2 += part[(size_t)(k + 2) * C2 + c];
+                        a3 += part[(size_t)(k + 3) * C2 + c];
+                    }
+                    for (; k < nblk; ++k) a0 += part[(size_t)k * C2 + c];
+                    const float a = (a0 + a1) + (a2 + a3);
+                    if (c < g.C) { if (fin.dgamma) fin.dgamma[c] = a; }
+                    else if (fin.dbeta) fin.dbeta[c - g.C] = a;
+                }
+                if (threadIdx.x == 0) g_ln_ticket[fin.slot] = 0;
+            }
+        }
     }
 }
 
@@ -198,6 +250,17 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
         if (dgamma) dgamma[c] = a;
         if (dbeta) dbeta[c] = b;
     }
+}
+
+// stream -> ticket slot (first come first served; a 65th concurrent stream would share slot 0 with the first)
+int ticket_slot(hipStream_t st) {
+    static std::mutex mu;
+    static std::vector<hipStream_t> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    for (size_t i = 0; i < seen.size(); ++i)
+        if (seen[i] == st) return (int)(i % kTicketSlots);
+    seen.push_back(st);
+    return (int)((seen.size() - 1) % kTicketSlots);
 }
 
 int lpr_for(int C) {
@@ -223,7 +286,7 @@ int check(const void *x, int rows, int C, int dtype, const char *what) {
 
 template <typename T, typename TO, bool VEC, int KIND>  // KIND 0 fwd (TO = output type), 1 bwd (TO = grad type)
 int launch_lpr(int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, const void *gy, const float *gamma,
-               const float *beta, void *y, float *mean, float *rstd, float *part, const LnGeom g) {
+               const float *beta, void *y, float *mean, float *rstd, float *part, const LnGeom g, const LnFinish fin) {
 #define VMASR_LN_CASE(L)                                                                                              \
     case L:                                                                                                           \
         if (KIND == 0)                                                                                                \
@@ -231,7 +294,7 @@ int launch_lpr(int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, 
                          beta, (TO *)y, mean, rstd, g);                                                               \
         else                                                                                                          \
             VMASR_LAUNCH(VMASR_K_LN_BWD, bytes, (ln_bwd_kernel<T, TO, L, VEC>), grid, dim3(256), 0, st, (const T *)x,   \
-                         (const TO *)gy, gamma, mean, rstd, (T *)y, part, g);                                         \
+                         (const TO *)gy, gamma, mean, rstd, (T *)y, part, g, fin);                                    \
         break;
     switch (lpr) {
         VMASR_LN_CASE(1) VMASR_LN_CASE(2) VMASR_LN_CASE(4) VMASR_LN_CASE(8) VMASR_LN_CASE(16) VMASR_LN_CASE(32)
@@ -244,10 +307,11 @@ int launch_lpr(int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, 
 
 template <int KIND>
 int dispatch(int dtype, int odt, bool vec, int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, const void *gy,
-             const float *gamma, const float *beta, void *y, float *mean, float *rstd, float *part, const LnGeom g) {
+             const float *gamma, const float *beta, void *y, float *mean, float *rstd, float *part, const LnGeom g,
+             const LnFinish fin = LnFinish{nullptr, nullptr, -1, nullptr}) {
 #define VMASR_LN_T(TT, TO)                                                                                             \
-    (vec ? launch_lpr<TT, TO, true, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g)            \
-         : launch_lpr<TT, TO, false, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g))
+    (vec ? launch_lpr<TT, TO, true, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g, fin)       \
+         : launch_lpr<TT, TO, false, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g, fin))
     // (x dtype, y/gy dtype) pairs: equal, 16-bit x with fp32 y (what autocast gives F.layer_norm), and
     // fp32 x with 16-bit y (the fp32 residual stream normalised straight into a GEMM operand)
     if (dtype == VMASR_F32 && odt == VMASR_F32) return VMASR_LN_T(float, float);
@@ -292,22 +356,34 @@ VMASR_EXPORT size_t vmasr_layer_norm_bwd_workspace(int32_t rows, int32_t C) {
 VMASR_EXPORT int vmasr_layer_norm_bwd(const void *x, const void *gy, const float *gamma, const float *mean,
                                       const float *rstd, void *dx, float *dgamma, float *dbeta, float *ws, int32_t rows,
                                       int32_t C, int32_t dtype, int32_t gy_dtype, vmasr_stream_t stream) {
+    return vmasr_layer_norm_bwd_res(x, gy, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, ws, rows, C, dtype, gy_dtype, stream);
+}
+
+VMASR_EXPORT int vmasr_layer_norm_bwd_res(const void *x, const void *gy, const float *gamma, const float *mean,
+                                          const float *rstd, const float *residual, void *dx, float *dgamma, float *dbeta,
+                                          float *ws, int32_t rows, int32_t C, int32_t dtype, int32_t gy_dtype,
+                                          vmasr_stream_t stream) {
     if (int e = check(x, rows, C, dtype, "layer_norm_bwd")) return e;
+    VMASR_REQUIRE(!residual || dtype == VMASR_F32, VMASR_EINVAL, "layer_norm_bwd: a residual needs fp32 x / dx");
     VMASR_REQUIRE(gy && mean && rstd && dx, VMASR_EINVAL, "layer_norm_bwd: null tensor");
     const bool affine = dgamma || dbeta;
     VMASR_REQUIRE(!affine || ws, VMASR_ENOSPACE, "layer_norm_bwd: workspace required for dgamma/dbeta");
     const int lpr = lpr_for(C);
     const LnGeom g{rows, C, (C + 4 * lpr - 1) / (4 * lpr), 0.f};
     const size_t al = dtype == VMASR_F32 ? 16 : 8;
-    const bool vec = C % 4 == 0 && aligned_to(x, al) && aligned_to(gy, 16) && aligned_to(dx, al);
+    const bool vec = C % 4 == 0 && aligned_to(x, al) && aligned_to(gy, 16) && aligned_to(dx, al) && (!residual || aligned_to(residual, 16));
     const double es = dtype == VMASR_F32 ? 4 : 2, eg = gy_dtype == VMASR_F32 ? 4 : 2;
     const double bytes = rows * (double)C * (2 * es + eg) + 8.0 * rows;
     const int nblk = grid_for(rows, lpr);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // partials small enough for ONE workgroup to sum from L2 in a few microseconds: the last workgroup does it;
+    // otherwise (wide rows, many workgroups) the column-parallel reduce kernel
+    const bool fused = affine && (size_t)nblk * 2 * C * sizeof(float) <= (256u << 10);
+    const LnFinish fin{dgamma, dbeta, fused ? ticket_slot(st) : -1, residual};
     if (int e = dispatch<1>(dtype, gy_dtype, vec, lpr, dim3(nblk), st, bytes, x, gy, gamma, nullptr, dx, const_cast<float *>(mean),
-                            const_cast<float *>(rstd), affine ? ws : nullptr, g))
+                            const_cast<float *>(rstd), affine ? ws : nullptr, g, fin))
         return e;
-    if (affine)
+    if (affine && !fused)
         VMASR_LAUNCH(VMASR_K_LN_BWD_REDUCE, (double)nblk * 2 * C * 4, ln_bwd_reduce_kernel, dim3((C + 3) / 4), dim3(256), 0,
                      st, ws, nblk, C, dgamma, dbeta);
     return check_launch("layer_norm_bwd");

@@ -1,0 +1,381 @@
+// mlp.hip — the Mlp branch of a VSSBlock as ONE kernel on the gfx950 matrix cores:
+//
+//     y = x + s * fc2(GELU(fc1(LayerNorm(x))))          model/vmamba.py:1832-1837 (VSSBlock._forward, pre-norm),
+//                                                         :483-509 (Mlp), timm DropPath (s = per-sample keep mask / keep)
+//
+// for the residual stream x (rows, d) fp32 with d in {8, 16, 32, 64, 128} and hidden = 4 d — every Mlp of every shipped
+// config except the d_model = 1 block (csrc/linear.hip) and dims-32's deepest stage.  Under bf16 autocast the reference
+// runs this as LayerNorm -> cast -> GEMM -> bias -> GELU -> GEMM -> bias -> add: 6-7 launches forward and ~13 backward
+// per block over tensors of 0.1-8 MB, i.e. at the launch-latency floor (34 blocks per generator pass).
+//
+// MI355X-first design (not a GEMM library call): a WAVE owns 32 rows of x and never talks to another wave.  Both
+// products run TRANSPOSED on v_mfma_f32_32x32x16_bf16 so that the data row is the accumulator's lane (column) index:
+//     H^T (hidden x rows) = W1 (hidden x d) . xn^T (d x rows)         A = W1 rows as stored,   B = the lane's own row of xn
+//     Y^T (d x rows)      = W2 (d x hidden) . act^T (hidden x rows)   A = W2 rows as stored,   B = GELU(H^T) straight from
+// the accumulator registers — a 32x32 accumulator tile has its column on the lane and its rows in the 16 registers, which is
+// exactly the B-operand layout of a product that sums over the tile's ROW index (here: hidden), so the hidden activations
+// never leave the register file: no LDS, no barrier, no HBM.  (The k order inside such a step is permuted — register
+// 8s + j of lane half h is row 16s + 8(j>>2) + 4h + (j&3) — so W2's fragment is gathered in that order: two 8-byte loads.)
+// LayerNorm is two-pass in registers (a row's features sit in lanes l and l + 32), bias + exact-erf GELU on the fp32
+// accumulators, residual + DropPath scale in the epilogue.  HBM traffic: read x, write y (8 d bytes per row).
+//
+// Backward (recompute, nothing saved but x): the same wave re-runs LayerNorm and H^T, forms
+//     dact^T = W2^T . (s gy)^T,   gpre^T = dact^T * GELU'(H^T),   dxn^T = W1^T . gpre^T      (again register -> operand)
+// and writes dxn (bf16) plus the operands of the two weight-gradient GEMMs — act, gpre, xn, s gy in bf16, `act` and `xn`
+// with a trailing ones column so that the bias gradients are a column of the same GEMM (host: vm_asr_amd/mlp.py).
+//
+// Numerics: bf16 operands, fp32 accumulation — the reference's autocast dtype; fc1's output is NOT rounded to bf16 before
+// GELU and fc2's not before the residual add (the reference rounds both), so the result is closer to the fp32 model.
+#include "common.h"
+
+namespace vmasr {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MlpArgs {
+    const float *x;                 // (rows, D)
+    const float *gamma, *beta;      // (D)
+    const bf16_t *w1;               // (4D, D)   fc1.weight
+    const float *b1;                // (4D)
+    const bf16_t *w2;               // (D, 4D)   fc2.weight
+    const float *b2;                // (D)
+    const float *scale;             // per-sample residual scale (DropPath) or null
+    float *y;                       // (rows, D)
+    long rows;
+    int rows_per_sample;
+    float eps;
+    // backward only
+    const float *gy;                // (rows, D)
+    const bf16_t *w1t;              // (D, 4D)   fc1.weight^T
+    const bf16_t *w2t;              // (4D, D)   fc2.weight^T
+    bf16_t *dxn;                    // (rows, D)
+    bf16_t *xn_aug;                 // (rows, D + 8):  xn | 1 0 0 0 0 0 0 0
+    bf16_t *gys;                    // (rows, D):      s * gy
+    bf16_t *act_aug;                // (rows, 4D + 8): GELU(h) | 1 0 ...
+    bf16_t *gpre;                   // (rows, 4D)
+    float *mean, *rstd;             // (rows)
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+    return z;
+}
+
+// The lane's row of x in operand order: element j of k-step s is feature 16 s + 8 h + j (0 beyond D / past the end).
+template <int D, int KS>
+__device__ __forceinline__ void load_row(const float *__restrict__ p, const bool ok, const int h, float (&v)[KS][8]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int f0 = 16 * s + 8 * h;
+        if (ok && f0 < D) {
+            const float4 q0 = *reinterpret_cast<const float4 *>(p + f0), q1 = *reinterpret_cast<const float4 *>(p + f0 + 4);
+            v[s][0] = q0.x; v[s][1] = q0.y; v[s][2] = q0.z; v[s][3] = q0.w;
+            v[s][4] = q1.x; v[s][5] = q1.y; v[s][6] = q1.z; v[s][7] = q1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[s][j] = 0.f;
+        }
+    }
+}
+
+// two-pass LayerNorm statistics of the row shared by lanes l and l ^ 32
+template <int D, int KS>
+__device__ __forceinline__ void row_stats(const float (&v)[KS][8], const int h, const float eps, float &mean, float &rstd) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += v[s][j];
+    s1 += __shfl_xor(s1, 32);
+    mean = s1 * (1.f / D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        if (16 * s + 8 * h < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float c = v[s][j] - mean;
+                s2 = fmaf(c, c, s2);
+            }
+        }
+    s2 += __shfl_xor(s2, 32);
+    rstd = rsqrtf(s2 * (1.f / D) + eps);
+}
+
+template <int D, int KS>
+__device__ __forceinline__ void normalise(const float (&v)[KS][8], const int h, const float mean, const float rstd,
+                                          const float *__restrict__ gamma, const float *__restrict__ beta, bf16x8 (&xn)[KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int f0 = 16 * s + 8 * h;
+        if (f0 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xn[s][j] = (bf16_t)fmaf((v[s][j] - mean) * rstd, gamma[f0 + j], beta[f0 + j]);
+        } else {
+            xn[s] = zero8();
+        }
+    }
+}
+
+// H^T tile t (32 hidden units x 32 rows) = W1[32 t .. 32 t + 31, :] . xn^T
+template <int D, int KS>
+__device__ __forceinline__ f32x16 hidden_tile(const bf16_t *__restrict__ w1, const int t, const int r, const int h,
+                                              const bf16x8 (&xn)[KS]) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bf16_t *wr = w1 + (size_t)(32 * t + r) * D;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int f0 = 16 * s + 8 * h;
+        const bf16x8 a = f0 < D ? *reinterpret_cast<const bf16x8 *>(wr + f0) : zero8();
+        acc = mfma_bf16(a, xn[s], acc);
+    }
+    return acc;
+}
+
+// fragment of a row-major (n_rows, ld) bf16 matrix W for the PERMUTED k order of an accumulator tile used as operand:
+// element j <-> column c0 + 8 (j >> 2) + (j & 3), c0 = 32 t + 16 s2 + 4 h  (two 8-byte loads); zero row when !valid
+__device__ __forceinline__ bf16x8 perm_frag(const bf16_t *__restrict__ row_ptr, const int c0, const bool valid) {
+    bf16x8 w = zero8();
+    if (valid) {
+        const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(row_ptr + c0), hi = *reinterpret_cast<const bf16x4 *>(row_ptr + c0 + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[j] = lo[j]; w[4 + j] = hi[j]; }
+    }
+    return w;
+}
+
+constexpr float kRsqrt2 = 0.70710678118654752f, kInvSqrt2Pi = 0.3989422804014327f;
+
+template <int D>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
+    constexpr int KS = (D + 15) / 16, HD = 4 * D, HT = HD / 32, OT = (D + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile * 32 < a.rows; tile += (long)gridDim.x * 4) {
+        const long row = tile * 32 + r;
+        const bool ok = row < a.rows;
+        const float *xr = a.x + row * D;
+        float xv[KS][8];
+        load_row<D, KS>(xr, ok, h, xv);
+        float mean, rstd;
+        row_stats<D, KS>(xv, h, a.eps, mean, rstd);
+        bf16x8 xn[KS];
+        normalise<D, KS>(xv, h, mean, rstd, a.gamma, a.beta, xn);
+
+        f32x16 out[OT];
+#pragma unroll
+        for (int u = 0; u < OT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) out[u][i] = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < HT; ++t) {
+            const f32x16 hacc = hidden_tile<D, KS>(a.w1, t, r, h, xn);
+            bf16x8 act[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bq = *reinterpret_cast<const float4 *>(a.b1 + 32 * t + 8 * g + 4 * h);
+                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = hacc[4 * g + c] + bb[c];
+                    act[g >> 1][4 * (g & 1) + c] = (bf16_t)(0.5f * v * (1.f + erff(v * kRsqrt2)));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < OT; ++u) {
+                const int o = 32 * u + r;
+                const bf16_t *wr = a.w2 + (size_t)o * HD;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    out[u] = mfma_bf16(perm_frag(wr, 32 * t + 16 * s2 + 4 * h, o < D), act[s2], out[u]);
+            }
+        }
+        const float sc = a.scale ? a.scale[ok ? row / a.rows_per_sample : 0] : 1.f;
+#pragma unroll
+        for (int u = 0; u < OT; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int o0 = 32 * u + 8 * g + 4 * h;
+                if (ok && o0 < D) {
+                    const float4 xq = *reinterpret_cast<const float4 *>(xr + o0);
+                    const float4 bq = *reinterpret_cast<const float4 *>(a.b2 + o0);
+                    float4 q;
+                    q.x = fmaf(sc, out[u][4 * g + 0] + bq.x, xq.x);
+                    q.y = fmaf(sc, out[u][4 * g + 1] + bq.y, xq.y);
+                    q.z = fmaf(sc, out[u][4 * g + 2] + bq.z, xq.z);
+                    q.w = fmaf(sc, out[u][4 * g + 3] + bq.w, xq.w);
+                    *reinterpret_cast<float4 *>(a.y + row * D + o0) = q;
+                }
+            }
+    }
+}
+
+__device__ __forceinline__ void store_bf16x4(bf16_t *p, const float v0, const float v1, const float v2, const float v3) {
+    bf16x4 q;
+    q[0] = (bf16_t)v0; q[1] = (bf16_t)v1; q[2] = (bf16_t)v2; q[3] = (bf16_t)v3;
+    *reinterpret_cast<bf16x4 *>(p) = q;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpArgs a) {
+    constexpr int KS = (D + 15) / 16, HD = 4 * D, HT = HD / 32, OT = (D + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile * 32 < a.rows; tile += (long)gridDim.x * 4) {
+        const long row = tile * 32 + r;
+        const bool ok = row < a.rows;
+        float xv[KS][8];
+        load_row<D, KS>(a.x + row * D, ok, h, xv);
+        float mean, rstd;
+        row_stats<D, KS>(xv, h, a.eps, mean, rstd);
+        bf16x8 xn[KS];
+        normalise<D, KS>(xv, h, mean, rstd, a.gamma, a.beta, xn);
+        load_row<D, KS>(a.gy + row * D, ok, h, xv);                     // xv <- gy
+        const float sc = a.scale ? a.scale[ok ? row / a.rows_per_sample : 0] : 1.f;
+        bf16x8 gyf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gyf[s][j] = (bf16_t)(sc * xv[s][j]);
+            const int f0 = 16 * s + 8 * h;
+            if (ok && f0 < D) {
+                *reinterpret_cast<bf16x8 *>(a.xn_aug + row * (D + 8) + f0) = xn[s];
+                *reinterpret_cast<bf16x8 *>(a.gys + row * D + f0) = gyf[s];
+            }
+        }
+        if (ok && h == 0) {
+            bf16x8 one = zero8();
+            one[0] = (bf16_t)1.f;
+            *reinterpret_cast<bf16x8 *>(a.xn_aug + row * (D + 8) + D) = one;
+            *reinterpret_cast<bf16x8 *>(a.act_aug + row * (HD + 8) + HD) = one;
+            a.mean[row] = mean;
+            a.rstd[row] = rstd;
+        }
+
+        f32x16 dx[OT];
+#pragma unroll
+        for (int u = 0; u < OT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dx[u][i] = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < HT; ++t) {
+            const f32x16 hacc = hidden_tile<D, KS>(a.w1, t, r, h, xn);
+            const f32x16 dacc = hidden_tile<D, KS>(a.w2t, t, r, h, gyf);   // dact^T = W2^T[32 t .., :] . (s gy)^T
+            bf16x8 gp[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hid0 = 32 * t + 8 * g + 4 * h;
+                const float4 bq = *reinterpret_cast<const float4 *>(a.b1 + hid0);
+                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+                float av[4], gv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = hacc[4 * g + c] + bb[c];
+                    const float cdf = 0.5f * (1.f + erff(v * kRsqrt2));
+                    const float pdf = kInvSqrt2Pi * __expf(-0.5f * v * v);
+                    av[c] = v * cdf;
+                    gv[c] = dacc[4 * g + c] * fmaf(v, pdf, cdf);
+                    gp[g >> 1][4 * (g & 1) + c] = (bf16_t)gv[c];
+                }
+                if (ok) {
+                    store_bf16x4(a.act_aug + row * (HD + 8) + hid0, av[0], av[1], av[2], av[3]);
+                    store_bf16x4(a.gpre + row * HD + hid0, gv[0], gv[1], gv[2], gv[3]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < OT; ++u) {
+                const int f = 32 * u + r;
+                const bf16_t *wr = a.w1t + (size_t)f * HD;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    dx[u] = mfma_bf16(perm_frag(wr, 32 * t + 16 * s2 + 4 * h, f < D), gp[s2], dx[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < OT; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = 32 * u + 8 * g + 4 * h;
+                if (ok && f0 < D)
+                    store_bf16x4(a.dxn + row * D + f0, dx[u][4 * g], dx[u][4 * g + 1], dx[u][4 * g + 2], dx[u][4 * g + 3]);
+            }
+    }
+}
+
+int grid_for(long rows) {
+    const long tiles = (rows + 127) / 128;
+    return (int)(tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048);
+}
+
+bool supported_d(int d) { return d == 8 || d == 16 || d == 32 || d == 64 || d == 128; }
+
+template <bool BWD>
+int launch(const MlpArgs &a, int d, hipStream_t st) {
+    const dim3 grid(grid_for(a.rows)), block(256);
+    const double bytes = (double)a.rows * d * (BWD ? 4.0 * 2 + 2.0 * 3 + 2.0 * 8 + 64 : 8.0);
+#define VMASR_MLP_CASE(DD)                                                                                   \
+    case DD:                                                                                                 \
+        if (BWD) VMASR_LAUNCH(VMASR_K_MLP_BWD, bytes, mlp_bwd_kernel<DD>, grid, block, 0, st, a);            \
+        else VMASR_LAUNCH(VMASR_K_MLP_FWD, bytes, mlp_fwd_kernel<DD>, grid, block, 0, st, a);                \
+        break;
+    switch (d) {
+        VMASR_MLP_CASE(8) VMASR_MLP_CASE(16) VMASR_MLP_CASE(32) VMASR_MLP_CASE(64) VMASR_MLP_CASE(128)
+        default: set_error("mlp: unsupported width %d", d); return VMASR_EINVAL;
+    }
+#undef VMASR_MLP_CASE
+    return check_launch(BWD ? "mlp_bwd" : "mlp_fwd");
+}
+
+}  // namespace
+}  // namespace vmasr
+
+using namespace vmasr;
+
+VMASR_EXPORT int vmasr_mlp_supported(int32_t d, int32_t hidden) { return supported_d(d) && hidden == 4 * d; }
+
+VMASR_EXPORT int vmasr_mlp_fwd(const float *x, const float *gamma, const float *beta, float eps, const void *w1, const float *b1,
+                               const void *w2, const float *b2, const float *scale, int32_t rows_per_sample, float *y,
+                               int64_t rows, int32_t d, vmasr_stream_t stream) {
+    VMASR_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && y, VMASR_EINVAL, "mlp_fwd: null tensor");
+    VMASR_REQUIRE(supported_d(d) && rows > 0, VMASR_EINVAL, "mlp_fwd: need d in {8,16,32,64,128} (got %d) and rows > 0", d);
+    VMASR_REQUIRE(!scale || rows_per_sample > 0, VMASR_EINVAL, "mlp_fwd: rows_per_sample must be positive with a scale vector");
+    VMASR_REQUIRE(aligned_to(x, 16) && aligned_to(y, 16) && aligned_to(w1, 16) && aligned_to(w2, 16) && aligned_to(b1, 16) &&
+                      aligned_to(b2, 16), VMASR_EINVAL, "mlp_fwd: tensors must be 16-byte aligned");
+    MlpArgs a{};
+    a.x = x; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.w1 = static_cast<const bf16_t *>(w1); a.b1 = b1; a.w2 = static_cast<const bf16_t *>(w2); a.b2 = b2;
+    a.scale = scale; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.y = y; a.rows = rows;
+    return launch<false>(a, d, static_cast<hipStream_t>(stream));
+}
+
+VMASR_EXPORT int vmasr_mlp_bwd(const float *x, const float *gy, const float *gamma, const float *beta, float eps, const void *w1,
+                               const void *w1t, const float *b1, const void *w2t, const float *scale, int32_t rows_per_sample,
+                               void *dxn, void *xn_aug, void *gys, void *act_aug, void *gpre, float *mean, float *rstd,
+                               int64_t rows, int32_t d, vmasr_stream_t stream) {
+    VMASR_REQUIRE(x && gy && gamma && beta && w1 && w1t && b1 && w2t && dxn && xn_aug && gys && act_aug && gpre && mean && rstd,
+                  VMASR_EINVAL, "mlp_bwd: null tensor");
+    VMASR_REQUIRE(supported_d(d) && rows > 0, VMASR_EINVAL, "mlp_bwd: need d in {8,16,32,64,128} (got %d) and rows > 0", d);
+    VMASR_REQUIRE(!scale || rows_per_sample > 0, VMASR_EINVAL, "mlp_bwd: rows_per_sample must be positive with a scale vector");
+    VMASR_REQUIRE(aligned_to(x, 16) && aligned_to(gy, 16) && aligned_to(w1, 16) && aligned_to(w1t, 16) && aligned_to(w2t, 16) &&
+                      aligned_to(b1, 16) && aligned_to(dxn, 16) && aligned_to(xn_aug, 16) && aligned_to(gys, 16) &&
+                      aligned_to(act_aug, 16) && aligned_to(gpre, 16), VMASR_EINVAL, "mlp_bwd: tensors must be 16-byte aligned");
+    MlpArgs a{};
+    a.x = x; a.gy = gy; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.w1 = static_cast<const bf16_t *>(w1); a.w1t = static_cast<const bf16_t *>(w1t); a.b1 = b1;
+    a.w2t = static_cast<const bf16_t *>(w2t);
+    a.scale = scale; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.rows = rows;
+    a.dxn = static_cast<bf16_t *>(dxn); a.xn_aug = static_cast<bf16_t *>(xn_aug); a.gys = static_cast<bf16_t *>(gys);
+    a.act_aug = static_cast<bf16_t *>(act_aug); a.gpre = static_cast<bf16_t *>(gpre); a.mean = mean; a.rstd = rstd;
+    return launch<true>(a, d, static_cast<hipStream_t>(stream));
+}

@@ -34,6 +34,7 @@ from .csm import CrossMergeHIP, CrossScanF32, CrossScanHIP
 from . import ss2d_core as _ss2d
 from . import ss2d_glue as _glue
 from . import xproj as _xproj
+from . import mlp as _mlp
 from .dwconv import dwconv3x3_silu
 from .layernorm import LayerNorm
 from .linear import Linear as _Linear
@@ -439,6 +440,9 @@ class VSSBlock(nn.Module):
         if self.mlp_branch:
             if self.post_norm:
                 x = x + self.drop_path(self.norm2(self.mlp(x)))
+            elif _mlp.supported(x, self.norm2, self.mlp):
+                # LayerNorm + fc1 + GELU + fc2 + residual (+ the stochastic-depth scale) as ONE MFMA kernel (csrc/mlp.hip)
+                x = _mlp.fused_mlp_residual(x, self.norm2, self.mlp, self.drop_path._mask(x) if self.drop_path.active() else None)
             else:
                 x = self.drop_path.residual(x, self.mlp(self.norm2(x)))
         return x
