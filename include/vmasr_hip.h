@@ -178,9 +178,9 @@ int vmasr_layer_norm_bwd(const void *x, const void *gy, const float *gamma, cons
                          const float *rstd, void *dx, float *dgamma, float *dbeta, float *ws, int32_t rows,
                          int32_t C, int32_t dtype, int32_t gy_dtype, vmasr_stream_t stream);
 /* Same, with `residual` (rows, C) fp32 or NULL added to dx: the gradient that arrives over the residual connection
- * around a pre-norm branch (x + branch(LayerNorm(x)), model/vmamba.py:1826-1837) — fp32 x / dx only. */
+ * around a pre-norm branch (x + branch(LayerNorm(x)), model/vmamba.py:1826-1837); residual has x's dtype. */
 int vmasr_layer_norm_bwd_res(const void *x, const void *gy, const float *gamma, const float *mean,
-                             const float *rstd, const float *residual, void *dx, float *dgamma, float *dbeta, float *ws,
+                             const float *rstd, const void *residual, void *dx, float *dgamma, float *dbeta, float *ws,
                              int32_t rows, int32_t C, int32_t dtype, int32_t gy_dtype, vmasr_stream_t stream);
 
 /* nn.Linear with in/out features in {1,2,4,8} (in*out <= 32) over `rows` rows: the d_model = 1
@@ -381,11 +381,11 @@ int vmasr_split_bf16(const float *x, void *hi, void *lo, int64_t n, vmasr_stream
 
 /* ---- the Mlp branch of a VSSBlock as one MFMA kernel (vm_asr_amd/csrc/mlp.hip) ------------------------------------
  * Replaces, under bf16 autocast, `x + DropPath(Mlp(LayerNorm(x)))` of VSSBlock._forward (model/vmamba.py:1832-1837;
- * Mlp :483-509: fc1 -> GELU (exact erf) -> fc2) for the fp32 residual stream x (rows, d), d in {8,16,32,64,128},
+ * Mlp :483-509: fc1 -> GELU (exact erf) -> fc2) for the fp32 residual stream x (rows, d), d in {8,16,32,64},
  * hidden = 4 d (vmasr_mlp_supported).  All buffers are caller-owned device memory, 16-byte aligned:
  *   gamma, beta (d) fp32 = norm2;  w1 (4d, d) bf16 = fc1.weight, b1 (4d) fp32;  w2 (d, 4d) bf16 = fc2.weight, b2 (d) fp32;
  *   scale: per-sample residual scale (the DropPath keep mask / keep, one float per sample of rows_per_sample rows) or NULL;
- *   y (rows, d) fp32 = x + scale * (fc2(GELU(fc1(LN(x)) + b1)) + b2).
+ *   y (rows, d) = x + scale * (fc2(GELU(fc1(LN(x)) + b1)) + b2).
  * vmasr_mlp_bwd recomputes the forward from x and writes what the host needs for the remaining (library) steps:
  *   dxn (rows, d) bf16 = gradient wrt LayerNorm's output  (-> vmasr_layer_norm_bwd_res with residual = gy gives dx, dgamma, dbeta)
  *   xn_aug (rows, d + 8) bf16 = [LN(x) | 1 0 0 0 0 0 0 0],  gpre (rows, 4d) bf16 = gradient wrt fc1's output:
@@ -393,13 +393,13 @@ int vmasr_split_bf16(const float *x, void *hi, void *lo, int64_t n, vmasr_stream
  *   gys (rows, d) bf16 = scale * gy,  act_aug (rows, 4d + 8) bf16 = [GELU(h) | 1 0 ...]:   gys^T . act_aug = [dW2 | db2 | 0]
  *   mean, rstd (rows) fp32 of the LayerNorm;   w1t (d, 4d) = fc1.weight^T, w2t (4d, d) = fc2.weight^T (bf16, contiguous). */
 int vmasr_mlp_supported(int32_t d, int32_t hidden);
-int vmasr_mlp_fwd(const float *x, const float *gamma, const float *beta, float eps, const void *w1, const float *b1,
-                  const void *w2, const float *b2, const float *scale, int32_t rows_per_sample, float *y, int64_t rows,
-                  int32_t d, vmasr_stream_t stream);
-int vmasr_mlp_bwd(const float *x, const float *gy, const float *gamma, const float *beta, float eps, const void *w1,
+int vmasr_mlp_fwd(const void *x, const float *gamma, const float *beta, float eps, const void *w1, const float *b1,
+                  const void *w2, const float *b2, const float *scale, int32_t rows_per_sample, void *y, int64_t rows,
+                  int32_t d, int32_t x_dtype, vmasr_stream_t stream);
+int vmasr_mlp_bwd(const void *x, const void *gy, const float *gamma, const float *beta, float eps, const void *w1,
                   const void *w1t, const float *b1, const void *w2t, const float *scale, int32_t rows_per_sample, void *dxn,
                   void *xn_aug, void *gys, void *act_aug, void *gpre, float *mean, float *rstd, int64_t rows, int32_t d,
-                  vmasr_stream_t stream);
+                  int32_t x_dtype, vmasr_stream_t stream);
 
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents

@@ -105,16 +105,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T *__restrict__ x, co
     }
 }
 
-// Tickets of the "last workgroup reduces" epilogue of ln_bwd_kernel: one counter per stream slot (launches on one stream
-// never overlap; the host maps every stream it sees to its own slot), zero at load time and reset by the workgroup that
-// takes the last ticket — so no zero-fill launch and nothing to allocate (graph-capturable).
-constexpr int kTicketSlots = 64;
+// dgamma / dbeta without a reduce launch: every workgroup adds its column sums into per-stream-slot accumulators with
+// device-scope float atomics and takes a ticket; the workgroup with the last ticket writes the totals out and resets
+// accumulators and ticket.  One slot per stream (launches on one stream never overlap; the host maps every stream it
+// sees to its own slot); everything is zero at load time and left zero by every launch — no zero-fill launch, nothing
+// to allocate (graph-capturable).  The order of the atomic adds varies from run to run: dgamma / dbeta are reproducible
+// to fp32 rounding, not bit for bit (as the reference's own atomics, cus/selective_scan_bwd_kernel.cuh:262-271).
+constexpr int kTicketSlots = 16;
+constexpr int kAccFloats = 4096;    // per slot: `copies` x (dgamma | dbeta); workgroup b adds into copy b % copies, copies = min(64, 4096 / 2C):
+                                    // same-address float atomics serialise at ~0.15 us each, so 1 024 workgroups on 8 copies cost 19 us
 __device__ unsigned int g_ln_ticket[kTicketSlots];
+__device__ float g_ln_acc[kTicketSlots][kAccFloats];     // dgamma | dbeta accumulators of the launch in flight on the slot's stream
 
 struct LnFinish {
     float *dgamma, *dbeta;   // written by the last workgroup when slot >= 0
     int slot;                // < 0: leave the per-workgroup partials to ln_bwd_reduce_kernel
-    const float *residual;   // optional (rows, C) fp32 added to dx (the gradient arriving over a residual connection)
+    const void *residual;    // optional (rows, C) of x's dtype added to dx (the gradient arriving over a residual connection)
 };
 
 template <typename T, typename TG, int LPR, bool VEC>
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
                     for (int i = 0; i < 4; ++i) o[i] = rs * (gv[k][i] * gm[k][i] - s1 - v[k][i] * s2);
                     if (fin.residual) {
                         float rv[4];
-                        load4<float, VEC>(fin.residual + r * g.C, (k * LPR + sub) * 4, g.C, rv);
+                        load4<T, VEC>(static_cast<const T *>(fin.residual) + r * g.C, (k * LPR + sub) * 4, g.C, rv);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] += rv[i];
                     }
@@ -175,8 +181,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
         }
     }
     // column sums over the block's rows: lanes with equal `sub` own the same columns
-    if (part) {
-        float *pg = part + (size_t)blockIdx.x * 2 * g.C, *pb = pg + g.C;
+    if (part || fin.slot >= 0) {
+        float *pg = part ? part + (size_t)blockIdx.x * 2 * g.C : nullptr, *pb = part ? pg + g.C : nullptr;
+        const int copies = min(64, kAccFloats / (2 * g.C));
+        float *acc = fin.slot >= 0 ? g_ln_acc[fin.slot] + (blockIdx.x % copies) * 2 * g.C : nullptr;
 #pragma unroll
         for (int k = 0; k < kMaxVecPerLane; ++k) {
             if (k >= g.nvec) break;
@@ -196,14 +204,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
                     bsum += s_acc[1][(rr * LPR + sb) * 4 + i];
                 }
                 const int c = (k * LPR + sb) * 4 + i;
-                if (c < g.C) { pg[c] = a; pb[c] = bsum; }
+                if (c < g.C) {
+                    if (acc) {                       // device-scope float atomics into the slot's accumulators
+                        unsafeAtomicAdd(acc + c, a);           // global_atomic_add_f32 (atomicAdd(float*) is a CAS loop without
+                        unsafeAtomicAdd(acc + g.C + c, bsum);  //  -munsafe-fp-atomics)
+                    } else {
+                        pg[c] = a;
+                        pb[c] = bsum;
+                    }
+                }
             }
         }
-        if (fin.slot >= 0) {
-            // the workgroup that takes the last ticket sums everybody's partials (release: fence + barrier before the
-            // ticket; acquire: fence after it) — replaces a 9 us launch per LayerNorm backward (65 per training step)
+        if (acc) {
+            // the workgroup that takes the last ticket hands the totals over and leaves accumulators and ticket at zero
+            // for the next launch on this stream (release: fence + barrier before the ticket; the totals are read with
+            // atomic exchanges, i.e. at the L2 where the adds happened) — replaces a 9 us reduce launch per LayerNorm
+            // backward (65 per training step) and needs no zero-fill launch either
+            // No __threadfence(): at agent scope it writes the whole L2 back (70 us per launch, measured).  Everything the
+            // last workgroup reads was produced by device-scope ATOMICS, which execute at the coherence point; waiting for
+            // this wave's atomics to complete (vmcnt) before the barrier orders them ahead of the ticket.
             __shared__ bool s_last;
-            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {
                 const unsigned int t = atomicAdd(&g_ln_ticket[fin.slot], 1u);
@@ -211,21 +232,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
             }
             __syncthreads();
             if (s_last) {
-                __threadfence();
-                const int nblk = gridDim.x, C2 = 2 * g.C;
-                for (int c = threadIdx.x; c < C2; c += 256) {
-                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four independent chains: the loads pipeline
-                    int k = 0;
-                    for (; k + 4 <= nblk; k += 4) {
-                        a0 += part[(size_t)k * C2 + c];
-                        a1 += part[(size_t)(k + 1) * C2 + c];
-                        a2 += part[(size_t)(k + 2) * C2 + c];
-                        a3 += part[(size_t)(k + 3) * C2 + c];
-                    }
-                    for (; k < nblk; ++k) a0 += part[(size_t)k * C2 + c];
-                    const float a = (a0 + a1) + (a2 + a3);
-                    if (c < g.C) { if (fin.dgamma) fin.dgamma[c] = a; }
-                    else if (fin.dbeta) fin.dbeta[c - g.C] = a;
+                for (int c = threadIdx.x; c < 2 * g.C; c += 256) {
+                    float v = 0.f;
+                    for (int q = 0; q < copies; ++q) v += atomicExch(g_ln_acc[fin.slot] + q * 2 * g.C + c, 0.f);
+                    if (c < g.C) { if (fin.dgamma) fin.dgamma[c] = v; }
+                    else if (fin.dbeta) fin.dbeta[c - g.C] = v;
                 }
                 if (threadIdx.x == 0) g_ln_ticket[fin.slot] = 0;
             }
@@ -360,28 +371,27 @@ VMASR_EXPORT int vmasr_layer_norm_bwd(const void *x, const void *gy, const float
 }
 
 VMASR_EXPORT int vmasr_layer_norm_bwd_res(const void *x, const void *gy, const float *gamma, const float *mean,
-                                          const float *rstd, const float *residual, void *dx, float *dgamma, float *dbeta,
+                                          const float *rstd, const void *residual, void *dx, float *dgamma, float *dbeta,
                                           float *ws, int32_t rows, int32_t C, int32_t dtype, int32_t gy_dtype,
                                           vmasr_stream_t stream) {
     if (int e = check(x, rows, C, dtype, "layer_norm_bwd")) return e;
-    VMASR_REQUIRE(!residual || dtype == VMASR_F32, VMASR_EINVAL, "layer_norm_bwd: a residual needs fp32 x / dx");
     VMASR_REQUIRE(gy && mean && rstd && dx, VMASR_EINVAL, "layer_norm_bwd: null tensor");
     const bool affine = dgamma || dbeta;
     VMASR_REQUIRE(!affine || ws, VMASR_ENOSPACE, "layer_norm_bwd: workspace required for dgamma/dbeta");
     const int lpr = lpr_for(C);
     const LnGeom g{rows, C, (C + 4 * lpr - 1) / (4 * lpr), 0.f};
     const size_t al = dtype == VMASR_F32 ? 16 : 8;
-    const bool vec = C % 4 == 0 && aligned_to(x, al) && aligned_to(gy, 16) && aligned_to(dx, al) && (!residual || aligned_to(residual, 16));
+    const bool vec = C % 4 == 0 && aligned_to(x, al) && aligned_to(gy, 16) && aligned_to(dx, al) && (!residual || aligned_to(residual, al));
     const double es = dtype == VMASR_F32 ? 4 : 2, eg = gy_dtype == VMASR_F32 ? 4 : 2;
     const double bytes = rows * (double)C * (2 * es + eg) + 8.0 * rows;
     const int nblk = grid_for(rows, lpr);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // partials small enough for ONE workgroup to sum from L2 in a few microseconds: the last workgroup does it;
-    // otherwise (wide rows, many workgroups) the column-parallel reduce kernel
-    const bool fused = affine && (size_t)nblk * 2 * C * sizeof(float) <= (256u << 10);
+    // few enough atomics (workgroups x 2 C): accumulate in place, the last workgroup finishes; otherwise (wide rows, many
+    // workgroups) per-workgroup partials + the column-parallel reduce kernel
+    const bool fused = affine && 2 * C <= kAccFloats / 2 && (size_t)nblk * 2 * C <= (1u << 17);
     const LnFinish fin{dgamma, dbeta, fused ? ticket_slot(st) : -1, residual};
     if (int e = dispatch<1>(dtype, gy_dtype, vec, lpr, dim3(nblk), st, bytes, x, gy, gamma, nullptr, dx, const_cast<float *>(mean),
-                            const_cast<float *>(rstd), affine ? ws : nullptr, g, fin))
+                            const_cast<float *>(rstd), (affine && !fused) ? ws : nullptr, g, fin))
         return e;
     if (affine && !fused)
         VMASR_LAUNCH(VMASR_K_LN_BWD_REDUCE, (double)nblk * 2 * C * 4, ln_bwd_reduce_kernel, dim3((C + 3) / 4), dim3(256), 0,

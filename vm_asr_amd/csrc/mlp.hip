@@ -3,7 +3,8 @@
 //     y = x + s * fc2(GELU(fc1(LayerNorm(x))))          model/vmamba.py:1832-1837 (VSSBlock._forward, pre-norm),
 //                                                         :483-509 (Mlp), timm DropPath (s = per-sample keep mask / keep)
 //
-// for the residual stream x (rows, d) fp32 with d in {8, 16, 32, 64, 128} and hidden = 4 d — every Mlp of every shipped
+// for the residual stream x (rows, d) fp32 or bf16 (under autocast the stream is bf16 behind every PatchMerging /
+// skip convolution, fp32 elsewhere) with d in {8, 16, 32, 64, 128} and hidden = 4 d — every Mlp of every shipped
 // config except the d_model = 1 block (csrc/linear.hip) and dims-32's deepest stage.  Under bf16 autocast the reference
 // runs this as LayerNorm -> cast -> GEMM -> bias -> GELU -> GEMM -> bias -> add: 6-7 launches forward and ~13 backward
 // per block over tensors of 0.1-8 MB, i.e. at the launch-latency floor (34 blocks per generator pass).
@@ -36,19 +37,19 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct MlpArgs {
-    const float *x;                 // (rows, D)
+    const void *x;                  // (rows, D) fp32 or bf16 (the residual stream's dtype: TX)
     const float *gamma, *beta;      // (D)
     const bf16_t *w1;               // (4D, D)   fc1.weight
     const float *b1;                // (4D)
     const bf16_t *w2;               // (D, 4D)   fc2.weight
     const float *b2;                // (D)
     const float *scale;             // per-sample residual scale (DropPath) or null
-    float *y;                       // (rows, D)
+    void *y;                        // (rows, D) TX
     long rows;
     int rows_per_sample;
     float eps;
     // backward only
-    const float *gy;                // (rows, D)
+    const void *gy;                 // (rows, D) TX
     const bf16_t *w1t;              // (D, 4D)   fc1.weight^T
     const bf16_t *w2t;              // (4D, D)   fc2.weight^T
     bf16_t *dxn;                    // (rows, D)
@@ -71,15 +72,44 @@ __device__ __forceinline__ bf16x8 zero8() {
 }
 
 // The lane's row of x in operand order: element j of k-step s is feature 16 s + 8 h + j (0 beyond D / past the end).
-template <int D, int KS>
-__device__ __forceinline__ void load_row(const float *__restrict__ p, const bool ok, const int h, float (&v)[KS][8]) {
+template <typename TX>
+__device__ __forceinline__ void load4x(const TX *__restrict__ p, float (&v)[4]) {
+    if constexpr (sizeof(TX) == 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        const bf16x4 q = *reinterpret_cast<const bf16x4 *>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)q[j];
+    }
+}
+
+template <typename TX>
+__device__ __forceinline__ void store4x(TX *__restrict__ p, const float v0, const float v1, const float v2, const float v3) {
+    if constexpr (sizeof(TX) == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v0, v1, v2, v3);
+    } else {
+        bf16x4 q;
+        q[0] = (bf16_t)v0; q[1] = (bf16_t)v1; q[2] = (bf16_t)v2; q[3] = (bf16_t)v3;
+        *reinterpret_cast<bf16x4 *>(p) = q;
+    }
+}
+
+template <int D, int KS, typename TX>
+__device__ __forceinline__ void load_row(const TX *__restrict__ p, const bool ok, const int h, float (&v)[KS][8]) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int f0 = 16 * s + 8 * h;
         if (ok && f0 < D) {
-            const float4 q0 = *reinterpret_cast<const float4 *>(p + f0), q1 = *reinterpret_cast<const float4 *>(p + f0 + 4);
-            v[s][0] = q0.x; v[s][1] = q0.y; v[s][2] = q0.z; v[s][3] = q0.w;
-            v[s][4] = q1.x; v[s][5] = q1.y; v[s][6] = q1.z; v[s][7] = q1.w;
+            if constexpr (sizeof(TX) == 4) {
+                const float4 q0 = *reinterpret_cast<const float4 *>(p + f0), q1 = *reinterpret_cast<const float4 *>(p + f0 + 4);
+                v[s][0] = q0.x; v[s][1] = q0.y; v[s][2] = q0.z; v[s][3] = q0.w;
+                v[s][4] = q1.x; v[s][5] = q1.y; v[s][6] = q1.z; v[s][7] = q1.w;
+            } else {
+                const bf16x8 q = *reinterpret_cast<const bf16x8 *>(p + f0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[s][j] = (float)q[j];
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[s][j] = 0.f;
@@ -157,17 +187,32 @@ __device__ __forceinline__ bf16x8 perm_frag(const bf16_t *__restrict__ row_ptr, 
 
 constexpr float kRsqrt2 = 0.70710678118654752f, kInvSqrt2Pi = 0.3989422804014327f;
 
-template <int D>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
+// Hidden-split workgroups (HS > 1: the deep stages have 1 024 .. 4 096 rows, i.e. 32 .. 128 row tiles — one wave per tile
+// would leave the chip empty and walk 8 .. 16 hidden tiles serially): the HS waves of a workgroup share ONE row tile and
+// each takes every HS-th hidden tile; their partial output tiles (feature x row, fp32) are summed in LDS with ds_add_f32
+// and the epilogue is spread over the waves by 4-feature groups.   s_out[feature * 32 + row]
+template <int OT>
+__device__ __forceinline__ void lds_accumulate(float *s_out, const f32x16 (&acc)[OT], const int r, const int h) {
+#pragma unroll
+    for (int u = 0; u < OT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(s_out + (32 * u + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r, acc[u][i]);
+}
+
+template <int D, typename TX, int HS>
+__global__ __launch_bounds__(HS > 4 ? 64 * HS : 256) void mlp_fwd_kernel(const MlpArgs a) {
     constexpr int KS = (D + 15) / 16, HD = 4 * D, HT = HD / 32, OT = (D + 31) / 32;
+    constexpr int TPW = HS > 1 ? 1 : 4;                          // row tiles per workgroup
+    __shared__ float s_out[HS > 1 ? OT * 32 * 32 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile * 32 < a.rows; tile += (long)gridDim.x * 4) {
+    const int split = HS > 1 ? wave : 0;
+    for (long tile = (long)blockIdx.x * TPW + (HS > 1 ? 0 : wave); tile * 32 < a.rows; tile += (long)gridDim.x * TPW) {
         const long row = tile * 32 + r;
         const bool ok = row < a.rows;
-        const float *xr = a.x + row * D;
+        const TX *xr = static_cast<const TX *>(a.x) + row * D;
         float xv[KS][8];
-        load_row<D, KS>(xr, ok, h, xv);
+        load_row<D, KS, TX>(xr, ok, h, xv);
         float mean, rstd;
         row_stats<D, KS>(xv, h, a.eps, mean, rstd);
         bf16x8 xn[KS];
@@ -178,8 +223,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         for (int u = 0; u < OT; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) out[u][i] = 0.f;
+        if constexpr (HS > 1) {
+            for (int i = threadIdx.x; i < OT * 32 * 32; i += 64 * HS) s_out[i] = 0.f;
+            __syncthreads();
+        }
 #pragma unroll 1
-        for (int t = 0; t < HT; ++t) {
+        for (int t = split; t < HT; t += HS) {
             const f32x16 hacc = hidden_tile<D, KS>(a.w1, t, r, h, xn);
             bf16x8 act[2];
 #pragma unroll
@@ -202,22 +251,27 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             }
         }
         const float sc = a.scale ? a.scale[ok ? row / a.rows_per_sample : 0] : 1.f;
+        if constexpr (HS > 1) {
+            lds_accumulate<OT>(s_out, out, r, h);
+            __syncthreads();
+        }
 #pragma unroll
         for (int u = 0; u < OT; ++u)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (HS > 1 && (4 * u + g) % HS != split) continue;            // the 4-feature groups go round the waves
                 const int o0 = 32 * u + 8 * g + 4 * h;
                 if (ok && o0 < D) {
-                    const float4 xq = *reinterpret_cast<const float4 *>(xr + o0);
+                    float xq[4], acc[4];
+                    load4x<TX>(xr + o0, xq);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = HS > 1 ? s_out[(o0 + c) * 32 + r] : out[u][4 * g + c];
                     const float4 bq = *reinterpret_cast<const float4 *>(a.b2 + o0);
-                    float4 q;
-                    q.x = fmaf(sc, out[u][4 * g + 0] + bq.x, xq.x);
-                    q.y = fmaf(sc, out[u][4 * g + 1] + bq.y, xq.y);
-                    q.z = fmaf(sc, out[u][4 * g + 2] + bq.z, xq.z);
-                    q.w = fmaf(sc, out[u][4 * g + 3] + bq.w, xq.w);
-                    *reinterpret_cast<float4 *>(a.y + row * D + o0) = q;
+                    store4x<TX>(static_cast<TX *>(a.y) + row * D + o0, fmaf(sc, acc[0] + bq.x, xq[0]), fmaf(sc, acc[1] + bq.y, xq[1]),
+                                fmaf(sc, acc[2] + bq.z, xq[2]), fmaf(sc, acc[3] + bq.w, xq[3]));
                 }
             }
+        if constexpr (HS > 1) __syncthreads();                               // s_out is reused by the next row tile
     }
 }
 
@@ -227,21 +281,24 @@ __device__ __forceinline__ void store_bf16x4(bf16_t *p, const float v0, const fl
     *reinterpret_cast<bf16x4 *>(p) = q;
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpArgs a) {
+template <int D, typename TX, int HS>
+__global__ __launch_bounds__(HS > 4 ? 64 * HS : 256) void mlp_bwd_kernel(const MlpArgs a) {
     constexpr int KS = (D + 15) / 16, HD = 4 * D, HT = HD / 32, OT = (D + 31) / 32;
+    constexpr int TPW = HS > 1 ? 1 : 4;
+    __shared__ float s_out[HS > 1 ? OT * 32 * 32 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile * 32 < a.rows; tile += (long)gridDim.x * 4) {
+    const int split = HS > 1 ? wave : 0;
+    for (long tile = (long)blockIdx.x * TPW + (HS > 1 ? 0 : wave); tile * 32 < a.rows; tile += (long)gridDim.x * TPW) {
         const long row = tile * 32 + r;
         const bool ok = row < a.rows;
         float xv[KS][8];
-        load_row<D, KS>(a.x + row * D, ok, h, xv);
+        load_row<D, KS, TX>(static_cast<const TX *>(a.x) + row * D, ok, h, xv);
         float mean, rstd;
         row_stats<D, KS>(xv, h, a.eps, mean, rstd);
         bf16x8 xn[KS];
         normalise<D, KS>(xv, h, mean, rstd, a.gamma, a.beta, xn);
-        load_row<D, KS>(a.gy + row * D, ok, h, xv);                     // xv <- gy
+        load_row<D, KS, TX>(static_cast<const TX *>(a.gy) + row * D, ok, h, xv);      // xv <- gy
         const float sc = a.scale ? a.scale[ok ? row / a.rows_per_sample : 0] : 1.f;
         bf16x8 gyf[KS];
 #pragma unroll
@@ -249,12 +306,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) gyf[s][j] = (bf16_t)(sc * xv[s][j]);
             const int f0 = 16 * s + 8 * h;
-            if (ok && f0 < D) {
+            if (ok && f0 < D && split == 0) {
                 *reinterpret_cast<bf16x8 *>(a.xn_aug + row * (D + 8) + f0) = xn[s];
                 *reinterpret_cast<bf16x8 *>(a.gys + row * D + f0) = gyf[s];
             }
         }
-        if (ok && h == 0) {
+        if (ok && h == 0 && split == 0) {
             bf16x8 one = zero8();
             one[0] = (bf16_t)1.f;
             *reinterpret_cast<bf16x8 *>(a.xn_aug + row * (D + 8) + D) = one;
@@ -268,8 +325,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpArgs a) {
         for (int u = 0; u < OT; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) dx[u][i] = 0.f;
+        if constexpr (HS > 1) {
+            for (int i = threadIdx.x; i < OT * 32 * 32; i += 64 * HS) s_out[i] = 0.f;
+            __syncthreads();
+        }
 #pragma unroll 1
-        for (int t = 0; t < HT; ++t) {
+        for (int t = split; t < HT; t += HS) {
             const f32x16 hacc = hidden_tile<D, KS>(a.w1, t, r, h, xn);
             const f32x16 dacc = hidden_tile<D, KS>(a.w2t, t, r, h, gyf);   // dact^T = W2^T[32 t .., :] . (s gy)^T
             bf16x8 gp[2];
@@ -302,35 +363,51 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpArgs a) {
                     dx[u] = mfma_bf16(perm_frag(wr, 32 * t + 16 * s2 + 4 * h, f < D), gp[s2], dx[u]);
             }
         }
+        if constexpr (HS > 1) {
+            lds_accumulate<OT>(s_out, dx, r, h);
+            __syncthreads();
+        }
 #pragma unroll
         for (int u = 0; u < OT; ++u)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (HS > 1 && (4 * u + g) % HS != split) continue;
                 const int f0 = 32 * u + 8 * g + 4 * h;
-                if (ok && f0 < D)
-                    store_bf16x4(a.dxn + row * D + f0, dx[u][4 * g], dx[u][4 * g + 1], dx[u][4 * g + 2], dx[u][4 * g + 3]);
+                if (ok && f0 < D) {
+                    float acc[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = HS > 1 ? s_out[(f0 + c) * 32 + r] : dx[u][4 * g + c];
+                    store_bf16x4(a.dxn + row * D + f0, acc[0], acc[1], acc[2], acc[3]);
+                }
             }
+        if constexpr (HS > 1) __syncthreads();
     }
 }
 
-int grid_for(long rows) {
-    const long tiles = (rows + 127) / 128;
+int grid_for(long rows, int tiles_per_wg) {
+    const long tiles = ((rows + 31) / 32 + tiles_per_wg - 1) / tiles_per_wg;
     return (int)(tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048);
 }
 
-bool supported_d(int d) { return d == 8 || d == 16 || d == 32 || d == 64 || d == 128; }
+// d = 128 (1 024 rows at batch 4) is built but not offered: with 16 hidden tiles per row tile and 32 row tiles the kernel is a
+// chain of dependent weight-fragment loads (62 us forward against 30 us for the hipBLASLt path, tools/bench_mlp.py); it needs
+// the weights staged through LDS for the workgroup — until then the module path runs there.
+bool supported_d(int d) { return d == 8 || d == 16 || d == 32 || d == 64; }
 
-template <bool BWD>
+template <bool BWD, typename TX>
 int launch(const MlpArgs &a, int d, hipStream_t st) {
-    const dim3 grid(grid_for(a.rows)), block(256);
-    const double bytes = (double)a.rows * d * (BWD ? 4.0 * 2 + 2.0 * 3 + 2.0 * 8 + 64 : 8.0);
-#define VMASR_MLP_CASE(DD)                                                                                   \
-    case DD:                                                                                                 \
-        if (BWD) VMASR_LAUNCH(VMASR_K_MLP_BWD, bytes, mlp_bwd_kernel<DD>, grid, block, 0, st, a);            \
-        else VMASR_LAUNCH(VMASR_K_MLP_FWD, bytes, mlp_fwd_kernel<DD>, grid, block, 0, st, a);                \
-        break;
+    const double sx = sizeof(TX);
+    // bytes: forward x in + y out; backward x, gy in + dxn, xn, gys (2 B) + act, gpre (2 B x 4 d) out
+    const double bytes = (double)a.rows * d * (BWD ? 2 * sx + 2.0 * 3 + 2.0 * 8 : 2 * sx);
+    // waves per row tile: 1 while the rows alone fill the chip (d <= 32: >= 16 384 rows at batch 4), hidden-split below that
+#define VMASR_MLP_CASE(DD, HS)                                                                                          \
+    case DD: {                                                                                                          \
+        const dim3 grid(grid_for(a.rows, HS > 1 ? 1 : 4)), block(HS > 4 ? 64 * HS : 256);                              \
+        if (BWD) VMASR_LAUNCH(VMASR_K_MLP_BWD, bytes, (mlp_bwd_kernel<DD, TX, HS>), grid, block, 0, st, a);            \
+        else VMASR_LAUNCH(VMASR_K_MLP_FWD, bytes, (mlp_fwd_kernel<DD, TX, HS>), grid, block, 0, st, a);                \
+    } break;
     switch (d) {
-        VMASR_MLP_CASE(8) VMASR_MLP_CASE(16) VMASR_MLP_CASE(32) VMASR_MLP_CASE(64) VMASR_MLP_CASE(128)
+        VMASR_MLP_CASE(8, 1) VMASR_MLP_CASE(16, 1) VMASR_MLP_CASE(32, 1) VMASR_MLP_CASE(64, 4) VMASR_MLP_CASE(128, 8)
         default: set_error("mlp: unsupported width %d", d); return VMASR_EINVAL;
     }
 #undef VMASR_MLP_CASE
@@ -344,11 +421,12 @@ using namespace vmasr;
 
 VMASR_EXPORT int vmasr_mlp_supported(int32_t d, int32_t hidden) { return supported_d(d) && hidden == 4 * d; }
 
-VMASR_EXPORT int vmasr_mlp_fwd(const float *x, const float *gamma, const float *beta, float eps, const void *w1, const float *b1,
-                               const void *w2, const float *b2, const float *scale, int32_t rows_per_sample, float *y,
-                               int64_t rows, int32_t d, vmasr_stream_t stream) {
+VMASR_EXPORT int vmasr_mlp_fwd(const void *x, const float *gamma, const float *beta, float eps, const void *w1, const float *b1,
+                               const void *w2, const float *b2, const float *scale, int32_t rows_per_sample, void *y,
+                               int64_t rows, int32_t d, int32_t x_dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(x_dtype == VMASR_F32 || x_dtype == VMASR_BF16, VMASR_EINVAL, "mlp_fwd: x must be fp32 or bf16");
     VMASR_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && y, VMASR_EINVAL, "mlp_fwd: null tensor");
-    VMASR_REQUIRE(supported_d(d) && rows > 0, VMASR_EINVAL, "mlp_fwd: need d in {8,16,32,64,128} (got %d) and rows > 0", d);
+    VMASR_REQUIRE(supported_d(d) && rows > 0, VMASR_EINVAL, "mlp_fwd: need d in {8,16,32,64} (got %d) and rows > 0", d);
     VMASR_REQUIRE(!scale || rows_per_sample > 0, VMASR_EINVAL, "mlp_fwd: rows_per_sample must be positive with a scale vector");
     VMASR_REQUIRE(aligned_to(x, 16) && aligned_to(y, 16) && aligned_to(w1, 16) && aligned_to(w2, 16) && aligned_to(b1, 16) &&
                       aligned_to(b2, 16), VMASR_EINVAL, "mlp_fwd: tensors must be 16-byte aligned");
@@ -356,16 +434,18 @@ VMASR_EXPORT int vmasr_mlp_fwd(const float *x, const float *gamma, const float *
     a.x = x; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.w1 = static_cast<const bf16_t *>(w1); a.b1 = b1; a.w2 = static_cast<const bf16_t *>(w2); a.b2 = b2;
     a.scale = scale; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.y = y; a.rows = rows;
-    return launch<false>(a, d, static_cast<hipStream_t>(stream));
+    return x_dtype == VMASR_F32 ? launch<false, float>(a, d, static_cast<hipStream_t>(stream))
+                                : launch<false, bf16_t>(a, d, static_cast<hipStream_t>(stream));
 }
 
-VMASR_EXPORT int vmasr_mlp_bwd(const float *x, const float *gy, const float *gamma, const float *beta, float eps, const void *w1,
+VMASR_EXPORT int vmasr_mlp_bwd(const void *x, const void *gy, const float *gamma, const float *beta, float eps, const void *w1,
                                const void *w1t, const float *b1, const void *w2t, const float *scale, int32_t rows_per_sample,
                                void *dxn, void *xn_aug, void *gys, void *act_aug, void *gpre, float *mean, float *rstd,
-                               int64_t rows, int32_t d, vmasr_stream_t stream) {
+                               int64_t rows, int32_t d, int32_t x_dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(x_dtype == VMASR_F32 || x_dtype == VMASR_BF16, VMASR_EINVAL, "mlp_bwd: x / gy must be fp32 or bf16");
     VMASR_REQUIRE(x && gy && gamma && beta && w1 && w1t && b1 && w2t && dxn && xn_aug && gys && act_aug && gpre && mean && rstd,
                   VMASR_EINVAL, "mlp_bwd: null tensor");
-    VMASR_REQUIRE(supported_d(d) && rows > 0, VMASR_EINVAL, "mlp_bwd: need d in {8,16,32,64,128} (got %d) and rows > 0", d);
+    VMASR_REQUIRE(supported_d(d) && rows > 0, VMASR_EINVAL, "mlp_bwd: need d in {8,16,32,64} (got %d) and rows > 0", d);
     VMASR_REQUIRE(!scale || rows_per_sample > 0, VMASR_EINVAL, "mlp_bwd: rows_per_sample must be positive with a scale vector");
     VMASR_REQUIRE(aligned_to(x, 16) && aligned_to(gy, 16) && aligned_to(w1, 16) && aligned_to(w1t, 16) && aligned_to(w2t, 16) &&
                       aligned_to(b1, 16) && aligned_to(dxn, 16) && aligned_to(xn_aug, 16) && aligned_to(gys, 16) &&
@@ -377,5 +457,6 @@ VMASR_EXPORT int vmasr_mlp_bwd(const float *x, const float *gy, const float *gam
     a.scale = scale; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.rows = rows;
     a.dxn = static_cast<bf16_t *>(dxn); a.xn_aug = static_cast<bf16_t *>(xn_aug); a.gys = static_cast<bf16_t *>(gys);
     a.act_aug = static_cast<bf16_t *>(act_aug); a.gpre = static_cast<bf16_t *>(gpre); a.mean = mean; a.rstd = rstd;
-    return launch<true>(a, d, static_cast<hipStream_t>(stream));
+    return x_dtype == VMASR_F32 ? launch<true, float>(a, d, static_cast<hipStream_t>(stream))
+                                : launch<true, bf16_t>(a, d, static_cast<hipStream_t>(stream));
 }

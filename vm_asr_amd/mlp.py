@@ -3,8 +3,8 @@
     fused_mlp_residual(x, norm2, mlp, scale=None)  ==  x + scale * mlp(norm2(x))
 
 i.e. `x + self.drop_path(self.mlp(self.norm2(x)))` of VSSBlock._forward (model/vmamba.py:1832-1837; Mlp :483-509 with
-exact-erf GELU; timm DropPath as a per-sample scale) under bf16 autocast, for the fp32 residual stream x (..., d),
-d in {8, 16, 32, 64, 128}, hidden = 4 d.  Forward: ONE kernel (LayerNorm, fc1, bias, GELU, fc2, bias, residual; bf16
+exact-erf GELU; timm DropPath as a per-sample scale) under bf16 autocast, for the residual stream x (..., d) in fp32 or bf16,
+d in {8, 16, 32, 64}, hidden = 4 d.  Forward: ONE kernel (LayerNorm, fc1, bias, GELU, fc2, bias, residual; bf16
 MFMA 32x32x16, fp32 accumulation; the hidden activations never leave the register file).  Backward: one kernel that
 recomputes the forward and produces dxn plus the bf16 operands of the weight-gradient GEMMs, then LayerNorm's backward
 (with the residual gradient folded in) and two GEMMs whose ones-column carries the bias gradients.  No CPU fallback.
@@ -26,7 +26,7 @@ def _p(t):
 
 def supported(x, norm, mlp):
     """GPU, bf16 autocast, fp32 channel-last stream, plain Mlp (GELU exact, no dropout) of a supported width."""
-    if os.environ.get("VMASR_FUSED_MLP", "1") != "1" or not x.is_cuda or x.dtype != torch.float32:
+    if os.environ.get("VMASR_FUSED_MLP", "1") != "1" or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
         return False
     if not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
         return False
@@ -65,7 +65,7 @@ class _FusedMlpFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             y = torch.empty_like(x2)
             _lib.check(_lib.lib().vmasr_mlp_fwd(_p(x2), _p(g32), _p(be32), float(eps), _p(w1b), _p(b1f), _p(w2b), _p(b2f), _p(sc), rps,
-                                                _p(y), rows, d, _lib.current_stream(x.device)), "mlp_fwd")
+                                                _p(y), rows, d, _lib.torch_dtype_code(x2.dtype), _lib.current_stream(x.device)), "mlp_fwd")
         ctx.save_for_backward(x2, g32, be32, w1b, b1f, w2b, sc)
         ctx.meta = (x.shape, eps, rps, gamma.dtype, beta.dtype, w1.dtype, b1.dtype, w2.dtype, b2.dtype)
         return y.view(x.shape)
@@ -76,7 +76,7 @@ class _FusedMlpFn(torch.autograd.Function):
         shape, eps, rps, gdt, bedt, w1dt, b1dt, w2dt, b2dt = ctx.meta
         rows, d = x2.shape
         hd = w1b.shape[0]
-        gy2 = gy.reshape(rows, d).float()
+        gy2 = gy.reshape(rows, d).to(x2.dtype)
         if not gy2.is_contiguous():
             gy2 = gy2.contiguous()
         lib = _lib.lib()
@@ -92,13 +92,13 @@ class _FusedMlpFn(torch.autograd.Function):
             stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
             _lib.check(lib.vmasr_mlp_bwd(_p(x2), _p(gy2), _p(g32), _p(be32), float(eps), _p(w1b), _p(w1t), _p(b1f), _p(w2t), _p(sc), rps,
                                          _p(dxn), _p(xn_aug), _p(gys), _p(act_aug), _p(gpre), _p(stats[0]), _p(stats[1]), rows, d,
-                                         _lib.current_stream(dev)), "mlp_bwd")
+                                         _lib.torch_dtype_code(x2.dtype), _lib.current_stream(dev)), "mlp_bwd")
             # dx = gy + LayerNorm'(dxn); dgamma, dbeta  (one launch: csrc/ln.hip with the residual gradient folded in)
             dx = torch.empty_like(x2)
             dgb = torch.empty((2, d), dtype=torch.float32, device=dev)
             ws = torch.empty(lib.vmasr_layer_norm_bwd_workspace(rows, d) // 4, dtype=torch.float32, device=dev)
             _lib.check(lib.vmasr_layer_norm_bwd_res(_p(x2), _p(dxn), _p(g32), _p(stats[0]), _p(stats[1]), _p(gy2), _p(dx), _p(dgb[0]),
-                                                    _p(dgb[1]), _p(ws), rows, d, _lib.F32, _lib.BF16, _lib.current_stream(dev)),
+                                                    _p(dgb[1]), _p(ws), rows, d, _lib.torch_dtype_code(x2.dtype), _lib.BF16, _lib.current_stream(dev)),
                        "layer_norm_bwd_res")
         # [dW1 | db1 | 0] = gpre^T xn_aug,  [dW2 | db2 | 0] = gys^T act_aug  (fp32 accumulation, split over the rows when few tiles)
         g1 = weight_grad(gpre, xn_aug)
