@@ -18,9 +18,6 @@
 // (deterministic, no atomics).
 #include "common.h"
 
-#include <mutex>
-#include <vector>
-
 namespace vmasr {
 namespace {
 
@@ -105,29 +102,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T *__restrict__ x, co
     }
 }
 
-// dgamma / dbeta without a reduce launch: every workgroup adds its column sums into per-stream-slot accumulators with
-// device-scope float atomics and takes a ticket; the workgroup with the last ticket writes the totals out and resets
-// accumulators and ticket.  One slot per stream (launches on one stream never overlap; the host maps every stream it
-// sees to its own slot); everything is zero at load time and left zero by every launch — no zero-fill launch, nothing
-// to allocate (graph-capturable).  The order of the atomic adds varies from run to run: dgamma / dbeta are reproducible
-// to fp32 rounding, not bit for bit (as the reference's own atomics, cus/selective_scan_bwd_kernel.cuh:262-271).
-constexpr int kTicketSlots = 16;
-constexpr int kAccFloats = 4096;    // per slot: `copies` x (dgamma | dbeta); workgroup b adds into copy b % copies, copies = min(64, 4096 / 2C):
-                                    // same-address float atomics serialise at ~0.15 us each, so 1 024 workgroups on 8 copies cost 19 us
-__device__ unsigned int g_ln_ticket[kTicketSlots];
-__device__ float g_ln_acc[kTicketSlots][kAccFloats];     // dgamma | dbeta accumulators of the launch in flight on the slot's stream
-
-struct LnFinish {
-    float *dgamma, *dbeta;   // written by the last workgroup when slot >= 0
-    int slot;                // < 0: leave the per-workgroup partials to ln_bwd_reduce_kernel
-    const void *residual;    // optional (rows, C) of x's dtype added to dx (the gradient arriving over a residual connection)
-};
-
+// `residual`: optional (rows, C) tensor of x's dtype added to dx — the gradient that arrives over the residual connection
+// around a pre-norm branch (vm_asr_amd/mlp.py).
+// (dgamma / dbeta stay per-workgroup partials + ln_bwd_reduce_kernel.  Measured in round 3: folding the reduction into this
+//  kernel — "last workgroup sums the partials", or device-scope float atomics into per-stream accumulators with a ticket —
+//  is SLOWER than the 9 us reduce launch it removes: an agent-scope __threadfence() writes the L2 back (70 us per launch),
+//  and without it 1 024 workgroups' atomics serialise per cache line (20-36 us per launch against 10 + 9).)
 template <typename T, typename TG, int LPR, bool VEC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, const TG *__restrict__ gy,
                                                      const float *__restrict__ gamma, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, T *__restrict__ dx,
-                                                     float *__restrict__ part, const LnGeom g, const LnFinish fin) {
+                                                     float *__restrict__ part, const LnGeom g, const T *__restrict__ residual) {
     constexpr int RPB = 256 / LPR;
     __shared__ float s_acc[2][1024];  // reused per vector slot
     const int sub = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
@@ -170,9 +155,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
                     float o[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = rs * (gv[k][i] * gm[k][i] - s1 - v[k][i] * s2);
-                    if (fin.residual) {
+                    if (residual) {
                         float rv[4];
-                        load4<T, VEC>(static_cast<const T *>(fin.residual) + r * g.C, (k * LPR + sub) * 4, g.C, rv);
+                        load4<T, VEC>(residual + r * g.C, (k * LPR + sub) * 4, g.C, rv);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] += rv[i];
                     }
@@ -181,10 +166,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
         }
     }
     // column sums over the block's rows: lanes with equal `sub` own the same columns
-    if (part || fin.slot >= 0) {
-        float *pg = part ? part + (size_t)blockIdx.x * 2 * g.C : nullptr, *pb = part ? pg + g.C : nullptr;
-        const int copies = min(64, kAccFloats / (2 * g.C));
-        float *acc = fin.slot >= 0 ? g_ln_acc[fin.slot] + (blockIdx.x % copies) * 2 * g.C : nullptr;
+    if (part) {
+        float *pg = part + (size_t)blockIdx.x * 2 * g.C, *pb = pg + g.C;
 #pragma unroll
         for (int k = 0; k < kMaxVecPerLane; ++k) {
             if (k >= g.nvec) break;
@@ -204,41 +187,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T *__restrict__ x, co
                     bsum += s_acc[1][(rr * LPR + sb) * 4 + i];
                 }
                 const int c = (k * LPR + sb) * 4 + i;
-                if (c < g.C) {
-                    if (acc) {                       // device-scope float atomics into the slot's accumulators
-                        unsafeAtomicAdd(acc + c, a);           // global_atomic_add_f32 (atomicAdd(float*) is a CAS loop without
-                        unsafeAtomicAdd(acc + g.C + c, bsum);  //  -munsafe-fp-atomics)
-                    } else {
-                        pg[c] = a;
-                        pb[c] = bsum;
-                    }
-                }
-            }
-        }
-        if (acc) {
-            // the workgroup that takes the last ticket hands the totals over and leaves accumulators and ticket at zero
-            // for the next launch on this stream (release: fence + barrier before the ticket; the totals are read with
-            // atomic exchanges, i.e. at the L2 where the adds happened) — replaces a 9 us reduce launch per LayerNorm
-            // backward (65 per training step) and needs no zero-fill launch either
-            // No __threadfence(): at agent scope it writes the whole L2 back (70 us per launch, measured).  Everything the
-            // last workgroup reads was produced by device-scope ATOMICS, which execute at the coherence point; waiting for
-            // this wave's atomics to complete (vmcnt) before the barrier orders them ahead of the ticket.
-            __shared__ bool s_last;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const unsigned int t = atomicAdd(&g_ln_ticket[fin.slot], 1u);
-                s_last = t == gridDim.x - 1;
-            }
-            __syncthreads();
-            if (s_last) {
-                for (int c = threadIdx.x; c < 2 * g.C; c += 256) {
-                    float v = 0.f;
-                    for (int q = 0; q < copies; ++q) v += atomicExch(g_ln_acc[fin.slot] + q * 2 * g.C + c, 0.f);
-                    if (c < g.C) { if (fin.dgamma) fin.dgamma[c] = v; }
-                    else if (fin.dbeta) fin.dbeta[c - g.C] = v;
-                }
-                if (threadIdx.x == 0) g_ln_ticket[fin.slot] = 0;
+                if (c < g.C) { pg[c] = a; pb[c] = bsum; }
             }
         }
     }
@@ -261,17 +210,6 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
         if (dgamma) dgamma[c] = a;
         if (dbeta) dbeta[c] = b;
     }
-}
-
-// stream -> ticket slot (first come first served; a 65th concurrent stream would share slot 0 with the first)
-int ticket_slot(hipStream_t st) {
-    static std::mutex mu;
-    static std::vector<hipStream_t> seen;
-    std::lock_guard<std::mutex> lock(mu);
-    for (size_t i = 0; i < seen.size(); ++i)
-        if (seen[i] == st) return (int)(i % kTicketSlots);
-    seen.push_back(st);
-    return (int)((seen.size() - 1) % kTicketSlots);
 }
 
 int lpr_for(int C) {
@@ -297,7 +235,7 @@ int check(const void *x, int rows, int C, int dtype, const char *what) {
 
 template <typename T, typename TO, bool VEC, int KIND>  // KIND 0 fwd (TO = output type), 1 bwd (TO = grad type)
 int launch_lpr(int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, const void *gy, const float *gamma,
-               const float *beta, void *y, float *mean, float *rstd, float *part, const LnGeom g, const LnFinish fin) {
+               const float *beta, void *y, float *mean, float *rstd, float *part, const LnGeom g, const void *residual) {
 #define VMASR_LN_CASE(L)                                                                                              \
     case L:                                                                                                           \
         if (KIND == 0)                                                                                                \
@@ -305,7 +243,7 @@ int launch_lpr(int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, 
                          beta, (TO *)y, mean, rstd, g);                                                               \
         else                                                                                                          \
             VMASR_LAUNCH(VMASR_K_LN_BWD, bytes, (ln_bwd_kernel<T, TO, L, VEC>), grid, dim3(256), 0, st, (const T *)x,   \
-                         (const TO *)gy, gamma, mean, rstd, (T *)y, part, g, fin);                                    \
+                         (const TO *)gy, gamma, mean, rstd, (T *)y, part, g, (const T *)residual);                    \
         break;
     switch (lpr) {
         VMASR_LN_CASE(1) VMASR_LN_CASE(2) VMASR_LN_CASE(4) VMASR_LN_CASE(8) VMASR_LN_CASE(16) VMASR_LN_CASE(32)
@@ -319,10 +257,10 @@ int launch_lpr(int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, 
 template <int KIND>
 int dispatch(int dtype, int odt, bool vec, int lpr, dim3 grid, hipStream_t st, double bytes, const void *x, const void *gy,
              const float *gamma, const float *beta, void *y, float *mean, float *rstd, float *part, const LnGeom g,
-             const LnFinish fin = LnFinish{nullptr, nullptr, -1, nullptr}) {
+             const void *residual = nullptr) {
 #define VMASR_LN_T(TT, TO)                                                                                             \
-    (vec ? launch_lpr<TT, TO, true, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g, fin)       \
-         : launch_lpr<TT, TO, false, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g, fin))
+    (vec ? launch_lpr<TT, TO, true, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g, residual)  \
+         : launch_lpr<TT, TO, false, KIND>(lpr, grid, st, bytes, x, gy, gamma, beta, y, mean, rstd, part, g, residual))
     // (x dtype, y/gy dtype) pairs: equal, 16-bit x with fp32 y (what autocast gives F.layer_norm), and
     // fp32 x with 16-bit y (the fp32 residual stream normalised straight into a GEMM operand)
     if (dtype == VMASR_F32 && odt == VMASR_F32) return VMASR_LN_T(float, float);
@@ -386,14 +324,10 @@ VMASR_EXPORT int vmasr_layer_norm_bwd_res(const void *x, const void *gy, const f
     const double bytes = rows * (double)C * (2 * es + eg) + 8.0 * rows;
     const int nblk = grid_for(rows, lpr);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // few enough atomics (workgroups x 2 C): accumulate in place, the last workgroup finishes; otherwise (wide rows, many
-    // workgroups) per-workgroup partials + the column-parallel reduce kernel
-    const bool fused = affine && 2 * C <= kAccFloats / 2 && (size_t)nblk * 2 * C <= (1u << 17);
-    const LnFinish fin{dgamma, dbeta, fused ? ticket_slot(st) : -1, residual};
     if (int e = dispatch<1>(dtype, gy_dtype, vec, lpr, dim3(nblk), st, bytes, x, gy, gamma, nullptr, dx, const_cast<float *>(mean),
-                            const_cast<float *>(rstd), (affine && !fused) ? ws : nullptr, g, fin))
+                            const_cast<float *>(rstd), affine ? ws : nullptr, g, residual))
         return e;
-    if (affine && !fused)
+    if (affine)
         VMASR_LAUNCH(VMASR_K_LN_BWD_REDUCE, (double)nblk * 2 * C * 4, ln_bwd_reduce_kernel, dim3((C + 3) / 4), dim3(256), 0,
                      st, ws, nblk, C, dgamma, dbeta);
     return check_launch("layer_norm_bwd");
