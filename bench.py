@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 
@@ -43,6 +43,12 @@ def make_config(workload, batch):
         c.TRAIN.ADVERSARIAL.ENABLE = True
         c.TRAIN.ADVERSARIAL.DISCRIMINATORS = ["mpd"]
         c.DATA.BATCH_SIZE = 4
+    elif workload == "vm_asr_48k_16k_MPD_VSSM32":     # configs[4]: the yaml as written sets DIMS 32, batch 8
+        c.MODEL.VSSM.DIMS = 32
+        c.TRAIN.ADVERSARIAL.ENABLE = True
+        c.TRAIN.ADVERSARIAL.DISCRIMINATORS = ["mpd"]
+        c.TRAIN.ADVERSARIAL.STFT_LOSS.EMPHASIZE_HIGH_FREQ = False
+        c.DATA.BATCH_SIZE = 8
     elif workload == "vm_asr_48k":
         c.TRAIN.ADVERSARIAL.ENABLE = False
         c.TRAIN.ADVERSARIAL.DISCRIMINATORS = ["mpd"]
@@ -101,12 +107,125 @@ def cpu_baseline(config, budget_s=60.0):
                       f"in {dt:.1f} s: torch-CPU modules + oracle C kernels (OpenMP)"}
 
 
+def run_point(config, args, device, rank, world, steps, warmup, timing):
+    """Build the trainer for `config`, warm up, capture, time `steps` steps (barrier + synchronize on both sides, max over
+    ranks) and — `timing` — run the same steps once more eagerly with the library's HIP-event timer on.
+    -> (seconds for `steps` steps, graphed?, per-rank dict or None, {kernel: dict(launches, ms, alg_bytes)} or None)."""
+    from vm_asr_amd import _lib
+    trainer = build_trainer(config, device, amp=not args.no_amp, capturable=not args.no_graphs, amp_scope=args.amp_scope)
+    for m in trainer.models.values():
+        m.train()
+    torch.manual_seed(config.SEED + 1 + rank)  # per-rank DropPath streams
+    batch = synth_batch(config, device, rank)
+
+    graphed = False
+    if not args.no_graphs:
+        graphed = trainer.enable_graphs(batch, warmup=max(2, min(3, warmup)))
+        if not graphed:
+            # never report the host-bound eager step (2x slower) as if it were the product's number: fail loudly
+            print(json.dumps({"error": "HIP graph capture / replay self-test failed; rerun with --no-graphs to measure the eager step",
+                              "detail": getattr(trainer, "graph_error", None), "rank": rank}), flush=True)
+            sys.exit(3)
+    for _ in range(warmup):
+        trainer.train_step(*batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    trainer.time_reduces = world > 1
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.train_step(*batch)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own time to finish its K steps
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = None
+    if world > 1:
+        trainer.time_reduces = False
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        mine = torch.tensor([dt_own / steps * 1e3, trainer.reduce_exposed_ms() / steps], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(float(v[0]), 3) for v in allr],
+                    "allreduce_exposed_ms_per_step": [round(float(v[1]), 3) for v in allr],
+                    "note": "exposed = time the compute stream waits at the join of the two asynchronous gradient all-reduces "
+                            "(MPD 164 MB launched before the generator backward, generator 9 MB after it)"}
+
+    # per-kernel device time: HIP events recorded by the library around each of its launches, on the
+    # launch stream.  Events cannot be read inside a replayed graph, so this is a second pass of the
+    # same K steps, executed eagerly right after the timed region (rank 0's numbers are reported).
+    prof = None
+    if timing:
+        g_saved, trainer._graphed = trainer._graphed, None
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        for _ in range(steps):
+            trainer.train_step(*batch)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        trainer._graphed = g_saved
+        prof = _lib.prof_collect() if rank == 0 else {}
+    del trainer
+    torch.cuda.empty_cache()
+    return dt, graphed, per_rank, prof
+
+
+SCAN_KERNELS = ("ss2d_fwd_agg", "ss2d_fwd_apply", "ss2d_bwd_agg", "ss2d_bwd_apply", "ss2d_carry")
+SCAN_BYTES_IN = ("sscan_fwd", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_apply", "ss2d_fwd_apply", "ss2d_bwd_apply")
+
+
+def scan_summary(prof, steps):
+    """(kernel table, dominant scan kernel name, op-level dict) from the library's event records.
+    The selective-scan operator = sscan.hip's kernels (deep stages) + the scan kernels of the fused SS2D core (ss2d.hip:
+    aggregate / carry / apply; its transpose and pair-merge kernels are what is left of cross-scan / cross-merge and are
+    listed in the table, not counted here); algorithmic bytes are counted once per op (the apply / single-pass kernels carry them)."""
+    kern = {k: dict(v, avg_us=v["ms"] / v["launches"] * 1e3, gbs=v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)
+            for k, v in prof.items()}
+    scan = {k: v for k, v in kern.items() if k.startswith("sscan") or k in SCAN_KERNELS}
+    if not scan:
+        return kern, None, None
+    dom = max(scan, key=lambda k: scan[k]["ms"])
+    op_bytes = sum(v["alg_bytes"] for k, v in scan.items() if k in SCAN_BYTES_IN)
+    op_ms = sum(v["ms"] for v in scan.values())
+    op = {"achieved": op_bytes / (op_ms * 1e-3) / 1e9, "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          "ms_per_step": op_ms / steps, "alg_bytes_per_step": op_bytes / steps}
+    return kern, dom, op
+
+
+def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, steps=10):
+    """A second operating point measured in the same process after the headline (N = 1 only): compact record with its own
+    roofline block.  `mpd_gemm`: VMASR_MPD_GEMM for this point (read when the discriminator's layers are built into the graph)."""
+    saved = os.environ.get("VMASR_MPD_GEMM")
+    os.environ["VMASR_MPD_GEMM"] = mpd_gemm
+    try:
+        cfg = make_config(workload, batch)
+        dt, graphed, _, prof = run_point(cfg, args, device, rank, world, steps, 3, True)
+    finally:
+        os.environ["VMASR_MPD_GEMM"] = saved if saved is not None else "bf16x3"
+    B = cfg.DATA.BATCH_SIZE
+    rec = {"workload": f"{workload}.yaml, per-GPU batch {B}, DIMS {cfg.MODEL.VSSM.DIMS}, MPD GEMMs {mpd_gemm}", "value": B * steps / dt,
+           "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "execution": "HIP graph replay" if graphed else "eager"}
+    kern, dom, op = scan_summary(prof, steps)
+    if dom:
+        d = kern[dom]
+        rec["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": d["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d["avg_us"], "launches": d["launches"],
+                           "selective_scan_op": op}
+    mf = {k: v for k, v in kern.items() if k.startswith("mlp_")}
+    if mf:
+        rec["mlp_mfma_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2)} for k, v in mf.items()}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="vm_asr_48k_MPD", choices=["vm_asr_48k_MPD", "vm_asr_48k"])
+    ap.add_argument("--workload", default="vm_asr_48k_MPD", choices=["vm_asr_48k_MPD", "vm_asr_48k", "vm_asr_48k_16k_MPD_VSSM32"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the yaml's)")
     ap.add_argument("--no-amp", action="store_true")
     ap.add_argument("--amp-scope", default="generator", choices=["generator", "step"],
@@ -116,6 +235,7 @@ def main():
                     help="the fp32 discriminator's compute-bound GEMMs: 'bf16x3' = error-compensated triple bf16 MFMA products "
                          "(fp32 operands split into hi + lo bf16, fp32 accumulation; csrc/split.hip), 'fp32' = f32-input MFMA GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-points", action="store_true", help="skip the secondary operating points (fp32 MPD GEMMs; DIMS 32, batch 8)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     args = ap.parse_args()
@@ -133,61 +253,8 @@ def main():
     torch.cuda.set_device(device)
 
     config = make_config(args.workload, args.batch)
-    trainer = build_trainer(config, device, amp=not args.no_amp, capturable=not args.no_graphs, amp_scope=args.amp_scope)
-    for m in trainer.models.values():
-        m.train()
-    torch.manual_seed(config.SEED + 1 + rank)  # per-rank DropPath streams
-    batch = synth_batch(config, device, rank)
-
-    graphed = False
-    if not args.no_graphs:
-        graphed = trainer.enable_graphs(batch, warmup=max(2, min(3, args.warmup)))
-        if not graphed:
-            # never report the host-bound eager step (2x slower) as if it were the product's number: fail loudly
-            print(json.dumps({"error": "HIP graph capture / replay self-test failed; rerun with --no-graphs to measure the eager step",
-                              "detail": getattr(trainer, "graph_error", None), "rank": rank}), flush=True)
-            sys.exit(3)
-    for _ in range(args.warmup):
-        trainer.train_step(*batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    trainer.time_reduces = world > 1
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.train_step(*batch)
-    torch.cuda.synchronize()
-    dt_own = time.perf_counter() - t0          # this rank's own time to finish its K steps
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    per_rank = None
-    if world > 1:
-        trainer.time_reduces = False
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-        mine = torch.tensor([dt_own / args.steps * 1e3, trainer.reduce_exposed_ms() / args.steps], device=device, dtype=torch.float64)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = {"ms_per_step": [round(float(v[0]), 3) for v in allr],
-                    "allreduce_exposed_ms_per_step": [round(float(v[1]), 3) for v in allr],
-                    "note": "exposed = time the compute stream waits at the join of the two asynchronous gradient all-reduces "
-                            "(MPD 164 MB launched before the generator backward, generator 9 MB after it)"}
-
-    # per-kernel device time: HIP events recorded by the library around each of its launches, on the
-    # launch stream.  Events cannot be read inside a replayed graph, so this is a second pass of the
-    # same K steps, executed eagerly right after the timed region (rank 0's numbers are reported).
-    timing = not args.no_kernel_timing
-    if timing:
-        g_saved, trainer._graphed = trainer._graphed, None
-        _lib.prof_reset()
-        _lib.prof_enable(True)
-        for _ in range(args.steps):
-            trainer.train_step(*batch)
-        torch.cuda.synchronize()
-        _lib.prof_enable(False)
-        trainer._graphed = g_saved
+    dt, graphed, per_rank, prof = run_point(config, args, device, rank, world, args.steps, args.warmup, not args.no_kernel_timing)
+    timing = prof is not None
 
     B = config.DATA.BATCH_SIZE
     out = {
@@ -201,7 +268,7 @@ def main():
                   "bf16 autocast over generator, losses and discriminator (selective scan / STFT fp32)"), "data": "synthetic",
         "config": {"workload": f"{args.workload}.yaml full train step (G fwd+bwd, "
                                f"{'MR-STFT+LSGAN+feature losses, MPD fwd+bwd, ' if config.TRAIN.ADVERSARIAL.ENABLE else 'MR-STFT loss, '}"
-                               f"AdamW); DIMS 16, d_state 1, clip 122640 @48 kHz, n_fft 1024 hop 240",
+                               f"AdamW); DIMS {config.MODEL.VSSM.DIMS}, d_state {config.MODEL.VSSM.SSM_D_STATE}, clip 122640 @48 kHz, n_fft 1024 hop 240",
                    "per_gpu_batch": B, "global_batch": B * world,
                    "parallelism": f"dp{world} (clip-sharded; one RCCL all-reduce per flat gradient buffer)",
                    "execution": ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
@@ -210,33 +277,22 @@ def main():
     if per_rank is not None:
         out["per_rank"] = per_rank
     if rank == 0 and timing:
-        prof = _lib.prof_collect()
-        kern = {k: dict(v, avg_us=v["ms"] / v["launches"] * 1e3,
-                        gbs=v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0) for k, v in prof.items()}
-        # the selective-scan operator = sscan.hip's kernels (deep stages) + the scan kernels of the fused SS2D core
-        # (ss2d.hip: aggregate / carry / apply; its transpose and pair-merge kernels are what is left of cross-scan /
-        # cross-merge and are listed in `kernels`, not counted here)
-        scan = {k: v for k, v in kern.items() if k.startswith("sscan") or k in ("ss2d_fwd_agg", "ss2d_fwd_apply", "ss2d_bwd_agg",
-                                                                                "ss2d_bwd_apply", "ss2d_carry")}
-        if scan:
-            dom = max(scan, key=lambda k: scan[k]["ms"])
-            d = scan[dom]
-            # op-level: all scan kernels; algorithmic bytes counted once per op (apply/fwd/bwd kernels carry them)
-            op_bytes = sum(v["alg_bytes"] for k, v in scan.items() if k in ("sscan_fwd", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_apply",
-                                                                           "ss2d_fwd_apply", "ss2d_bwd_apply"))
-            op_ms = sum(v["ms"] for v in scan.values())
+        kern, dom, op = scan_summary(prof, args.steps)
+        if dom:
+            d = kern[dom]
             # HBM bytes per launch from the committed PMC passes of this same workload (rocprofv3 cannot
-            # run inside bench.py): profiles/r02_pmc_traffic.json, made by tools/pmc_bench_report.py
+            # run inside bench.py): profiles/<PMC_FILE>, made by tools/pmc_bench_report.py
             traffic = None
+            pmc_file = PMC_FILE if os.path.exists(os.path.join(ROOT, "profiles", PMC_FILE)) else "r02_pmc_traffic.json"
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
                 traffic = pmc[dom]["hbm_bytes_per_launch"] if B == 4 and args.workload == "vm_asr_48k_MPD" else None
             except Exception:
                 pass
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": d["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": f"profiles/{PMC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                   "FETCH_SIZE x2 per the gfx950 correction)" if traffic else None,
                 "bytes_definition": "SURVEY.md 8(d) algorithmic bytes of the selective-scan calls the launch performs (for the fused "
                                     "ss2d_* kernels: the reference contract's Delta/B/C/direction streams that never reach HBM here "
@@ -244,11 +300,21 @@ def main():
                 "avg_launch_us": d["avg_us"],
                 "timed_in": "eager pass of the same K steps right after the timed region (HIP events on the launch stream)",
                 "launches": d["launches"], "alg_bytes_per_launch": d["alg_bytes"] / d["launches"],
-                "selective_scan_op": {"achieved": op_bytes / (op_ms * 1e-3) / 1e9, "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      "ms_per_step": op_ms / args.steps, "alg_bytes_per_step": op_bytes / args.steps},
+                "selective_scan_op": op,
                 "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbs"], 1),
                                 "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in sorted(kern.items())},
             }
+    if rank == 0 and world == 1 and not args.no_extra_points and args.workload == "vm_asr_48k_MPD" and not args.batch and not args.no_graphs:
+        # driver-visible secondary operating points: the reference-precision discriminator GEMMs, and
+        # configs[4]'s yaml (DIMS 32, batch 8) with its own roofline block.  Never part of `value`.
+        pts = {}
+        for name, wl, bsz, gemm in (("mpd_gemm_fp32", "vm_asr_48k_MPD", 0, "fp32"),
+                                    ("vm_asr_48k_16k_MPD_VSSM32", "vm_asr_48k_16k_MPD_VSSM32", 0, args.mpd_gemm)):
+            try:
+                pts[name] = extra_point(name, wl, bsz, gemm, args, device, rank, world)
+            except Exception as e:   # informative only
+                pts[name] = {"error": f"{type(e).__name__}: {e}"}
+        out["operating_points"] = pts
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(config)

@@ -342,3 +342,79 @@ def test_fullsize_backward_hip_fp64_adjudicated():
     print(f"per-tensor ratio: median {float(np.median(list(ratio.values()))):.2f}, 95th percentile {p95:.2f}, max {ratio[worst[-1]]:.2f}")
     assert p95 <= 3.0, p95
     assert ratio[worst[-1]] <= 10.0, (worst[-1], ratio[worst[-1]], e_hip[worst[-1]], e_cpu[worst[-1]])
+
+
+@pytest.mark.gpu
+def test_fullsize_backward_dims32_hip_fp64_adjudicated():
+    """configs[4] (vm_asr_48k_16k_MPD_VSSM32.yaml: DIMS 32 -> d_inner 64 .. 512, dt_rank 2 .. 16, KD up to 2048) BACKWARD at full
+    size through the HIP path in fp32: every parameter gradient against the float64 evaluation (tests/f64ref.py on the GPU,
+    pinned to the reference's float64 run above) and, beside it, the CPU oracle's fp32 backward — the same relative claim as
+    test_fullsize_backward_hip_fp64_adjudicated makes for DIMS 16."""
+    import f64ref
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
+    (dims, n_fft, win, hop), wave, target, hf, y32, y64, lsd_ref = _case("d32")
+    assert dims == 32
+    gy = torch.randn(1, 1, wave.shape[-1], generator=torch.Generator().manual_seed(78))
+    m_gpu = _model(hop, dims, n_fft, win).to("cuda:0")
+    m64 = f64ref.model64(m_gpu)
+    with f64ref.Patch(f64ref.FAMILIES):
+        (m64(wave.double().cuda(), hf.cuda()) * gy.double().cuda()).sum().backward()
+    (m_gpu(wave.cuda(), hf.cuda()).float() * gy.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    m_cpu = use_oracle(_model(hop, dims, n_fft, win))
+    with oracle_stft_patch():
+        (m_cpu(wave, hf) * gy).sum().backward()
+    g64 = {n: p.grad for n, p in m64.named_parameters()}
+    got = {n: p.grad for n, p in m_gpu.named_parameters()}
+    ref = {n: p.grad for n, p in m_cpu.named_parameters()}
+    assert all((got[n] is None) == (g64[n] is None) == (ref[n] is None) for n in g64)
+    names = [n for n in g64 if g64[n] is not None]
+    assert all(torch.isfinite(got[n]).all() for n in names)
+    floor = 1e-5 * max(g64[n].norm().item() for n in names)
+    e_hip = {n: (got[n].double() - g64[n]).norm().item() for n in names}
+    e_cpu = {n: (ref[n].double().cuda() - g64[n]).norm().item() for n in names}
+    tot64 = sum(g64[n].pow(2).sum() for n in names).sqrt().item()
+    t_hip, t_cpu = (sum(v ** 2 for v in e.values()) ** 0.5 / tot64 for e in (e_hip, e_cpu))
+    ratio = sorted(e_hip[n] / (e_cpu[n] + floor) for n in names)
+    print(f"[d32] full-size backward vs float64: whole-vector rel L2  hip {t_hip:.2e}  cpu-oracle fp32 {t_cpu:.2e}; per-tensor ratio "
+          f"median {ratio[len(ratio) // 2]:.2f}, 95th percentile {ratio[int(0.95 * len(ratio))]:.2f}, max {ratio[-1]:.2f}")
+    assert t_hip <= 2.0 * t_cpu, (t_hip, t_cpu)
+    assert ratio[int(0.95 * len(ratio))] <= 3.0 and ratio[-1] <= 10.0, (ratio[int(0.95 * len(ratio))], ratio[-1])
+
+
+@pytest.mark.gpu
+def test_dstate32_nfft2048_model_forward_hip_vs_oracle():
+    """SURVEY.md 0.1 / BASELINE configs[4] as BASELINE.json words it ("d_state=32 n_fft=2048"): the reference's own override
+    `--opts MODEL.VSSM.SSM_D_STATE 32 DATA.STFT.N_FFT 2048` on vm_asr_48k_16k_MPD_VSSM32.yaml (DIMS 32) — the long-sequence
+    stress at MODEL level (L up to 524 288 with 32 states per row: the general-N scan path inside the real network), one
+    full-size clip, fp32: HIP forward against the CPU oracle's forward of the same module and against float64."""
+    import f64ref
+    import oracle
+    import vm_asr_amd
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
+    from synth import synth_state
+    from vm_asr_amd.config import get_config
+    cfg = get_config(opts=["MODEL.NAME", "DualStreamInteractiveMambaUNet", "MODEL.VSSM.DIMS", 32, "MODEL.VSSM.SSM_D_STATE", 32,
+                           "DATA.STFT.N_FFT", 2048, "DATA.TARGET_SR", 48000, "TRAIN.LOW_FREQ_REPLACEMENT", True])
+    assert cfg.DATA.STFT.HOP_LENGTH == 240 and cfg.DATA.STFT.WIN_LENGTH == 1024     # config.py:313-320, :55 (win stays 1024)
+    T = int(cfg.DATA.SEGMENT * cfg.DATA.TARGET_SR)
+    wave = 0.1 * torch.randn(1, 1, T, generator=torch.Generator().manual_seed(4242))
+    hf = torch.full((1,), int((2048 // 2 + 1) * 16000 / 48000), dtype=torch.int64)
+
+    def build():
+        torch.manual_seed(123)
+        return synth_state(vm_asr_amd.get_model(cfg)["generator"]).eval()
+    m = build().to("cuda:0")
+    assert any(mod.d_state == 32 for mod in m.modules() if hasattr(mod, "d_state"))
+    with torch.no_grad():
+        y = m(wave.cuda(), hf.cuda()).float().cpu().numpy()
+    y64 = f64ref.forward64(m, wave, hf)
+    with oracle_stft_patch(), torch.no_grad():
+        y_cpu = use_oracle(build())(wave, hf).float().numpy()
+    peak = np.abs(y64).max()
+    e, ec = np.abs(y - y64), np.abs(y_cpu - y64)
+    print(f"[d_state 32, n_fft 2048, dims 32] hip fp32: max {e.max() / peak:.2e} rms {_rms(e) / peak:.2e} | cpu-oracle fp32: max "
+          f"{ec.max() / peak:.2e} rms {_rms(ec) / peak:.2e} | hip vs cpu-oracle max {np.abs(y - y_cpu).max() / peak:.2e}")
+    assert y.shape == (1, 1, T) and np.isfinite(y).all()
+    assert e.max() <= K_MAX * ec.max() + 1e-4 * peak and _rms(e) <= K_RMS * _rms(ec) + 1e-5 * peak
+    assert e.max() <= 5e-3 * peak and _rms(e) <= 2e-4 * peak
