@@ -126,19 +126,24 @@ __device__ __forceinline__ float decay_f(float dl, float A) { return (float)exp(
 #elif defined(VMASR_FAST_DECAY)      // round 1-2 behaviour, for A/B measurements
 __device__ __forceinline__ float decay_f(float dl, float A) { return __builtin_amdgcn_exp2f(dl * (A * kLog2e)); }
 #else
-__device__ __forceinline__ float decay_f(float dl, float A) {
-    const float z = fmaxf(dl * A, -104.f);             // exp(-104) < the smallest denormal; also keeps n finite
-    const float n = __builtin_rintf(z * kLog2e);
-    float r = fmaf(n, -0.693145751953125f, z);          // ln 2 = hi + lo, hi exact in 12 bits: n * hi is exact
-    r = fmaf(n, -1.428606765330187e-06f, r);
-    float p = 0.0013933643931522965f;                   // near-minimax fit of (e^r - 1 - r) / r^2 on |r| <= ln2 / 2
+__device__ __forceinline__ float decay_poly(const float r) {   // e^r on |r| <= ln2 / 2: near-minimax fit of (e^r - 1 - r) / r^2
+    float p = 0.0013933643931522965f;
     p = fmaf(p, r, 0.008363175205886364f);
     p = fmaf(p, r, 0.04166646674275398f);
     p = fmaf(p, r, 0.16666576266288757f);
     p = fmaf(p, r, 0.5f);
     p = fmaf(p, r, 1.f);
-    p = fmaf(p, r, 1.f);
-    return ldexpf(p, (int)n);
+    return fmaf(p, r, 1.f);
+}
+__device__ __forceinline__ float decay_f(float dl, float A) {
+    const float z = fmaxf(dl * A, -104.f);             // exp(-104) < the smallest denormal; also keeps n finite
+    // wave-uniform fast path: with the model's delta = 1e-3 .. 1e-1 and A ~ -1 every lane has |z| < ln2 / 2, i.e. n = 0 —
+    // no range reduction, no ldexp (7 instead of 13 VALU instructions; the branch is scalar)
+    if (__builtin_amdgcn_ballot_w64(z < -0.34657359f) == 0) return decay_poly(z);
+    const float n = __builtin_rintf(z * kLog2e);
+    float r = fmaf(n, -0.693145751953125f, z);          // ln 2 = hi + lo, hi exact in 12 bits: n * hi is exact
+    r = fmaf(n, -1.428606765330187e-06f, r);
+    return ldexpf(decay_poly(r), (int)n);
 }
 #endif
 
