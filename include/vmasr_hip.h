@@ -239,6 +239,10 @@ int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_t H, int32_t 
  *                       the gradient of `y[i, :M_i]` views for all slots (reference: autograd's slice backward). */
 int vmasr_im2col_kx1_split_multi(const float *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, void *hi, void *lo,
                                  int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows_out, vmasr_stream_t stream);
+/* Same gather, written as ONE (n, rows_out, 3 k C) bf16 operand [hi | lo | hi]: the A side of the K-concatenated triple
+ * [hi | lo | hi] . [w_hi; w_hi; w_lo] (the three bf16 products of the fp32 GEMM accumulate inside one GEMM call). */
+int vmasr_im2col_kx1_split3_multi(const float *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, void *cat3, int32_t C,
+                                  int32_t k, int32_t stride, int32_t pad, int64_t rows_out, vmasr_stream_t stream);
 int vmasr_col2im_kx1_multi(const void *dcols, void *const *dxs, const int64_t *Ns, const int32_t *Hs, int32_t n, int32_t C,
                            int32_t k, int32_t stride, int32_t pad, int64_t rows, int32_t dtype, vmasr_stream_t stream);
 /* col2im_multi into ONE stacked destination dx (n, dx_rows, C): slot s = gradient of its N_s * H_s rows, zeros below (the

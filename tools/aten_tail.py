@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-cfg = bench.make_config("vm_asr_48k_MPD", 0)
+cfg = bench.make_config(os.environ.get("WORKLOAD", "vm_asr_48k_MPD"), int(os.environ.get("BATCH", "0")))
 dev = torch.device("cuda", 0)
 tr = bench.build_trainer(cfg, dev, amp=True, capturable=False)
 for m in tr.models.values():

@@ -78,6 +78,7 @@ SYMBOLS = {
     "vmasr_spectral_power_iter_batched": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i32, ctypes.c_float, c_vp, c_vp]),
     "vmasr_im2col_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_im2col_kx1_split": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "vmasr_im2col_kx1_split3_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "vmasr_col2im_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_im2col_kx1_split_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "vmasr_col2im_kx1_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),

@@ -126,8 +126,10 @@ struct SlotTable {
     long rows[kMaxSlots];        // stack_rows: valid rows of the slot
 };
 
+// cat3: ONE (n, rows, 3 K) operand [hi | lo | hi] (hi = the base pointer, lo unused) — the A side of the K-concatenated
+// product [hi | lo | hi] . [w_hi; w_hi; w_lo], which accumulates the three bf16 products of an fp32 GEMM inside one GEMM
 __global__ __launch_bounds__(256) void im2col_split_multi_kernel(const SlotTable t, bf16_t *__restrict__ hi,
-                                                                 bf16_t *__restrict__ lo, const ColGeom g0) {
+                                                                 bf16_t *__restrict__ lo, const ColGeom g0, const int cat3) {
     const int s = blockIdx.y;
     const float *__restrict__ x = static_cast<const float *>(t.src[s]);
     const int N = t.N[s], H = t.H[s], H1 = t.H1[s];
@@ -152,8 +154,16 @@ __global__ __launch_bounds__(256) void im2col_split_multi_kernel(const SlotTable
             Hh.b[q] = (bf16_t)e[q];
             L.b[q] = (bf16_t)(e[q] - (float)Hh.b[q]);
         }
-        oh[i] = Hh.raw;
-        ol[i] = L.raw;
+        if (cat3) {
+            const long kq = (long)g0.k * cv;                 // 8-byte units per row of one block
+            uint2 *__restrict__ o3 = reinterpret_cast<uint2 *>(hi) + ((size_t)s * g0.rows_out + i / kq) * 3 * kq + i % kq;
+            o3[0] = Hh.raw;
+            o3[kq] = L.raw;
+            o3[2 * kq] = Hh.raw;
+        } else {
+            oh[i] = Hh.raw;
+            ol[i] = L.raw;
+        }
     }
 }
 
@@ -301,9 +311,25 @@ VMASR_EXPORT int vmasr_col2im_kx1(const void *dcols, void *dx, int64_t N, int32_
     return run(false, dcols, dx, N, H, C, k, stride, pad, 0, dtype, static_cast<hipStream_t>(stream));
 }
 
+static int im2col_split_multi_impl(const float *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, void *hi,
+                                   void *lo, int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows_out, int cat3,
+                                   vmasr_stream_t stream);
+
 VMASR_EXPORT int vmasr_im2col_kx1_split_multi(const float *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, void *hi,
                                               void *lo, int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows_out,
                                               vmasr_stream_t stream) {
+    return im2col_split_multi_impl(xs, Ns, Hs, n, hi, lo, C, k, stride, pad, rows_out, 0, stream);
+}
+
+VMASR_EXPORT int vmasr_im2col_kx1_split3_multi(const float *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, void *cat3,
+                                               int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows_out,
+                                               vmasr_stream_t stream) {
+    return im2col_split_multi_impl(xs, Ns, Hs, n, cat3, cat3, C, k, stride, pad, rows_out, 1, stream);
+}
+
+static int im2col_split_multi_impl(const float *const *xs, const int64_t *Ns, const int32_t *Hs, int32_t n, void *hi,
+                                   void *lo, int32_t C, int32_t k, int32_t stride, int32_t pad, int64_t rows_out, int cat3,
+                                   vmasr_stream_t stream) {
     VMASR_REQUIRE(xs && Ns && Hs && hi && lo, VMASR_EINVAL, "im2col_kx1_split_multi: null argument");
     VMASR_REQUIRE(n > 0 && n <= kMaxSlots, VMASR_EINVAL, "im2col_kx1_split_multi: 1..%d slots (got %d)", kMaxSlots, n);
     VMASR_REQUIRE(C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && rows_out > 0, VMASR_EINVAL,
@@ -322,14 +348,14 @@ VMASR_EXPORT int vmasr_im2col_kx1_split_multi(const float *const *xs, const int6
         t.N[s] = (int)Ns[s];
         t.H[s] = Hs[s];
         t.H1[s] = H1;
-        bytes += (double)Ns[s] * Hs[s] * C * 4 + (double)rows_out * k * C * 4;
+        bytes += (double)Ns[s] * Hs[s] * C * 4 + (double)rows_out * k * C * (cat3 ? 6 : 4);
     }
     const ColGeom g{0, 0, C, k, stride, pad, 0, (long)rows_out};
     const long total = (long)rows_out * k * (C / 4);
     const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
     hipStream_t st = static_cast<hipStream_t>(stream);
     VMASR_LAUNCH(VMASR_K_IM2COL, bytes, im2col_split_multi_kernel, dim3(blocks, n), dim3(256), 0, st, t, static_cast<bf16_t *>(hi),
-                 static_cast<bf16_t *>(lo), g);
+                 static_cast<bf16_t *>(lo), g, cat3);
     return check_launch("im2col_kx1_split_multi");
 }
 

@@ -667,24 +667,44 @@ class _StackedConvSplitFn(torch.autograd.Function):
             n, K = len(xs), k * C
             xcs = [x.float().contiguous() for x in xs]
             ptrs, Ns, Hs = _slot_arrays([x.data_ptr() for x in xcs], [x.shape[0] * x.shape[1] for x in xcs], [x.shape[2] for x in xcs])
+        w = weight.detach().float().contiguous()
+        N = w.shape[1]
+        fused = act and N % 4 == 0 and N <= 1024
+        kcat = fused and os.environ.get("VMASR_MPD_KCAT", "0") == "1"
         with torch.cuda.device(dev):
-            ch = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
-            cl = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
-            _lib.check(lib.vmasr_im2col_kx1_split_multi(ptrs, Ns, Hs, n, ch.data_ptr(), cl.data_ptr(), C, k, stride, pad, rows,
-                                                        _lib.current_stream(dev)), "im2col_kx1_split_multi")
+            if kcat:
+                # (opt-in, VMASR_MPD_KCAT=1 — measured SLOWER in round 3: 38.8 vs 38.0 ms per step.  The epilogue gains 0.36 ms
+                #  (one partial product to read instead of three), but im2col writes a third operand block (+0.25 ms) and
+                #  hipBLASLt's kernels for K' = 3K with M = 4.7k .. 36k are slower than three K-sized products (+0.9 ms).)
+                # ONE operand [hi | lo | hi] (n, rows, 3K): the forward triple as a single GEMM over the concatenated contraction;
+                # hi / lo stay addressable as column blocks (ld = 3K) for the weight-gradient GEMMs
+                acat = torch.empty((n, rows, 3 * K), dtype=torch.bfloat16, device=dev)
+                _lib.check(lib.vmasr_im2col_kx1_split3_multi(ptrs, Ns, Hs, n, acat.data_ptr(), C, k, stride, pad, rows,
+                                                             _lib.current_stream(dev)), "im2col_kx1_split3_multi")
+                ch, cl = acat[:, :, :K], acat[:, :, K:2 * K]
+            else:
+                ch = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
+                cl = torch.empty((n, rows, K), dtype=torch.bfloat16, device=dev)
+                _lib.check(lib.vmasr_im2col_kx1_split_multi(ptrs, Ns, Hs, n, ch.data_ptr(), cl.data_ptr(), C, k, stride, pad, rows,
+                                                            _lib.current_stream(dev)), "im2col_kx1_split_multi")
         # weights: one pass to the (n, K, 3N) bf16 operand [hi^T | hi^T | lo^T] (csrc/split.hip): column blocks 0 and 2 are
         # the forward B operands; all of it, transposed, is the [wh; wh; wl] operand of the column-gradient GEMM
         # (kept as the transpose of a contiguous tensor: hipBLASLt's kernels for that layout are ~9 % faster here)
-        w = weight.detach().float().contiguous()
-        N = w.shape[1]
         with torch.cuda.device(dev):
             wcat = torch.empty((n, K, 3 * N), dtype=torch.bfloat16, device=dev)
             _lib.check(lib.vmasr_weight_prep_split(w.data_ptr(), wcat.data_ptr(), n, N, K, _lib.current_stream(dev)), "weight_prep_split")
         wth, wtl = wcat[:, :, :N], wcat[:, :, 2 * N:]
         b32 = bias.detach().float().contiguous()
-        fused = act and N % 4 == 0 and N <= 1024
         pre = None
-        if fused:
+        if kcat:
+            f32 = torch.float32
+            with torch.cuda.device(dev):
+                wk = torch.cat((wth, wth, wtl), dim=1)                       # (n, 3K, N) = [w_hi^T; w_hi^T; w_lo^T]
+                pre = torch.bmm(acat, wk, out_dtype=f32)
+                y = torch.empty_like(pre)
+                _lib.check(lib.vmasr_bias_gelu_fwd(pre.data_ptr(), b32.data_ptr(), y.data_ptr(), n, rows, N, 1,
+                                                   _lib.current_stream(dev)), "bias_gelu_fwd")
+        elif fused:
             # the three products side by side; the epilogue sums them, adds the bias (-> pre, in place in part 0) and applies GELU
             f32 = torch.float32
             with torch.cuda.device(dev):
