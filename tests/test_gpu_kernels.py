@@ -424,7 +424,9 @@ def test_small_linear_vs_torch(io):
 @pytest.mark.parametrize("cfg", [(2, 2, 1, 1, 4096), (2, 32, 1, 1, 1024), (1, 256, 1, 8, 256), (2, 16, 4, 2, 300),
                                  (1, 128, 1, 4, 1023),
                                  # row-parallel kernels of the deep stages (d_inner >= 64, L % 4 == 0): full / ragged tiles, odd D
-                                 (2, 64, 1, 2, 4096), (3, 128, 1, 4, 1000), (1, 100, 2, 3, 200), (2, 64, 1, 2, 16384)], ids=str)
+                                 (2, 64, 1, 2, 4096), (3, 128, 1, 4, 1000), (1, 100, 2, 3, 200), (2, 64, 1, 2, 16384),
+                                 # matrix-core kernels (d_state 1, D % 32 == 0, L % 32 == 0, even dt_rank): the deep-stage call shapes
+                                 (4, 128, 1, 4, 1024), (8, 256, 1, 8, 256), (1, 512, 1, 8, 96)], ids=str)
 def test_xproj_vs_einsum(cfg):
     from vm_asr_amd.xproj import x_proj_dt
     Bn, D, N, R, L = cfg

@@ -590,10 +590,7 @@ def test_graph_replay_on_new_batches_matches_eager_training():
             m.train()
         tr.train_step(*batches[0])
         if mode == "graph":
-            assert tr.enable_graphs(batches[0], warmup=2)
-        else:
-            for _ in range(2):
-                tr.train_step(*batches[0])                  # the eager warm-up steps graph capture runs
+            assert tr.enable_graphs(batches[0], warmup=2)   # its warm-up steps are undone: same state as the eager trainer
         out = []
         for b in batches[1:]:
             _, lg = tr.train_step(*b)
@@ -627,10 +624,7 @@ def test_fullsize_graph_replay_matches_eager_on_new_batches():
             m.train()
         tr.train_step(*batches[0])
         if mode == "graph":
-            assert tr.enable_graphs(batches[0], warmup=2)
-        else:
-            for _ in range(2):
-                tr.train_step(*batches[0])
+            assert tr.enable_graphs(batches[0], warmup=2)   # (warm-up undone afterwards)
         out = []
         for b in batches[1:]:
             _, lg = tr.train_step(*b)

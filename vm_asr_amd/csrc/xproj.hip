@@ -20,6 +20,8 @@
 // fp32 accumulation and fp32 weights; xs may be fp32 or 16-bit.  c <= 16 (d_state <= 4 at R <= 8).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace vmasr {
 namespace {
 
@@ -301,6 +303,128 @@ __global__ __launch_bounds__(256) void xproj_bwd_a_dpar_kernel(const float *__re
     }
 }
 
+// ---- deep stages on the matrix cores (d_state 1, d_inner a multiple of 32, L a multiple of 32) -----------------------
+// Both projections are skinny GEMMs over the rows of one direction: x_dbl (C x L) = Wx[k] (C x D) . xs (D x L) and
+// dts (D x L) = Wdt[k] (D x R) . x_dbl[:R].  The row-parallel kernels above need the whole Wx / Wdt in LDS per workgroup,
+// two barriers and run one workgroup per CU (22-27 us per call on <= 4 MB).  Here a WAVE owns 32 positions and nothing is
+// shared: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation — the numerics of the FMA kernels) with the
+// contraction index on the two lane halves, so every operand is ONE element per lane in its natural layout: A = a weight
+// row element, B = xs[d + (lane >> 5)][pos + (lane & 31)] (two coalesced 128-byte rows per instruction).  The C x 32
+// result comes back with the position on the lane; one exchange between the lane halves gives every lane all C rows of its
+// position, which are at once the B operand of the second product (k = dt component on the lane half).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NMAX>
+__device__ __forceinline__ void rows_to_lanes(const f32x16 &acc, const int n, const int half, float (&v)[NMAX]) {
+    // accumulator row c lives in lane half (c >> 2) & 1, register (c & 3) + 4 (c >> 3)
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c)
+        if (c < n) {
+            const float mine = acc[(c & 3) + 4 * (c >> 3)];
+            const float other = __shfl_xor(mine, 32, 64);
+            v[c] = (half == ((c >> 2) & 1)) ? mine : other;
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xproj_fwd_mfma_kernel(const T *__restrict__ xs, const float *__restrict__ Wx,
+                                                             const float *__restrict__ Wdt, float *__restrict__ dts,
+                                                             float *__restrict__ Bs, float *__restrict__ Cs,
+                                                             float *__restrict__ dtr, const XpGeom g) {
+    const int C = g.R + 2;
+    const int lane = threadIdx.x & 63, j = lane & 31, kq = lane >> 5;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int pos = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + j;
+    if (pos - j >= g.L) return;                                     // wave-uniform (L is a multiple of 32)
+    const size_t bk = (size_t)b * g.K + k;
+    const T *xp = xs + bk * g.D * g.L + pos;
+    const float *wx = Wx + (size_t)k * C * g.D + (j < C ? j : 0) * g.D;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 4
+    for (int d0 = 0; d0 < g.D; d0 += 2) {
+        const float a = j < C ? wx[d0 + kq] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, to_f32(xp[(size_t)(d0 + kq) * g.L]), acc, 0, 0, 0);
+    }
+    float xd[kMaxC];
+    rows_to_lanes<kMaxC>(acc, C, kq, xd);
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+        if (c < C && (c & 1) == kq) {   // the two halves hold the same values: each stores every other row
+            float *dst = c < g.R ? dtr + (bk * g.R + c) * g.L : (c == g.R ? Bs + bk * g.L : Cs + bk * g.L);
+            dst[pos] = xd[c];
+        }
+    // dts = Wdt[k] . x_dbl[:R]: 32 rows of D per product, dt component on the lane half
+    const float *wd = Wdt + (size_t)k * g.D * g.R;
+    float *dp = dts + bk * g.D * g.L + pos;
+    for (int dt = 0; dt < g.D; dt += 32) {
+        f32x16 o;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int q0 = 0; q0 < kMaxR; q0 += 2)
+            if (q0 < g.R) {
+                const float a = q0 + kq < g.R ? wd[(size_t)(dt + j) * g.R + q0 + kq] : 0.f;
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kq ? xd[q0 + 1 < kMaxC ? q0 + 1 : q0] : xd[q0], o, 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dp[(size_t)(dt + (i & 3) + 8 * (i >> 2) + 4 * kq) * g.L] = o[i];
+    }
+}
+
+// backward of the two projections wrt their input: d(x_dbl)[:R] = Wdt[k]^T . ddts, rows R, R+1 = dBs, dCs;
+// dxs = Wx[k]^T . d(x_dbl) (+ du); d(x_dbl) is kept (ws) for the weight-gradient kernel
+template <typename T>
+__global__ __launch_bounds__(256) void xproj_bwd_a_mfma_kernel(const float *__restrict__ ddts, const float *__restrict__ dBs,
+                                                               const float *__restrict__ dCs, const float *__restrict__ du,
+                                                               const float *__restrict__ Wx, const float *__restrict__ Wdt,
+                                                               T *__restrict__ dxs, float *__restrict__ dxdbl, const XpGeom g) {
+    const int C = g.R + 2;
+    const int lane = threadIdx.x & 63, j = lane & 31, kq = lane >> 5;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int pos = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + j;
+    if (pos - j >= g.L) return;
+    const size_t bk = (size_t)b * g.K + k, row0 = bk * g.D;
+    const float *gp = ddts + row0 * g.L + pos;
+    const float *wd = Wdt + (size_t)k * g.D * g.R + (j < g.R ? j : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 4
+    for (int d0 = 0; d0 < g.D; d0 += 2) {
+        const float a = j < g.R ? wd[(size_t)(d0 + kq) * g.R] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gp[(size_t)(d0 + kq) * g.L], acc, 0, 0, 0);
+    }
+    float gd[kMaxC];
+    rows_to_lanes<kMaxC>(acc, g.R, kq, gd);
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) {
+        if (c == g.R) gd[c] = dBs[bk * g.L + pos];
+        if (c == g.R + 1) gd[c] = dCs[bk * g.L + pos];
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+        if (c < C && (c & 1) == kq) dxdbl[(bk * C + c) * g.L + pos] = gd[c];
+    const float *wx = Wx + (size_t)k * C * g.D;
+    for (int dt = 0; dt < g.D; dt += 32) {
+        f32x16 o;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int c0 = 0; c0 < kMaxC; c0 += 2)
+            if (c0 < C) {
+                const float a = c0 + kq < C ? wx[(size_t)(c0 + kq) * g.D + dt + j] : 0.f;
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kq ? gd[c0 + 1 < kMaxC ? c0 + 1 : c0] : gd[c0], o, 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const size_t off = (row0 + dt + (i & 3) + 8 * (i >> 2) + 4 * kq) * g.L + pos;
+            dxs[off] = from_f32<T>(o[i] + (du ? du[off] : 0.f));
+        }
+    }
+}
+
 // one wave per (k, 4 rows d, 4096-position chunk of one batch element): partial dWx[k, c, d] and
 // dWdt[k, d, r] -> float atomics (a few hundred adds per address at most; outputs zero-initialised)
 constexpr int kXpChunk = 4096;   // positions per wave; 1024 when that leaves the chip under-filled (deep stages)
@@ -377,6 +501,12 @@ __global__ __launch_bounds__(256) void xproj_bwd_b_kernel(const T *__restrict__ 
     }
 }
 
+// the MFMA kernels: d_state 1, whole 32-row / 32-position tiles, even dt_rank (the contraction runs two at a time)
+bool mfma_ok(const XpGeom &g, bool vec) {
+    static const bool on = [] { const char *e = getenv("VMASR_XPROJ_MFMA"); return !(e && e[0] == '0'); }();
+    return on && vec && g.N == 1 && g.D >= 64 && g.D % 32 == 0 && g.L % 32 == 0 && g.R % 2 == 0 && g.R + 2 <= kMaxC;
+}
+
 int check(const XpGeom &g, int dtype, const char *what) {
     VMASR_REQUIRE(g.B > 0 && g.K > 0 && g.D > 0 && g.N > 0 && g.R > 0 && g.L > 0, VMASR_EINVAL, "%s: non-positive size", what);
     VMASR_REQUIRE(g.R <= kMaxR && g.R + 2 * g.N <= kMaxC, VMASR_EINVAL, "%s: need dt_rank <= %d and dt_rank + 2*d_state <= %d",
@@ -412,6 +542,15 @@ VMASR_EXPORT int vmasr_xproj_fwd(const void *xs, const float *Wx, const float *W
     const double es = dtype == VMASR_F32 ? 4 : 2;
     const double bytes = (double)B * K * L * (D * (es + 4.0) + (C + 0.0) * 4.0);
     const size_t smd = sm + (size_t)C * 4 * kDpTL * sizeof(float);
+    if (mfma_ok(g, vec)) {                             // deep stages on the matrix cores (xproj_fwd_mfma_kernel)
+        const dim3 gm((L / 32 + 3) / 4, K, B);
+#define VMASR_XPM(TT) VMASR_LAUNCH(VMASR_K_XPROJ_FWD, bytes, (xproj_fwd_mfma_kernel<TT>), gm, dim3(256), 0, st, (const TT *)xs, Wx, Wdt, dts, Bs, Cs, dtr, g)
+        if (dtype == VMASR_F32) VMASR_XPM(float);
+        else if (dtype == VMASR_F16) VMASR_XPM(f16_t);
+        else VMASR_XPM(bf16_t);
+#undef VMASR_XPM
+        return check_launch("xproj_fwd");
+    }
     if (vec && D >= kDparMinD && smd <= 64 * 1024) {   // deep stages: row-parallel workgroups (see xproj_fwd_dpar_kernel)
         const dim3 gd((L + kDpTL - 1) / kDpTL, K, B);
 #define VMASR_XPD(TT) VMASR_LAUNCH(VMASR_K_XPROJ_FWD, bytes, (xproj_fwd_dpar_kernel<TT>), gd, dim3(256), smd, st, (const TT *)xs, Wx, Wdt, dts, Bs, Cs, dtr, g)
@@ -455,7 +594,9 @@ VMASR_EXPORT int vmasr_xproj_bwd(const void *xs, const float *Wx, const float *W
     const int chunk = ((long)((nwaves + 3) / 4) * ((L + kXpChunk - 1) / kXpChunk) * B < 1024 && L > 1024) ? 1024 : kXpChunk;
 #define VMASR_XPB(TT, V)                                                                                                 \
     do {                                                                                                                 \
-        if (dpar) VMASR_LAUNCH(VMASR_K_XPROJ_BWD_A, bytes_a, (xproj_bwd_a_dpar_kernel<TT>), gd, dim3(256), smd, st, ddts, dBs, dCs, du, \
+        if (mfma_ok(g, vec)) VMASR_LAUNCH(VMASR_K_XPROJ_BWD_A, bytes_a, (xproj_bwd_a_mfma_kernel<TT>), dim3((L / 32 + 3) / 4, K, B), \
+                                          dim3(256), 0, st, ddts, dBs, dCs, du, Wx, Wdt, (TT *)dxs, ws, g);               \
+        else if (dpar) VMASR_LAUNCH(VMASR_K_XPROJ_BWD_A, bytes_a, (xproj_bwd_a_dpar_kernel<TT>), gd, dim3(256), smd, st, ddts, dBs, dCs, du, \
                                Wx, Wdt, (TT *)dxs, ws, g);                                                               \
         else VMASR_LAUNCH(VMASR_K_XPROJ_BWD_A, bytes_a, (xproj_bwd_a_kernel<TT, V>), grid, dim3(256), sm, st, ddts, dBs, dCs, du, \
                           Wx, Wdt, (TT *)dxs, ws, g);                                                                    \
