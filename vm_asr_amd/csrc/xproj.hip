@@ -339,14 +339,26 @@ __global__ __launch_bounds__(256) void xproj_fwd_mfma_kernel(const T *__restrict
     const size_t bk = (size_t)b * g.K + k;
     const T *xp = xs + bk * g.D * g.L + pos;
     const float *wx = Wx + (size_t)k * C * g.D + (j < C ? j : 0) * g.D;
-    f32x16 acc;
+    f32x16 acc, acc1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 4
-    for (int d0 = 0; d0 < g.D; d0 += 2) {
-        const float a = j < C ? wx[d0 + kq] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, to_f32(xp[(size_t)(d0 + kq) * g.L]), acc, 0, 0, 0);
+    for (int i = 0; i < 16; ++i) acc[i] = acc1[i] = 0.f;
+    // 32 rows of D per step: all 32 operand loads in flight before the first product; two accumulators halve the
+    // dependent-MFMA chain (64 cycles per f32 32x32x2)
+    for (int d0 = 0; d0 < g.D; d0 += 32) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            av[t] = j < C ? wx[d0 + 2 * t + kq] : 0.f;
+            bv[t] = to_f32(xp[(size_t)(d0 + 2 * t + kq) * g.L]);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t + 1], bv[t + 1], acc1, 0, 0, 0);
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
     float xd[kMaxC];
     rows_to_lanes<kMaxC>(acc, C, kq, xd);
 #pragma unroll
@@ -388,14 +400,24 @@ __global__ __launch_bounds__(256) void xproj_bwd_a_mfma_kernel(const float *__re
     const size_t bk = (size_t)b * g.K + k, row0 = bk * g.D;
     const float *gp = ddts + row0 * g.L + pos;
     const float *wd = Wdt + (size_t)k * g.D * g.R + (j < g.R ? j : 0);
-    f32x16 acc;
+    f32x16 acc, acc1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 4
-    for (int d0 = 0; d0 < g.D; d0 += 2) {
-        const float a = j < g.R ? wd[(size_t)(d0 + kq) * g.R] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gp[(size_t)(d0 + kq) * g.L], acc, 0, 0, 0);
+    for (int i = 0; i < 16; ++i) acc[i] = acc1[i] = 0.f;
+    for (int d0 = 0; d0 < g.D; d0 += 32) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            av[t] = j < g.R ? wd[(size_t)(d0 + 2 * t + kq) * g.R] : 0.f;
+            bv[t] = gp[(size_t)(d0 + 2 * t + kq) * g.L];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t + 1], bv[t + 1], acc1, 0, 0, 0);
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
     float gd[kMaxC];
     rows_to_lanes<kMaxC>(acc, g.R, kq, gd);
 #pragma unroll
@@ -503,7 +525,7 @@ __global__ __launch_bounds__(256) void xproj_bwd_b_kernel(const T *__restrict__ 
 
 // the MFMA kernels: d_state 1, whole 32-row / 32-position tiles, even dt_rank (the contraction runs two at a time)
 bool mfma_ok(const XpGeom &g, bool vec) {
-    static const bool on = [] { const char *e = getenv("VMASR_XPROJ_MFMA"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char *e = getenv("VMASR_XPROJ_MFMA"); return e && e[0] == '1'; }();   // opt-in: measured slower
     return on && vec && g.N == 1 && g.D >= 64 && g.D % 32 == 0 && g.L % 32 == 0 && g.R % 2 == 0 && g.R + 2 <= kMaxC;
 }
 
