@@ -345,8 +345,11 @@ int vmasr_masked_l1_bwd(const void *sgn, const float *gout, float *dgen, const i
  *   out02, out13 (B,D,H*W) fp32 scratch;  y (B,D,H*W) fp32 = the merged output.
  * backward: dy (B,D,H*W) fp32 in, dyT / adj (like state) / part (vmasr_ss2d_part_floats) scratch,
  *   dx (B,D,H,W) `dtype`, dWx (4,3,D), dWdt (4,D), ddtb (4,D), dAlog (4D), dDs (4D) fp32 out (plain stores). */
+#define VMASR_SS2D_PAIRS 1   /* flags: forward leaves the two pair outputs out02 (h,w order) / out13 (w,h order) to the caller
+                              * (no merge launch, y unused); backward takes dy AND dyT as inputs (no transpose launch) —
+                              * for a consumer / producer that handles both orders itself (vmasr_ln_gate_pair_*) */
 typedef struct vmasr_ss2d_params {
-    int32_t B, D, H, W, dtype;
+    int32_t B, D, H, W, dtype, flags;
     const void *x;
     void *xT;
     const float *Wx, *Wdt, *dtb, *Alog, *Ds;
@@ -377,6 +380,18 @@ int vmasr_ln_gate_fwd(const float *y, const void *sz, const float *gamma, const 
 int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta, const float *mean,
                       const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta, int32_t B, int32_t D, int32_t L,
                       int32_t dtype, vmasr_stream_t stream);
+/* ln_gate on the two PAIR outputs of the fused core: y = y02 (B, D, H*W in (h,w) order) + transpose(y13 (B, D, W*H in (w,h)
+ * order)) is formed on the fly — what is left of CrossMerge (model/vmamba.py:50-73) never becomes a tensor; the backward
+ * writes the gradient in both orders (dy02, dy13: the inputs of vmasr_ss2d_bwd with VMASR_SS2D_PAIRS).  D in {2,4,8,16,32},
+ * H and W multiples of 16 (vmasr_ln_gate_pair_supported). */
+int vmasr_ln_gate_pair_supported(int32_t D, int32_t H, int32_t W);
+int vmasr_ln_gate_pair_fwd(const float *y02, const float *y13, const void *sz, const float *gamma, const float *beta, void *out,
+                           float *mean, float *rstd, int32_t B, int32_t D, int32_t H, int32_t W, float eps, int32_t dtype,
+                           vmasr_stream_t stream);
+int vmasr_ln_gate_pair_bwd(const float *y02, const float *y13, const void *sz, const void *dout, const float *gamma,
+                           const float *beta, const float *mean, const float *rstd, float *dy02, float *dy13, void *dsz,
+                           float *dgamma, float *dbeta, int32_t B, int32_t D, int32_t H, int32_t W, int32_t dtype,
+                           vmasr_stream_t stream);
 
 /* x (n fp32) -> hi = bf16(x), lo = bf16(x - hi): the operands of an error-compensated 3-GEMM bf16 product that
  * reproduces the fp32 GEMM of the period discriminator's convolutions (model/discriminator.py:21-147) to ~1e-6

@@ -43,7 +43,7 @@ class SScanBwdParams(ctypes.Structure):
 
 class SS2DParams(ctypes.Structure):
     """POD mirror of vmasr_ss2d_params."""
-    _fields_ = ([(n, c_i32) for n in ("B", "D", "H", "W", "dtype")]
+    _fields_ = ([(n, c_i32) for n in ("B", "D", "H", "W", "dtype", "flags")]
                 + [(n, c_vp) for n in ("x", "xT", "Wx", "Wdt", "dtb", "Alog", "Ds", "state", "out02", "out13", "y",
                                        "dy", "dyT", "adj", "part", "dx", "dWx", "dWdt", "ddtb", "dAlog", "dDs")])
 
@@ -108,6 +108,9 @@ SYMBOLS = {
     "vmasr_ss2d_pre_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_ln_gate_fwd": (ctypes.c_int, [c_vp] * 7 + [c_i32, c_i32, c_i32, ctypes.c_float, c_i32, c_vp]),
     "vmasr_ln_gate_bwd": (ctypes.c_int, [c_vp] * 11 + [c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_ln_gate_pair_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
+    "vmasr_ln_gate_pair_fwd": (ctypes.c_int, [c_vp] * 8 + [c_i32, c_i32, c_i32, c_i32, ctypes.c_float, c_i32, c_vp]),
+    "vmasr_ln_gate_pair_bwd": (ctypes.c_int, [c_vp] * 13 + [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_ss2d_supported": (ctypes.c_int, [c_i32] * 5),
     "vmasr_ss2d_part_floats": (c_sz, [c_i32] * 4),
     "vmasr_ss2d_fwd": (ctypes.c_int, [ctypes.POINTER(SS2DParams), c_vp]),

@@ -563,6 +563,7 @@ int run_fwd(const vmasr_ss2d_params &p, hipStream_t st) {
     VMASR_LAUNCH(VMASR_K_SS2D_CARRY, (double)nseq * ntiles * 16, (ss2d_carry_kernel<false>), dim3((nseq + 3) / 4), dim3(256), 0, st,
                  p.state, nseq, ntiles);
     SS2D_DISPATCH(ss2d_fwd_kernel, 1, VMASR_K_SS2D_FWD_APPLY, (3.0 * 4 * el + 2.0 * 4 * pos) * 4, a);
+    if (p.flags & VMASR_SS2D_PAIRS) return check_launch("ss2d_fwd");      // the consumer adds out02 + out13^T itself
     const dim3 grid(((p.W + kXT - 1) / kXT) * ((p.H + kXT - 1) / kXT), p.B * p.D);
     VMASR_LAUNCH(VMASR_K_SS2D_MERGE, 12.0 * el, (merge_pairs_kernel<float>), grid, dim3(256), 0, st, p.out02, p.out13, p.y, p.H, p.W);
     return check_launch("ss2d_fwd");
@@ -575,7 +576,7 @@ int run_bwd(const vmasr_ss2d_params &p, hipStream_t st) {
     VMASR_REQUIRE(ntiles % c.TPG == 0, VMASR_EINVAL, "ss2d_bwd: tile count must be a multiple of %d", c.TPG);
     const Geo geo{p.B, p.D, L, ntiles, ntiles / c.TPG};
     const size_t sm = lds_bytes(c);
-    launch_transpose<float, float>(p.dy, p.dyT, p.B * p.D, p.H, p.W, st);
+    if (!(p.flags & VMASR_SS2D_PAIRS)) launch_transpose<float, float>(p.dy, p.dyT, p.B * p.D, p.H, p.W, st);
     BwdArgs q{{p.x, p.xT, p.Wx, p.Wdt, p.dtb, p.Alog, p.Ds, p.state, nullptr, nullptr}, p.dy, p.dyT, p.adj, p.out02, p.out13, p.part};
     const double el = (double)p.B * p.D * L, pos = (double)p.B * L;
     SS2D_DISPATCH_BWD(ss2d_bwd_kernel, 0, VMASR_K_SS2D_BWD_AGG, 2.0 * el * (sizeof(T) + 4), q);
@@ -615,7 +616,7 @@ VMASR_EXPORT int vmasr_ss2d_fwd(const vmasr_ss2d_params *pp, vmasr_stream_t stre
     VMASR_REQUIRE(pp, VMASR_EINVAL, "ss2d_fwd: null params");
     const vmasr_ss2d_params &p = *pp;
     if (int e = check(p, "ss2d_fwd")) return e;
-    VMASR_REQUIRE(p.xT && p.state && p.out02 && p.out13 && p.y, VMASR_EINVAL, "ss2d_fwd: null buffer");
+    VMASR_REQUIRE(p.xT && p.state && p.out02 && p.out13 && (p.y || (p.flags & VMASR_SS2D_PAIRS)), VMASR_EINVAL, "ss2d_fwd: null buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (p.dtype) {
         case VMASR_F32: return run_fwd<float>(p, st);

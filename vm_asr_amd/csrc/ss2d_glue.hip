@@ -390,6 +390,107 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_direct(const float *__restric
     else if (threadIdx.x < 2 * D) atomicAdd(dbeta + threadIdx.x - D, acc[threadIdx.x]);
 }
 
+// ---- pair variants: y = y02 + transpose(y13) formed on the fly (the last step of CrossMerge never becomes a tensor) ------
+// A workgroup owns a 16 x 16 (h, w) tile, thread (th, tw): the (h,w)-ordered operand is read as 64-byte runs along w, the
+// (w,h)-ordered one as 16-byte runs along h that the workgroup's four waves complete to 64 bytes (L1 hits) — instead of a
+// merge kernel that reads both and writes y (12 B per (row, position)) and of this kernel reading y back.
+struct PairGeom {
+    int H, W, tiles_w, ntiles;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ln_gate_pair_fwd_kernel(const float *__restrict__ y02, const float *__restrict__ y13,
+                                                               const T *__restrict__ sz, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, T *__restrict__ out,
+                                                               float *__restrict__ mean, float *__restrict__ rstd,
+                                                               const PairGeom g, const float eps) {
+    const int b = blockIdx.y, L = g.H * g.W;
+    const int h = (blockIdx.x / g.tiles_w) * 16 + (threadIdx.x >> 4), w = (blockIdx.x % g.tiles_w) * 16 + (threadIdx.x & 15);
+    const int l = h * g.W + w, lt = w * g.H + h;
+    const size_t row = (size_t)b * L + l;
+    float v[D], zv[D];
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const size_t base = ((size_t)b * D + d) * L;
+        v[d] = y02[base + l] + y13[base + lt];
+        s += v[d];
+    }
+    const float mu = s * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { v[d] -= mu; q = fmaf(v[d], v[d], q); }
+    const float rs = rsqrtf(q * (1.f / D) + eps);
+    RowIO<T, D>::load(sz + row * D, zv);
+#pragma unroll
+    for (int d = 0; d < D; ++d) zv[d] *= fmaf(v[d] * rs, gamma[d], beta[d]);
+    RowIO<T, D>::store(out + row * D, zv);
+    mean[row] = mu;
+    rstd[row] = rs;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ln_gate_pair_bwd_kernel(const float *__restrict__ y02, const float *__restrict__ y13,
+                                                               const T *__restrict__ sz, const T *__restrict__ dout,
+                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                               const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                               float *__restrict__ dy02, float *__restrict__ dy13,
+                                                               T *__restrict__ dsz, float *__restrict__ dgamma,
+                                                               float *__restrict__ dbeta, const PairGeom g, const int iters) {
+    __shared__ float acc[2 * D];
+    const int b = blockIdx.y, L = g.H * g.W;
+    if (threadIdx.x < 2 * D) acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    float dg[D], db[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { dg[d] = 0.f; db[d] = 0.f; }
+#pragma unroll 1
+    for (int k = 0; k < iters; ++k) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (tile >= g.ntiles) break;
+        const int h = (tile / g.tiles_w) * 16 + (threadIdx.x >> 4), w = (tile % g.tiles_w) * 16 + (threadIdx.x & 15);
+        const int l = h * g.W + w, lt = w * g.H + h;
+        const size_t row = (size_t)b * L + l;
+        const float m = mean[row], r = rstd[row];
+        float xh[D], zv[D], go[D];
+        RowIO<T, D>::load(sz + row * D, zv);
+        RowIO<T, D>::load(dout + row * D, go);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const size_t base = ((size_t)b * D + d) * L;
+            xh[d] = (y02[base + l] + y13[base + lt] - m) * r;
+            const float a = fmaf(xh[d], gamma[d], beta[d]);
+            const float gl = go[d] * zv[d];
+            zv[d] = go[d] * a;                   // d sz
+            dg[d] = fmaf(gl, xh[d], dg[d]);
+            db[d] += gl;
+            go[d] = gl * gamma[d];               // g
+            s1 += go[d];
+            s2 = fmaf(go[d], xh[d], s2);
+        }
+        RowIO<T, D>::store(dsz + row * D, zv);
+        s1 *= (1.f / D);
+        s2 *= (1.f / D);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const size_t base = ((size_t)b * D + d) * L;
+            const float gv = r * (go[d] - s1 - xh[d] * s2);
+            dy02[base + l] = gv;
+            dy13[base + lt] = gv;
+        }
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float a = wave_sum(dg[d]), c = wave_sum(db[d]);
+        if (lane == 0) { atomicAdd(&acc[d], a); atomicAdd(&acc[D + d], c); }
+    }
+    __syncthreads();
+    if (threadIdx.x < D) atomicAdd(dgamma + threadIdx.x, acc[threadIdx.x]);
+    else if (threadIdx.x < 2 * D) atomicAdd(dbeta + threadIdx.x - D, acc[threadIdx.x]);
+}
+
 #define GLUE_DIRECT_D(KERNEL, T, KID, BYTES, GRIDX, ...)                                                              \
     do {                                                                                                             \
         const dim3 grid(GRIDX, B);                                                                                   \
@@ -553,4 +654,45 @@ VMASR_EXPORT int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *d
     GLUE_DISPATCH(ln_gate_bwd_kernel, VMASR_K_LN_GATE, bytes, sm);
 #undef GLUE_ARGS
     return check_launch("ln_gate_bwd");
+}
+
+VMASR_EXPORT int vmasr_ln_gate_pair_supported(int32_t D, int32_t H, int32_t W) {
+    return (direct_ok(D) && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0) ? 1 : 0;
+}
+
+VMASR_EXPORT int vmasr_ln_gate_pair_fwd(const float *y02, const float *y13, const void *sz, const float *gamma, const float *beta,
+                                        void *out, float *mean, float *rstd, int32_t B, int32_t D, int32_t H, int32_t W, float eps,
+                                        int32_t dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(vmasr_ln_gate_pair_supported(D, H, W) && B > 0 && B <= 65535, VMASR_EINVAL,
+                  "ln_gate_pair_fwd: need d_inner in {2,4,8,16,32} and H, W multiples of 16");
+    VMASR_REQUIRE(dtype == VMASR_F32 || dtype == VMASR_F16 || dtype == VMASR_BF16, VMASR_EINVAL, "ln_gate_pair_fwd: bad dtype");
+    VMASR_REQUIRE(y02 && y13 && sz && gamma && beta && out && mean && rstd, VMASR_EINVAL, "ln_gate_pair_fwd: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int L = H * W, esz = dtype == VMASR_F32 ? 4 : 2;
+    const PairGeom g{H, W, W / 16, (H / 16) * (W / 16)};
+    const double bytes = (double)B * L * D * (8 + 2 * esz);
+#define GLUE_ARGS(TT) y02, y13, static_cast<const TT *>(sz), gamma, beta, static_cast<TT *>(out), mean, rstd, g, eps
+    GLUE_DIRECT(ln_gate_pair_fwd_kernel, VMASR_K_LN_GATE, bytes, g.ntiles);
+#undef GLUE_ARGS
+    return check_launch("ln_gate_pair_fwd");
+}
+
+VMASR_EXPORT int vmasr_ln_gate_pair_bwd(const float *y02, const float *y13, const void *sz, const void *dout, const float *gamma,
+                                        const float *beta, const float *mean, const float *rstd, float *dy02, float *dy13, void *dsz,
+                                        float *dgamma, float *dbeta, int32_t B, int32_t D, int32_t H, int32_t W, int32_t dtype,
+                                        vmasr_stream_t stream) {
+    VMASR_REQUIRE(vmasr_ln_gate_pair_supported(D, H, W) && B > 0 && B <= 65535, VMASR_EINVAL,
+                  "ln_gate_pair_bwd: need d_inner in {2,4,8,16,32} and H, W multiples of 16");
+    VMASR_REQUIRE(dtype == VMASR_F32 || dtype == VMASR_F16 || dtype == VMASR_BF16, VMASR_EINVAL, "ln_gate_pair_bwd: bad dtype");
+    VMASR_REQUIRE(y02 && y13 && sz && dout && gamma && beta && mean && rstd && dy02 && dy13 && dsz && dgamma && dbeta, VMASR_EINVAL,
+                  "ln_gate_pair_bwd: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int L = H * W, esz = dtype == VMASR_F32 ? 4 : 2;
+    const PairGeom g{H, W, W / 16, (H / 16) * (W / 16)};
+    const int nblk = std::min(g.ntiles, kGlueMaxBlocks), iters = (g.ntiles + nblk - 1) / nblk;
+    const double bytes = (double)B * L * D * (16 + 3 * esz);
+#define GLUE_ARGS(TT) y02, y13, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy02, dy13, static_cast<TT *>(dsz), dgamma, dbeta, g, iters
+    GLUE_DIRECT(ln_gate_pair_bwd_kernel, VMASR_K_LN_GATE, bytes, nblk);
+#undef GLUE_ARGS
+    return check_launch("ln_gate_pair_bwd");
 }

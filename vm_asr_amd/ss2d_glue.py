@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["ss2d_pre", "ln_gate", "supported"]
+__all__ = ["ss2d_pre", "ln_gate", "ln_gate_pairs", "pairs_supported", "supported"]
 
 
 def _p(t):
@@ -87,6 +87,53 @@ class _LNGateFn(torch.autograd.Function):
                                                     _p(dgb[0]), _p(dgb[1]), B, D, L, _lib.torch_dtype_code(sz.dtype),
                                                     _lib.current_stream(sz.device)), "ln_gate_bwd")
         return dy, dsz, dgb[0].to(ctx.meta[0]), dgb[1].to(ctx.meta[1]), None
+
+
+class _LNGatePairsFn(torch.autograd.Function):
+    """ln_gate on the un-merged pair outputs of the fused core (csrc/ss2d_glue.hip: ln_gate_pair_*)."""
+
+    @staticmethod
+    def forward(ctx, y02, y13, sz, gamma, beta, eps):
+        B, H, W, D = sz.shape
+        y02, y13 = y02.float().contiguous(), y13.float().contiguous()
+        sz = sz.contiguous()
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        with torch.cuda.device(sz.device):
+            out = torch.empty_like(sz)
+            stats = torch.empty((2, B, H * W), dtype=torch.float32, device=sz.device)
+            _lib.check(_lib.lib().vmasr_ln_gate_pair_fwd(_p(y02), _p(y13), _p(sz), _p(g32), _p(b32), _p(out), _p(stats[0]), _p(stats[1]),
+                                                         B, D, H, W, float(eps), _lib.torch_dtype_code(sz.dtype),
+                                                         _lib.current_stream(sz.device)), "ln_gate_pair_fwd")
+        ctx.save_for_backward(y02, y13, sz, g32, b32, stats)
+        ctx.meta = (gamma.dtype, beta.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y02, y13, sz, g32, b32, stats = ctx.saved_tensors
+        B, H, W, D = sz.shape
+        dout = dout.to(sz.dtype).contiguous()
+        with torch.cuda.device(sz.device):
+            dys = torch.empty((2,) + tuple(y02.shape), dtype=torch.float32, device=sz.device)
+            dsz = torch.empty_like(sz)
+            dgb = torch.zeros((2, D), dtype=torch.float32, device=sz.device)
+            _lib.check(_lib.lib().vmasr_ln_gate_pair_bwd(_p(y02), _p(y13), _p(sz), _p(dout), _p(g32), _p(b32), _p(stats[0]), _p(stats[1]),
+                                                         _p(dys[0]), _p(dys[1]), _p(dsz), _p(dgb[0]), _p(dgb[1]), B, D, H, W,
+                                                         _lib.torch_dtype_code(sz.dtype), _lib.current_stream(sz.device)), "ln_gate_pair_bwd")
+        return dys[0], dys[1], dsz, dgb[0].to(ctx.meta[0]), dgb[1].to(ctx.meta[1]), None
+
+
+def pairs_supported(D, H, W, dtype):
+    if os.environ.get("VMASR_SS2D_PAIRS", "1") != "1" or dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        return False
+    return bool(_lib.lib().vmasr_ln_gate_pair_supported(int(D), int(H), int(W)))
+
+
+def ln_gate_pairs(y02, y13, sz, gamma, beta, eps):
+    """== ln_gate(y02 + transpose_hw(y13), sz, gamma, beta, eps) without the merged tensor (sz: (B, H, W, D))."""
+    if not sz.is_cuda:
+        raise RuntimeError("ln_gate_pairs: expected a CUDA (HIP) tensor; vm_asr_amd has no CPU path")
+    return _LNGatePairsFn.apply(y02, y13, sz, gamma, beta, eps)
 
 
 def ss2d_pre(xz):

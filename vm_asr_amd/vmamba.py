@@ -379,8 +379,16 @@ class SS2D(nn.Module):
             # chunk + SiLU(z) + layout copy as one kernel; LayerNorm + cast + gate (and the layout copy in front of
             # them) as another (csrc/ss2d_glue.hip)
             xT, sz = _glue.ss2d_pre(x)
-            y = self.forward_core(self._conv_act(xT), merged_only=True)           # (B, D, L) fp32
-            y = _glue.ln_gate(y, sz, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
+            u = self._conv_act(xT)
+            Bn, H, W = x.shape[0], x.shape[1], x.shape[2]
+            if (self.k_group == 4 and _ss2d.supported(self.d_state, self.dt_rank, self.d_inner, H, W)
+                    and _glue.pairs_supported(self.d_inner, H, W, sz.dtype)):
+                # fused core + LayerNorm-gate without the merged tensor: the core leaves its two pair outputs, ln_gate adds them
+                y02, y13 = _ss2d.ss2d_core_pairs(u, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds)
+                y = _glue.ln_gate_pairs(y02, y13, sz, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
+            else:
+                y = self.forward_core(u, merged_only=True)                        # (B, D, L) fp32
+                y = _glue.ln_gate(y, sz, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
             return self.dropout(self.out_proj(y))
         z = None
         if not self.disable_z:
