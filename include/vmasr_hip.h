@@ -182,6 +182,12 @@ int vmasr_layer_norm_bwd(const void *x, const void *gy, const float *gamma, cons
 int vmasr_layer_norm_bwd_res(const void *x, const void *gy, const float *gamma, const float *mean,
                              const float *rstd, const void *residual, void *dx, float *dgamma, float *dbeta, float *ws,
                              int32_t rows, int32_t C, int32_t dtype, int32_t gy_dtype, vmasr_stream_t stream);
+/* Deferred dgamma / dbeta: vmasr_layer_norm_bwd(_res) with ws but dgamma = dbeta = NULL writes the per-workgroup partials only
+ * (vmasr_layer_norm_bwd_blocks(rows, C) rows of 2 C floats); vmasr_layer_norm_bwd_reduce_multi sums the partials of n such
+ * calls in ONE launch (host arrays of device pointers / sizes; the table travels as a kernel argument). */
+int32_t vmasr_layer_norm_bwd_blocks(int32_t rows, int32_t C);
+int vmasr_layer_norm_bwd_reduce_multi(const float *const *parts, float *const *dgammas, float *const *dbetas, const int32_t *nblks,
+                                      const int32_t *Cs, int32_t n, vmasr_stream_t stream);
 
 /* nn.Linear with in/out features in {1,2,4,8} (in*out <= 32) over `rows` rows: the d_model = 1
  * VSS block and the 4->1 pointwise conv of the output layer (model/model.py:862-885,

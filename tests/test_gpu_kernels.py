@@ -526,3 +526,36 @@ def test_spectral_power_iteration_batched_matches_single():
                 _close(got._u, sr._u.numpy(), 1e-4, 1e-5, f"u {what} {tuple(w.shape)}")
                 _close(got._v, sr._v.numpy(), 1e-4, 1e-5, f"v {what} {tuple(w.shape)}")
     assert b.power_iterate_all(1) and float(b._sn_batch.ws.abs().max()) >= 0   # table reused, scratch sane
+
+
+def test_layer_norm_deferred_reduction_matches_immediate():
+    """layernorm.DEFER_REDUCE: the dgamma / dbeta of every LayerNorm call of a backward pass come from ONE reduce launch at the
+    end of the pass (autograd queue_callback); same values as the immediate reduction; a weight used twice in one graph, or
+    one that already holds a .grad, is reduced at once."""
+    from vm_asr_amd import layernorm as L
+    torch.manual_seed(0)
+    lns = [L.LayerNorm(c).to(DEV) for c in (8, 16, 64, 128)]
+    xs = [torch.randn(4 * 4096 // max(1, c // 8), c, device=DEV, requires_grad=True) for c in (8, 16, 64, 128)]
+
+    def run():
+        for m in lns:
+            m.zero_grad(set_to_none=True)
+        loss = sum((m(x) * (i + 1)).sin().sum() for i, (m, x) in enumerate(zip(lns, xs))) + (lns[1](xs[1] * 2)).sum()   # lns[1] twice
+        loss.backward()
+        return [p.grad.clone() for m in lns for p in m.parameters()]
+    ref = run()
+    L.DEFER_REDUCE = True
+    deferred = []
+    orig = L.defer_reduction
+    L.defer_reduction = lambda *a: (deferred.append(a[4]) or True) and orig(*a)
+    try:
+        L.reset_uses()
+        got = run()
+        assert not L._pending and sorted(deferred) == [8, 64, 128]          # all but the LayerNorm used twice
+        got2 = run()           # (use counts were cleared by the flush)
+    finally:
+        L.DEFER_REDUCE = False
+        L.defer_reduction = orig
+        L.reset_uses()
+    for a, b, c in zip(ref, got, got2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * a.abs().max().item()) and torch.equal(b, c)

@@ -61,6 +61,8 @@ SYMBOLS = {
     "vmasr_layer_norm_bwd_workspace": (c_sz, [c_i32, c_i32]),
     "vmasr_layer_norm_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_layer_norm_bwd_res": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_layer_norm_bwd_blocks": (c_i32, [c_i32, c_i32]),
+    "vmasr_layer_norm_bwd_reduce_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "vmasr_mlp_supported": (ctypes.c_int, [c_i32, c_i32]),
     "vmasr_mlp_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_mlp_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,

@@ -18,6 +18,8 @@
 // (deterministic, no atomics).
 #include "common.h"
 
+#include <algorithm>
+
 namespace vmasr {
 namespace {
 
@@ -212,6 +214,37 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
     }
 }
 
+// dgamma / dbeta of MANY LayerNorm backward calls in one launch (blockIdx.y = call): the calls of one backward pass write
+// their per-workgroup partials only, the host queues (partials, nblk, C, dgamma, dbeta) and flushes the queue once at the end of
+// the pass — one launch instead of 65 (9 us each at <= 1 MB: pure launch floor).  The table travels by value (kernel argument).
+constexpr int kMaxReduceItems = 96;
+struct ReduceItem {
+    const float *part;
+    float *dgamma, *dbeta;
+    int nblk, C;
+};
+struct ReduceTable {
+    ReduceItem it[kMaxReduceItems];
+};
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce_multi_kernel(const ReduceTable t) {
+    const ReduceItem r = t.it[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < r.C; c += gridDim.x * 4) {   // one wave per column
+        float a = 0.f, b = 0.f;
+        for (int k = lane; k < r.nblk; k += 64) {
+            a += r.part[(size_t)k * 2 * r.C + c];
+            b += r.part[(size_t)k * 2 * r.C + r.C + c];
+        }
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (lane == 0) {
+            if (r.dgamma) r.dgamma[c] = a;
+            if (r.dbeta) r.dbeta[c] = b;
+        }
+    }
+}
+
 int lpr_for(int C) {
     int lpr = 1;
     while (lpr < 64 && lpr * 4 * 1 < C && lpr * 4 < C) lpr *= 2;  // smallest power of two with 4*LPR >= C (cap 64)
@@ -314,7 +347,9 @@ VMASR_EXPORT int vmasr_layer_norm_bwd_res(const void *x, const void *gy, const f
                                           vmasr_stream_t stream) {
     if (int e = check(x, rows, C, dtype, "layer_norm_bwd")) return e;
     VMASR_REQUIRE(gy && mean && rstd && dx, VMASR_EINVAL, "layer_norm_bwd: null tensor");
-    const bool affine = dgamma || dbeta;
+    // ws without dgamma / dbeta: write the per-workgroup partials only (the caller reduces them later, together with other
+    // calls': vmasr_layer_norm_bwd_reduce_multi)
+    const bool affine = dgamma || dbeta || ws;
     VMASR_REQUIRE(!affine || ws, VMASR_ENOSPACE, "layer_norm_bwd: workspace required for dgamma/dbeta");
     const int lpr = lpr_for(C);
     const LnGeom g{rows, C, (C + 4 * lpr - 1) / (4 * lpr), 0.f};
@@ -327,8 +362,33 @@ VMASR_EXPORT int vmasr_layer_norm_bwd_res(const void *x, const void *gy, const f
     if (int e = dispatch<1>(dtype, gy_dtype, vec, lpr, dim3(nblk), st, bytes, x, gy, gamma, nullptr, dx, const_cast<float *>(mean),
                             const_cast<float *>(rstd), affine ? ws : nullptr, g, residual))
         return e;
-    if (affine)
+    if (dgamma || dbeta)
         VMASR_LAUNCH(VMASR_K_LN_BWD_REDUCE, (double)nblk * 2 * C * 4, ln_bwd_reduce_kernel, dim3((C + 3) / 4), dim3(256), 0,
                      st, ws, nblk, C, dgamma, dbeta);
     return check_launch("layer_norm_bwd");
+}
+
+VMASR_EXPORT int32_t vmasr_layer_norm_bwd_blocks(int32_t rows, int32_t C) {
+    return (rows <= 0 || C <= 0 || C > 1024) ? 0 : grid_for(rows, lpr_for(C));
+}
+
+VMASR_EXPORT int vmasr_layer_norm_bwd_reduce_multi(const float *const *parts, float *const *dgammas, float *const *dbetas,
+                                                   const int32_t *nblks, const int32_t *Cs, int32_t n, vmasr_stream_t stream) {
+    VMASR_REQUIRE(parts && dgammas && dbetas && nblks && Cs && n > 0, VMASR_EINVAL, "layer_norm_bwd_reduce_multi: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int base = 0; base < n; base += kMaxReduceItems) {
+        const int m = std::min(kMaxReduceItems, n - base);
+        ReduceTable t{};
+        int maxC = 0;
+        double bytes = 0;
+        for (int i = 0; i < m; ++i) {
+            VMASR_REQUIRE(parts[base + i] && nblks[base + i] > 0 && Cs[base + i] > 0 && Cs[base + i] <= 1024, VMASR_EINVAL,
+                          "layer_norm_bwd_reduce_multi: bad item %d", base + i);
+            t.it[i] = ReduceItem{parts[base + i], dgammas[base + i], dbetas[base + i], nblks[base + i], Cs[base + i]};
+            maxC = std::max(maxC, Cs[base + i]);
+            bytes += (double)nblks[base + i] * 2 * Cs[base + i] * 4;
+        }
+        VMASR_LAUNCH(VMASR_K_LN_BWD_REDUCE, bytes, ln_bwd_reduce_multi_kernel, dim3(std::min((maxC + 3) / 4, 32), m), dim3(256), 0, st, t);
+    }
+    return check_launch("layer_norm_bwd_reduce_multi");
 }

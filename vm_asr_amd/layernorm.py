@@ -22,6 +22,73 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+# ---- deferred dgamma / dbeta -----------------------------------------------------------------------------------------
+# A LayerNorm backward = one kernel (dx + per-workgroup partials of dgamma / dbeta) + a 9 us reduce launch; a training step has
+# 65 of them.  With DEFER_REDUCE the calls of one backward pass only write their partials and queue the reduction; ONE launch at
+# the end of the pass (autograd's queue_callback: runs when the engine finishes the current backward) fills all dgamma / dbeta.
+# Only safe when nobody reads a parameter gradient before the backward pass ends and gradients are not accumulated in place while
+# it runs — the trainer's flat-buffer mode (grads dropped before the pass, packed after it) — so it is OFF unless the trainer
+# turns it on; a call whose weight / bias already has a .grad reduces at once.
+DEFER_REDUCE = False
+_pending = []
+_uses = {}          # id(weight) -> forward calls since the last flush / reset: a weight used twice in one graph must not defer
+                    # (autograd would add the second call's gradient into the first's still-empty tensor)
+
+
+def note_use(*params):
+    """(called from autograd.Function.forward, where grad mode is off: the caller checks ctx.needs_input_grad)"""
+    if DEFER_REDUCE:
+        for t in params:
+            if t is not None:
+                _uses[id(t)] = _uses.get(id(t), 0) + 1
+
+
+def used_once(*params):
+    return all(_uses.get(id(t), 0) == 1 for t in params if t is not None)
+
+
+def reset_uses():
+    _uses.clear()
+
+
+def _flush_pending():
+    """Reduce the queued partials (one launch per <= 96 calls) on the current stream."""
+    global _pending
+    items, _pending = _pending, []
+    _uses.clear()
+    if not items:
+        return
+    import numpy as np
+    dev = items[0][0].device
+    n = len(items)
+    parts = np.array([i[0].data_ptr() for i in items], dtype=np.uint64)
+    dgs, dbs = np.array([i[1][1] for i in items], dtype=np.uint64), np.array([i[2][1] for i in items], dtype=np.uint64)
+    nblk, cs = np.array([i[3] for i in items], dtype=np.int32), np.array([i[4] for i in items], dtype=np.int32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().vmasr_layer_norm_bwd_reduce_multi(parts.ctypes.data, dgs.ctypes.data, dbs.ctypes.data, nblk.ctypes.data,
+                                                                cs.ctypes.data, n, _lib.current_stream(dev)), "layer_norm_bwd_reduce_multi")
+        # autograd normally STEALS the returned gradient tensor as param.grad (fresh .grad, sole owner, contiguous); if it cloned
+        # instead, copy the reduced values over (correct either way; the extra copy only in the unusual case)
+        for _, (gst, gptr), (bst, bptr), _, C, weight, bias in items:
+            for param, st, ptr in ((weight, gst, gptr), (bias, bst, bptr)):
+                if param is None or st is None or param.grad is None or param.grad.data_ptr() == ptr:
+                    continue
+                param.grad.copy_(torch.empty(0, dtype=torch.float32, device=dev).set_(st, 0, (C,)).view_as(param.grad))
+
+
+def defer_reduction(ws, dg, db, rows, C, weight=None, bias=None):
+    """Queue (partials -> dg, db) for the end of the running backward pass; False if deferral does not apply.
+    Only the STORAGES of dg / db are kept (a second reference to the tensors themselves would make autograd clone them
+    instead of adopting them as .grad)."""
+    if not DEFER_REDUCE:
+        return False
+    if not _pending:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+    ref = lambda t: (None, 0) if t is None else (t.untyped_storage(), t.data_ptr())   # noqa: E731
+    _pending.append((ws, ref(dg), ref(db), int(_lib.lib().vmasr_layer_norm_bwd_blocks(rows, C)), C, weight, bias))
+    return True
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps, out_dtype):
@@ -43,6 +110,11 @@ class _LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w32 if w32 is not None else torch.empty(0, device=x.device), mean, rstd)
         ctx.meta = (x.shape, weight is not None, bias is not None,
                     None if weight is None else weight.dtype, None if bias is None else bias.dtype)
+        if any(ctx.needs_input_grad[1:3]):
+            note_use(weight, bias)
+        ctx.fresh = lambda: (all(getattr(t, "grad", None) is None for t in (weight, bias) if t is not None)
+                             and used_once(weight, bias))
+        ctx.params = (weight, bias)
         return y.view(x.shape)
 
     @staticmethod
@@ -63,10 +135,13 @@ class _LayerNormFn(torch.autograd.Function):
             ws = None
             if has_w or has_b:
                 ws = torch.empty(lib.vmasr_layer_norm_bwd_workspace(rows, C) // 4, dtype=torch.float32, device=x2.device)
+            # fp32 parameters whose .grad is still empty: their gradients can be filled at the end of the pass (see DEFER_REDUCE)
+            later = (ws is not None and DEFER_REDUCE and wdt in (None, torch.float32) and bdt in (None, torch.float32) and ctx.fresh()
+                     and defer_reduction(ws, dg, db, rows, C, *ctx.params))
             _lib.check(lib.vmasr_layer_norm_bwd(_p(x2), _p(gy2), _p(w32) if has_w else None, _p(mean), _p(rstd), _p(dx),
-                                                _p(dg), _p(db), _p(ws), rows, C, _lib.torch_dtype_code(x2.dtype),
-                                                _lib.torch_dtype_code(gy2.dtype), _lib.current_stream(x2.device)),
-                       "layer_norm_bwd")
+                                                None if later else _p(dg), None if later else _p(db), _p(ws), rows, C,
+                                                _lib.torch_dtype_code(x2.dtype), _lib.torch_dtype_code(gy2.dtype),
+                                                _lib.current_stream(x2.device)), "layer_norm_bwd")
         return (dx.view(shape), dg.to(wdt) if has_w else None, db.to(bdt) if has_b else None, None, None)
 
 

@@ -15,6 +15,7 @@ import os
 import torch
 
 from . import _lib
+from . import layernorm as _ln
 from .linear import LP_ATTR, weight_grad
 
 __all__ = ["fused_mlp_residual", "supported"]
@@ -68,6 +69,10 @@ class _FusedMlpFn(torch.autograd.Function):
                                                 _p(y), rows, d, _lib.torch_dtype_code(x2.dtype), _lib.current_stream(x.device)), "mlp_fwd")
         ctx.save_for_backward(x2, g32, be32, w1b, b1f, w2b, sc)
         ctx.meta = (x.shape, eps, rps, gamma.dtype, beta.dtype, w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        if any(ctx.needs_input_grad[1:3]):
+            _ln.note_use(gamma, beta)
+        ctx.fresh = lambda: gamma.grad is None and beta.grad is None and _ln.used_once(gamma, beta)
+        ctx.params = (gamma, beta)
         return y.view(x.shape)
 
     @staticmethod
@@ -95,15 +100,17 @@ class _FusedMlpFn(torch.autograd.Function):
                                          _lib.torch_dtype_code(x2.dtype), _lib.current_stream(dev)), "mlp_bwd")
             # dx = gy + LayerNorm'(dxn); dgamma, dbeta  (one launch: csrc/ln.hip with the residual gradient folded in)
             dx = torch.empty_like(x2)
-            dgb = torch.empty((2, d), dtype=torch.float32, device=dev)
+            dg_ = torch.empty(d, dtype=torch.float32, device=dev)      # separate tensors: autograd adopts each as a .grad
+            db_ = torch.empty(d, dtype=torch.float32, device=dev)
             ws = torch.empty(lib.vmasr_layer_norm_bwd_workspace(rows, d) // 4, dtype=torch.float32, device=dev)
-            _lib.check(lib.vmasr_layer_norm_bwd_res(_p(x2), _p(dxn), _p(g32), _p(stats[0]), _p(stats[1]), _p(gy2), _p(dx), _p(dgb[0]),
-                                                    _p(dgb[1]), _p(ws), rows, d, _lib.torch_dtype_code(x2.dtype), _lib.BF16, _lib.current_stream(dev)),
+            later = (gdt == torch.float32 and bedt == torch.float32 and ctx.fresh() and _ln.defer_reduction(ws, dg_, db_, rows, d, *ctx.params))
+            _lib.check(lib.vmasr_layer_norm_bwd_res(_p(x2), _p(dxn), _p(g32), _p(stats[0]), _p(stats[1]), _p(gy2), _p(dx),
+                                                    None if later else _p(dg_), None if later else _p(db_), _p(ws), rows, d, _lib.torch_dtype_code(x2.dtype), _lib.BF16, _lib.current_stream(dev)),
                        "layer_norm_bwd_res")
         # [dW1 | db1 | 0] = gpre^T xn_aug,  [dW2 | db2 | 0] = gys^T act_aug  (fp32 accumulation, split over the rows when few tiles)
         g1 = weight_grad(gpre, xn_aug)
         g2 = weight_grad(gys, act_aug)
-        return (dx.view(shape), dgb[0].to(gdt), dgb[1].to(bedt), g1[:, :d].to(w1dt), g1[:, d].to(b1dt), g2[:, :hd].to(w2dt),
+        return (dx.view(shape), dg_.to(gdt), db_.to(bedt), g1[:, :d].to(w1dt), g1[:, d].to(b1dt), g2[:, :hd].to(w2dt),
                 g2[:, hd].to(b2dt), None, None)
 
 

@@ -594,11 +594,20 @@ class Trainer(BaseTrainer):
         return ms
 
     # ---- one optimisation step (the unit bench.py times) ------------------------------------
+    def _set_deferred_reductions(self):
+        """LayerNorm's dgamma / dbeta of a whole backward pass in one launch (layernorm.DEFER_REDUCE): only when no
+        parameter gradient is read or accumulated in place before the pass ends — flat gradient buffers, no accumulation."""
+        from . import layernorm
+        layernorm.DEFER_REDUCE = (self.device.type == "cuda" and self.dp_mode == "flat" and self._gather
+                                  and os.environ.get("VMASR_LN_DEFER", "1") == "1")
+        layernorm.reset_uses()
+
     def _forward_losses(self, wave_input, wave_target, highcut):
         """generator forward -> discriminator + generator losses (one autograd graph; the D graph is built on the
         same D weights the G pass sees, so both backwards can run before either optimiser step).
         Returns the state the two backward phases consume."""
         acc = self._acc
+        self._set_deferred_reductions()
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
             wave_out = self.models["generator"](wave_input, highcut)
         shared = self._share_fake_pass()
