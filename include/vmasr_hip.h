@@ -426,6 +426,21 @@ int vmasr_mlp_bwd(const void *x, const void *gy, const float *gamma, const float
                   void *xn_aug, void *gys, void *act_aug, void *gpre, float *mean, float *rstd, int64_t rows, int32_t d,
                   int32_t x_dtype, vmasr_stream_t stream);
 
+/* ---- the input side of SS2D.forwardv2 as one MFMA kernel (vm_asr_amd/csrc/mlp.hip: inproj_kernel) ----------------------
+ * xz = in_proj(LayerNorm(x)) (model/vmamba.py:1826-1827, 1535); x', z = xz.chunk(2, -1); xT = x'.permute(0,3,1,2);
+ * sz = SiLU(z) (:1537-1542) — LayerNorm + Linear + vmasr_ss2d_pre_fwd in one launch, under bf16 autocast, for x (rows, d) fp32 or
+ * bf16 with rows = B * L, d in {8,16,32,64}, in_proj.weight w (4d, d) bf16 without bias, L a multiple of 32.  gamma = beta = NULL:
+ * no LayerNorm (the output layers' blocks use nn.Identity).  xT (B, 2d, L) and sz (rows, 2d) bf16.
+ * vmasr_inproj_bwd recomputes the forward and turns dxT / dsz into dxn (rows, d) bf16 (gradient wrt LayerNorm's output, or wrt x
+ * without a norm), xn (rows, d) and gpre (rows, 4d) bf16 (dW = gpre^T . xn), mean / rstd (rows) for vmasr_layer_norm_bwd;
+ * wt (d, 4d) = w^T contiguous. */
+int vmasr_inproj_supported(int32_t d, int32_t d_proj, int64_t L);
+int vmasr_inproj_fwd(const void *x, const float *gamma, const float *beta, float eps, const void *w, void *xT, void *sz, int64_t rows,
+                     int32_t L, int32_t d, int32_t x_dtype, vmasr_stream_t stream);
+int vmasr_inproj_bwd(const void *x, const float *gamma, const float *beta, float eps, const void *w, const void *wt, const void *dxT,
+                     const void *dsz, void *dxn, void *xn, void *gpre, float *mean, float *rstd, int64_t rows, int32_t L, int32_t d,
+                     int32_t x_dtype, vmasr_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents
  * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
@@ -479,6 +494,8 @@ enum {
     VMASR_K_CONV_POST,          /* the discriminators' 1024 -> 1 output convolution on the stacked maps */
     VMASR_K_MLP_FWD,            /* LayerNorm + fc1 + GELU + fc2 + residual of a VSS block as one MFMA kernel */
     VMASR_K_MLP_BWD,
+    VMASR_K_INPROJ_FWD,         /* LayerNorm + in_proj + chunk + SiLU(z) + channel-first copy of a VSS block's SS2D as one MFMA kernel */
+    VMASR_K_INPROJ_BWD,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

@@ -94,3 +94,64 @@ def test_vssblock_uses_the_fused_mlp_under_autocast_only():
         finally:
             os.environ.pop("VMASR_FUSED_MLP")
     assert y1.dtype == torch.float32 and (y1 - y0).abs().max() <= 2e-2 * y0.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d,shape,with_norm", [(8, (2, 16, 16), True), (16, (1, 32, 32), True), (16, (2, 8, 8), False), (32, (2, 8, 16), True),
+                                               (64, (1, 16, 16), True), (64, (2, 8, 4), False)])
+def test_fused_in_proj_matches_float64_as_well_as_torch_autocast(d, shape, with_norm, xdt):
+    """LayerNorm -> in_proj -> chunk -> (channel-first x, SiLU(z)) as one MFMA kernel (vm_asr_amd/inproj.py; model/vmamba.py:
+    1826-1827, 1535-1542) against float64, with torch's bf16 autocast of the same lines as the yardstick; with a LayerNorm and
+    with nn.Identity (the output layers' blocks), fp32 and bf16 streams."""
+    from vm_asr_amd.inproj import fused_in_proj, supported
+    from vm_asr_amd.layernorm import LayerNorm
+    from vm_asr_amd.linear import Linear
+    torch.manual_seed(d + shape[1])
+    dev = "cuda"
+    norm = LayerNorm(d).to(dev) if with_norm else nn.Identity()
+    proj = Linear(d, 4 * d, bias=False).to(dev)
+    if with_norm:
+        with torch.no_grad():
+            norm.weight.add_(0.1 * torch.randn_like(norm.weight)); norm.bias.add_(0.1 * torch.randn_like(norm.bias))
+    B, H, W = shape
+    x = torch.randn(B, H, W, d, device=dev).to(xdt)
+    gT, gz = torch.randn(B, 2 * d, H, W, device=dev).to(torch.bfloat16), torch.randn(B, H, W, 2 * d, device=dev).to(torch.bfloat16)
+    params = ([norm.weight, norm.bias] if with_norm else []) + [proj.weight]
+
+    def ref(dtype):
+        c = lambda t: t.detach().to(dtype).requires_grad_()       # noqa: E731
+        xi, ps = c(x), [c(p) for p in params]
+        xn = F.layer_norm(xi, (d,), ps[0], ps[1], norm.eps) if with_norm else xi
+        xz = F.linear(xn, ps[-1])
+        xx, z = xz.chunk(2, -1)
+        xT, sz = xx.permute(0, 3, 1, 2), F.silu(z)
+        ((xT * gT.to(dtype)).sum() + (sz * gz.to(dtype)).sum()).backward()
+        return [xT.detach(), sz.detach(), xi.grad] + [p.grad for p in ps]
+
+    def run(fn):
+        xi = x.clone().requires_grad_()
+        for p in params:
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            xT, sz = fn(xi)
+        ((xT.float() * gT.float()).sum() + (sz.float() * gz.float()).sum()).backward()
+        return [xT.detach().double(), sz.detach().double(), xi.grad.double()] + [p.grad.double() for p in params]
+
+    def plain(xi):
+        xz = proj(norm(xi))
+        xx, z = xz.chunk(2, -1)
+        return xx.permute(0, 3, 1, 2).contiguous(), F.silu(z)
+
+    def fused(xi):
+        assert supported(xi, norm, proj)
+        return fused_in_proj(xi, norm, proj)
+    want, got, auto = ref(torch.float64), run(fused), run(plain)
+    names = ["xT", "sz", "dx"] + (["dgamma", "dbeta"] if with_norm else []) + ["dW"]
+    tol = 1.6e-2
+    for n, a, b, c in zip(names, got, auto, want):
+        sc = max(c.abs().max().item(), 1e-12)
+        e_f, e_a = (a - c).abs().max().item() / sc, (b - c).abs().max().item() / sc
+        print(f"d={d} {shape} norm={with_norm} {n}: fused {e_f:.2e}  torch autocast {e_a:.2e}")
+        assert a.shape == c.shape and torch.isfinite(a).all(), n
+        assert e_f <= tol and e_f <= 1.5 * e_a + 3e-3, (n, e_f, e_a)

@@ -384,6 +384,136 @@ __global__ __launch_bounds__(HS > 4 ? 64 * HS : 256) void mlp_bwd_kernel(const M
     }
 }
 
+// ---- the input side of SS2D.forwardv2 as one kernel (model/vmamba.py:1826-1827 pre-norm, :1535-1542) ------------------------
+//     xz = in_proj(LayerNorm(x));  x', z = xz.chunk(2);  xT = x'.permute(0,3,1,2) (channel-first, for the depthwise conv);
+//     sz = SiLU(z)                                                       (= LayerNorm + Linear + vmasr_ss2d_pre_fwd)
+// Same wave-owns-32-rows / transposed-product scheme as the Mlp kernel: H^T = W_in (4d x d) . xn^T puts the position on the
+// lane and the output channel on the accumulator register, which is exactly how both outputs want to be written — the
+// channel-first x' as 64-byte runs along the positions (one 2-byte store per register), SiLU(z) as 8-byte runs along the
+// channels of the lane's own row.  `norm` = 0: the block has no LayerNorm (output layers 0 and 2 use nn.Identity).
+// Backward (recompute): gpre^T = [dxT | dsz * SiLU'(z)] tile by tile, dxn^T = W_in^T . gpre^T from the registers; writes dxn,
+// xn and gpre (bf16) for LayerNorm's backward and the weight-gradient GEMM dW = gpre^T . xn.
+struct InProjArgs {
+    const void *x;                 // (rows, D) TX
+    const float *gamma, *beta;     // (D) or unused when !norm
+    const bf16_t *w;               // (4D, D)  in_proj.weight
+    const bf16_t *wt;              // (D, 4D)  its transpose (backward)
+    bf16_t *xT;                    // (B, 2D, L) channel-first x half          (backward: dxT, read)
+    bf16_t *sz;                    // (rows, 2D) SiLU(z)                        (backward: dsz, read)
+    bf16_t *dxn, *xn, *gpre;       // backward outputs: (rows, D), (rows, D), (rows, 4D)
+    float *mean, *rstd;            // (rows) backward outputs (LayerNorm statistics)
+    long rows;
+    int L, norm;
+    float eps;
+};
+
+template <int D, typename TX, bool BWD>
+__global__ __launch_bounds__(256) void inproj_kernel(const InProjArgs a) {
+    constexpr int KS = (D + 15) / 16, HD = 4 * D, HT = HD / 32, OT = (D + 31) / 32, DI = 2 * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile * 32 < a.rows; tile += (long)gridDim.x * 4) {
+        const long row = tile * 32 + r;
+        const bool ok = row < a.rows;
+        const long b = row / a.L, l = row % a.L;
+        float xv[KS][8];
+        load_row<D, KS, TX>(static_cast<const TX *>(a.x) + row * D, ok, h, xv);
+        float mean = 0.f, rstd = 1.f;
+        bf16x8 xn[KS];
+        if (a.norm) {
+            row_stats<D, KS>(xv, h, a.eps, mean, rstd);
+            normalise<D, KS>(xv, h, mean, rstd, a.gamma, a.beta, xn);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xn[s][j] = (bf16_t)xv[s][j];
+        }
+        f32x16 dx[OT];
+        if constexpr (BWD) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int f0 = 16 * s + 8 * h;
+                if (ok && f0 < D) *reinterpret_cast<bf16x8 *>(a.xn + row * D + f0) = xn[s];
+            }
+            if (ok && h == 0 && a.norm) { a.mean[row] = mean; a.rstd[row] = rstd; }
+#pragma unroll
+            for (int u = 0; u < OT; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dx[u][i] = 0.f;
+        }
+#pragma unroll 1
+        for (int t = 0; t < HT; ++t) {
+            // x-half tiles need no product in the backward (their gradient arrives as dxT); D = 8 has both halves in tile 0
+            const bool need_h = !BWD || 32 * t + 31 >= DI;
+            f32x16 hacc;
+            if (need_h) hacc = hidden_tile<D, KS>(a.w, t, r, h, xn);
+            bf16x8 gp[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hid0 = 32 * t + 8 * g + 4 * h;           // 4 consecutive channels, all in one half (DI is a multiple of 16)
+                if (hid0 < DI) {                                    // x half: channel-first
+                    bf16_t *col = a.xT + ((size_t)b * DI + hid0) * a.L + l;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if constexpr (BWD) gp[g >> 1][4 * (g & 1) + c] = ok ? col[(size_t)c * a.L] : (bf16_t)0.f;
+                        else if (ok) col[(size_t)c * a.L] = (bf16_t)hacc[4 * g + c];
+                    }
+                } else {                                            // z half: channel-last, SiLU
+                    bf16_t *zp = a.sz + row * DI + (hid0 - DI);
+                    float v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = hacc[4 * g + c];
+                    if constexpr (BWD) {
+                        bf16x4 gq;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) gq[c] = (bf16_t)0.f;
+                        if (ok) gq = *reinterpret_cast<const bf16x4 *>(zp);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float sg = 1.f / (1.f + __expf(-v[c]));
+                            gp[g >> 1][4 * (g & 1) + c] = (bf16_t)((float)gq[c] * sg * fmaf(v[c], 1.f - sg, 1.f));
+                        }
+                    } else if (ok) {
+                        float o[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = v[c] / (1.f + __expf(-v[c]));
+                        store_bf16x4(zp, o[0], o[1], o[2], o[3]);
+                    }
+                }
+                if constexpr (BWD) {
+                    if (ok) {
+                        bf16x4 q;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) q[c] = gp[g >> 1][4 * (g & 1) + c];
+                        *reinterpret_cast<bf16x4 *>(a.gpre + row * HD + hid0) = q;
+                    }
+                }
+            }
+            if constexpr (BWD) {
+#pragma unroll
+                for (int u = 0; u < OT; ++u) {
+                    const int f = 32 * u + r;
+                    const bf16_t *wr = a.wt + (size_t)f * HD;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        dx[u] = mfma_bf16(perm_frag(wr, 32 * t + 16 * s2 + 4 * h, f < D), gp[s2], dx[u]);
+                }
+            }
+        }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int u = 0; u < OT; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = 32 * u + 8 * g + 4 * h;
+                    if (ok && f0 < D)
+                        store_bf16x4(a.dxn + row * D + f0, dx[u][4 * g], dx[u][4 * g + 1], dx[u][4 * g + 2], dx[u][4 * g + 3]);
+                }
+        }
+    }
+}
+
 int grid_for(long rows, int tiles_per_wg) {
     const long tiles = ((rows + 31) / 32 + tiles_per_wg - 1) / tiles_per_wg;
     return (int)(tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048);
@@ -459,4 +589,60 @@ VMASR_EXPORT int vmasr_mlp_bwd(const void *x, const void *gy, const float *gamma
     a.act_aug = static_cast<bf16_t *>(act_aug); a.gpre = static_cast<bf16_t *>(gpre); a.mean = mean; a.rstd = rstd;
     return x_dtype == VMASR_F32 ? launch<true, float>(a, d, static_cast<hipStream_t>(stream))
                                 : launch<true, bf16_t>(a, d, static_cast<hipStream_t>(stream));
+}
+
+template <bool BWD, typename TX>
+static int launch_inproj(const InProjArgs &a, int d, hipStream_t st) {
+    const dim3 grid(grid_for(a.rows, 4)), block(256);
+    const double sx = sizeof(TX);
+    const double bytes = (double)a.rows * d * (BWD ? sx + 2.0 * 2 + 2.0 * 4 * 2 : sx + 2.0 * 4);
+#define VMASR_INP_CASE(DD)                                                                                          \
+    case DD:                                                                                                        \
+        VMASR_LAUNCH(BWD ? VMASR_K_INPROJ_BWD : VMASR_K_INPROJ_FWD, bytes, (inproj_kernel<DD, TX, BWD>), grid, block, 0, st, a); \
+        break;
+    switch (d) {
+        VMASR_INP_CASE(8) VMASR_INP_CASE(16) VMASR_INP_CASE(32) VMASR_INP_CASE(64)
+        default: set_error("inproj: unsupported width %d", d); return VMASR_EINVAL;
+    }
+#undef VMASR_INP_CASE
+    return check_launch(BWD ? "inproj_bwd" : "inproj_fwd");
+}
+
+VMASR_EXPORT int vmasr_inproj_supported(int32_t d, int32_t d_proj, int64_t L) {
+    return (d == 8 || d == 16 || d == 32 || d == 64) && d_proj == 4 * d && L > 0 && L % 32 == 0;
+}
+
+VMASR_EXPORT int vmasr_inproj_fwd(const void *x, const float *gamma, const float *beta, float eps, const void *w, void *xT, void *sz,
+                                  int64_t rows, int32_t L, int32_t d, int32_t x_dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(x && w && xT && sz, VMASR_EINVAL, "inproj_fwd: null tensor");
+    VMASR_REQUIRE(vmasr_inproj_supported(d, 4 * d, L) && rows > 0 && rows % L == 0, VMASR_EINVAL,
+                  "inproj_fwd: need d in {8,16,32,64}, L a multiple of 32 and rows a multiple of L");
+    VMASR_REQUIRE(x_dtype == VMASR_F32 || x_dtype == VMASR_BF16, VMASR_EINVAL, "inproj_fwd: x must be fp32 or bf16");
+    VMASR_REQUIRE((!gamma) == (!beta), VMASR_EINVAL, "inproj_fwd: gamma and beta go together");
+    VMASR_REQUIRE(aligned_to(x, 16) && aligned_to(w, 16) && aligned_to(sz, 8) && aligned_to(xT, 2), VMASR_EINVAL, "inproj_fwd: unaligned");
+    InProjArgs a{};
+    a.x = x; a.gamma = gamma; a.beta = beta; a.norm = gamma ? 1 : 0; a.eps = eps; a.w = static_cast<const bf16_t *>(w);
+    a.xT = static_cast<bf16_t *>(xT); a.sz = static_cast<bf16_t *>(sz); a.rows = rows; a.L = L;
+    return x_dtype == VMASR_F32 ? launch_inproj<false, float>(a, d, static_cast<hipStream_t>(stream))
+                                : launch_inproj<false, bf16_t>(a, d, static_cast<hipStream_t>(stream));
+}
+
+VMASR_EXPORT int vmasr_inproj_bwd(const void *x, const float *gamma, const float *beta, float eps, const void *w, const void *wt,
+                                  const void *dxT, const void *dsz, void *dxn, void *xn, void *gpre, float *mean, float *rstd,
+                                  int64_t rows, int32_t L, int32_t d, int32_t x_dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(x && w && wt && dxT && dsz && dxn && xn && gpre, VMASR_EINVAL, "inproj_bwd: null tensor");
+    VMASR_REQUIRE(vmasr_inproj_supported(d, 4 * d, L) && rows > 0 && rows % L == 0, VMASR_EINVAL,
+                  "inproj_bwd: need d in {8,16,32,64}, L a multiple of 32 and rows a multiple of L");
+    VMASR_REQUIRE(x_dtype == VMASR_F32 || x_dtype == VMASR_BF16, VMASR_EINVAL, "inproj_bwd: x must be fp32 or bf16");
+    VMASR_REQUIRE((!gamma) == (!beta) && (!gamma || (mean && rstd)), VMASR_EINVAL, "inproj_bwd: gamma, beta, mean, rstd go together");
+    VMASR_REQUIRE(aligned_to(x, 16) && aligned_to(w, 16) && aligned_to(wt, 16) && aligned_to(dsz, 8) && aligned_to(dxn, 8) &&
+                      aligned_to(xn, 16) && aligned_to(gpre, 8), VMASR_EINVAL, "inproj_bwd: unaligned");
+    InProjArgs a{};
+    a.x = x; a.gamma = gamma; a.beta = beta; a.norm = gamma ? 1 : 0; a.eps = eps;
+    a.w = static_cast<const bf16_t *>(w); a.wt = static_cast<const bf16_t *>(wt);
+    a.xT = static_cast<bf16_t *>(const_cast<void *>(dxT)); a.sz = static_cast<bf16_t *>(const_cast<void *>(dsz));
+    a.dxn = static_cast<bf16_t *>(dxn); a.xn = static_cast<bf16_t *>(xn); a.gpre = static_cast<bf16_t *>(gpre);
+    a.mean = mean; a.rstd = rstd; a.rows = rows; a.L = L;
+    return x_dtype == VMASR_F32 ? launch_inproj<true, float>(a, d, static_cast<hipStream_t>(stream))
+                                : launch_inproj<true, bf16_t>(a, d, static_cast<hipStream_t>(stream));
 }

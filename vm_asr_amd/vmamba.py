@@ -35,6 +35,7 @@ from . import ss2d_core as _ss2d
 from . import ss2d_glue as _glue
 from . import xproj as _xproj
 from . import mlp as _mlp
+from . import inproj as _inproj
 from .dwconv import dwconv3x3_silu
 from .layernorm import LayerNorm
 from .linear import Linear as _Linear
@@ -373,12 +374,17 @@ class SS2D(nn.Module):
                 and fc.keywords.get("SelectiveScan") is SelectiveScanCore and fc.keywords.get("CrossScan") is CrossScanHIP
                 and fc.keywords.get("CrossMerge") is CrossMergeHIP and fc.keywords.get("force_fp32", False))
 
-    def forward(self, x: torch.Tensor, **kwargs):
-        x = self.in_proj(x)
-        if x.dim() == 4 and self._fused_glue_ok(x) and _glue.supported(self.d_inner, x.shape[1] * x.shape[2], x.dtype):
+    def forward(self, x: torch.Tensor, pre_norm=None, **kwargs):
+        """pre_norm: the block's LayerNorm (or nn.Identity) when the caller hands over the UN-normalised stream, so that
+        LayerNorm + in_proj + chunk + SiLU(z) + the channel-first copy can run as one MFMA kernel (vm_asr_amd/inproj.py)."""
+        fused_in = (pre_norm is not None and x.dim() == 4 and self._fused_glue_ok(x) and _inproj.supported(x, pre_norm, self.in_proj)
+                    and _glue.supported(self.d_inner, x.shape[1] * x.shape[2], torch.bfloat16))
+        if not fused_in:
+            x = self.in_proj(x if pre_norm is None else pre_norm(x))
+        if fused_in or (x.dim() == 4 and self._fused_glue_ok(x) and _glue.supported(self.d_inner, x.shape[1] * x.shape[2], x.dtype)):
             # chunk + SiLU(z) + layout copy as one kernel; LayerNorm + cast + gate (and the layout copy in front of
             # them) as another (csrc/ss2d_glue.hip)
-            xT, sz = _glue.ss2d_pre(x)
+            xT, sz = _inproj.fused_in_proj(x, pre_norm, self.in_proj) if fused_in else _glue.ss2d_pre(x)
             u = self._conv_act(xT)
             Bn, H, W = x.shape[0], x.shape[1], x.shape[2]
             if (self.k_group == 4 and _ss2d.supported(self.d_state, self.dt_rank, self.d_inner, H, W)
@@ -444,7 +450,7 @@ class VSSBlock(nn.Module):
             if self.post_norm:
                 x = input + self.drop_path(self.norm(self.op(input)))
             else:
-                x = self.drop_path.residual(input, self.op(self.norm(input)))
+                x = self.drop_path.residual(input, self.op(input, pre_norm=self.norm))
         if self.mlp_branch:
             if self.post_norm:
                 x = x + self.drop_path(self.norm2(self.mlp(x)))
