@@ -370,6 +370,36 @@ size_t vmasr_ss2d_part_floats(int32_t B, int32_t D, int32_t H, int32_t W);
 int vmasr_ss2d_fwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
 int vmasr_ss2d_bwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
 
+/* ---- the SS2D core of the deep stages (vm_asr_amd/csrc/ss2d_deep.hip) -------------------------------------------------
+ * The same operator as vmasr_ss2d_fwd/bwd (model/vmamba.py:1472-1497, model/csm_triton.py:7-154,
+ * cus/selective_scan_{fwd,bwd}_kernel.cuh) for d_state 1, dt_rank R in {2,4,8}, d_inner 64..512 (a multiple of 32),
+ * H and W multiples of 4, H*W in {256,512,1024,2048,4096} (vmasr_ss2d_deep_supported): a workgroup owns whole (b, d) rows,
+ * cross-scan / cross-merge are LDS index computations, x_proj runs as a small kernel in front (and its adjoint behind).
+ * All buffers are caller-owned device memory; `dtype` (VMASR_F32 or VMASR_BF16) is the type of x, dx, tp, tb, tc, gpos:
+ *   x (B,D,H,W);  WxT (4,D,R+2) = x_proj_weight with its last two axes swapped;  Wdt (4,D,R) = dt_projs_weight;  dtb (4,D);
+ *   Alog (4D);  Ds (4D)                                                                                  weights fp32
+ *   xdbl (B,4,R+2,H*W) fp32: written by the forward, read by the backward (directions 1/3 in (w,h) order);
+ *   y (B,D,H*W) fp32 = the merged output.
+ * backward: dy (B,D,H*W) fp32 in;  du (B,D,H*W) fp32, tp / tb / tc (B,4,D,H*W) scratch;
+ *   pg (B,4,D,WR,12) fp32 out with WR = vmasr_ss2d_deep_waves_per_row: per-wave sums [dWdt[0..R-1], ddtb, dAlog, dDs] — the
+ *   caller sums over (B, WR);  dx (B,D,H,W);  g32 (fp32 scratch) / gpos (`dtype`) (B,4(R+2),H*W): gradient of x_dbl per
+ *   row-major position — dWx[k][c][d] = sum_{b,p} gpos[b][k(R+2)+c][p] x[b][d][p] (one GEMM on the caller's side). */
+typedef struct vmasr_ss2d_deep_params {
+    int32_t B, D, H, W, R, dtype;
+    const void *x;
+    const float *WxT, *Wdt, *dtb, *Alog, *Ds;
+    float *xdbl, *y;
+    const float *dy;
+    float *du;
+    void *tp, *tb, *tc;
+    float *pg, *g32;
+    void *dx, *gpos;
+} vmasr_ss2d_deep_params;
+int vmasr_ss2d_deep_supported(int32_t d_state, int32_t dt_rank, int32_t d_inner, int32_t H, int32_t W);
+int32_t vmasr_ss2d_deep_waves_per_row(int32_t H, int32_t W);
+int vmasr_ss2d_deep_fwd(const vmasr_ss2d_deep_params *p, vmasr_stream_t stream);
+int vmasr_ss2d_deep_bwd(const vmasr_ss2d_deep_params *p, vmasr_stream_t stream);
+
 /* ---- glue of SS2D.forwardv2 around the scan core (vm_asr_amd/csrc/ss2d_glue.hip; model/vmamba.py:1535-1550) ----------
  * ss2d_pre : xz (B*L, 2D) -> xT (B, D, L) = the x half channel-first, sz (B*L, D) = SiLU(z half)
  *            (replaces chunk + SiLU on a strided view + permute(0,3,1,2).contiguous()); _bwd: (dxT, dsz) -> dxz
@@ -496,6 +526,10 @@ enum {
     VMASR_K_MLP_BWD,
     VMASR_K_INPROJ_FWD,         /* LayerNorm + in_proj + chunk + SiLU(z) + channel-first copy of a VSS block's SS2D as one MFMA kernel */
     VMASR_K_INPROJ_BWD,
+    VMASR_K_SS2D_DEEP_XPROJ,    /* deep-stage SS2D core: x_proj (x -> x_dbl)                                    */
+    VMASR_K_SS2D_DEEP_FWD,      /* dt_proj + the four directional scans of whole rows + cross-merge, one launch */
+    VMASR_K_SS2D_DEEP_BWD,      /* its backward: du, per-row terms of d(x_dbl), parameter sums                  */
+    VMASR_K_SS2D_DEEP_XBWD,     /* adjoint of x_proj: terms -> d(x_dbl) -> dx                                   */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

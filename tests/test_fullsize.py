@@ -205,7 +205,7 @@ def test_f64ref_equals_float64_reference(tag):
     assert y.dtype == np.float64 and np.abs(y - y64).max() <= 1e-9 * np.abs(y64).max()
 
 
-N_CLIPS, GM_RMS, GM_MAX = 8, 1.6, 1.9
+N_CLIPS, GM_RMS, GM_MAX = int(os.environ.get("VMASR_TEST_CLIPS", "16")), 1.6, 1.9
 
 
 @pytest.mark.gpu
@@ -221,7 +221,12 @@ def test_fullsize_forward_hip_error_distribution(tag):
     (tools/accuracy_probe.py --ops); what remains at network level (~1.2x) is within two standard errors of 1 and has
     one known contributor: hipBLASLt's fp32 GEMMs are 1.4 .. 1.7x further from float64 than MKL's for K >= 256
     (tools/linear_accuracy.py; accumulation order), and the Linear layers are the largest single-family term of the
-    final error in three of the four configs (isolation runs in the same log)."""
+    final error in three of the four configs (isolation runs in the same log).
+    16 clips since the deep-stage core (csrc/ss2d_deep.hip) went in: with 8 the statistic's own scatter (+-15 %) reached the
+    bound on one config; over 16 clips 1.41 / 1.17 / 1.51 / 1.19 (RMS; worst sample 1.62 / 1.16 / 1.63 / 1.22) with the deep
+    core and 1.35 / 1.21 / 1.41 / 1.13 (1.56 / 1.21 / 1.44 / 1.07) with the unfused chain on the same clips — no difference
+    beyond the standard error of ~0.1; at operator level the deep core's output is as far from float64 as the oracle chain's
+    (ratio 1.00, tests/test_ss2d_deep.py)."""
     import f64ref
     from oracle.torch_backend import oracle_stft_patch, use_oracle
     (dims, n_fft, win, hop), wave0, target, hf, y32, y64, lsd_ref = _case(tag)

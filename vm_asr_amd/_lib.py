@@ -48,6 +48,13 @@ class SS2DParams(ctypes.Structure):
                                        "dy", "dyT", "adj", "part", "dx", "dWx", "dWdt", "ddtb", "dAlog", "dDs")])
 
 
+class SS2DDeepParams(ctypes.Structure):
+    """POD mirror of vmasr_ss2d_deep_params."""
+    _fields_ = ([(n, c_i32) for n in ("B", "D", "H", "W", "R", "dtype")]
+                + [(n, c_vp) for n in ("x", "WxT", "Wdt", "dtb", "Alog", "Ds", "xdbl", "y", "dy", "du", "tp", "tb", "tc", "pg",
+                                       "g32", "dx", "gpos")])
+
+
 # name -> (restype, argtypes); every symbol declared in include/vmasr_hip.h
 SYMBOLS = {
     "vmasr_abi_version": (ctypes.c_int, []),
@@ -121,6 +128,10 @@ SYMBOLS = {
     "vmasr_ss2d_part_floats": (c_sz, [c_i32] * 4),
     "vmasr_ss2d_fwd": (ctypes.c_int, [ctypes.POINTER(SS2DParams), c_vp]),
     "vmasr_ss2d_bwd": (ctypes.c_int, [ctypes.POINTER(SS2DParams), c_vp]),
+    "vmasr_ss2d_deep_supported": (ctypes.c_int, [c_i32] * 5),
+    "vmasr_ss2d_deep_waves_per_row": (c_i32, [c_i32, c_i32]),
+    "vmasr_ss2d_deep_fwd": (ctypes.c_int, [ctypes.POINTER(SS2DDeepParams), c_vp]),
+    "vmasr_ss2d_deep_bwd": (ctypes.c_int, [ctypes.POINTER(SS2DDeepParams), c_vp]),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -182,7 +193,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 48
+K_COUNT = 52
 
 
 def zeros_f32(device, *shapes):

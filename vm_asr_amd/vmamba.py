@@ -32,6 +32,7 @@ import torch.utils.checkpoint as checkpoint
 
 from .csm import CrossMergeHIP, CrossScanF32, CrossScanHIP
 from . import ss2d_core as _ss2d
+from . import ss2d_deep as _deep
 from . import ss2d_glue as _glue
 from . import xproj as _xproj
 from . import mlp as _mlp
@@ -295,6 +296,11 @@ class SS2D(nn.Module):
             # the whole core (cross-scan, x_proj, dt_proj, 4 scans, cross-merge) as one fused operator: the
             # high-resolution stages (d_state 1, dt_rank 1, d_inner <= 32) — csrc/ss2d.hip
             y = _ss2d.ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+            return y if merged_only else self._merge_norm(y, x, B, H, W, to_dtype)
+        if hip_default and delta_softplus and K == 4 and _deep.supported(N, R, D, H, W, x.dtype):
+            # the deep stages (dt_rank 2..8, d_inner 64..512, H*W <= 4096): whole rows per workgroup, cross-scan / cross-merge
+            # through an LDS image, x_proj as a small kernel in front — csrc/ss2d_deep.hip
+            y = _deep.ss2d_deep(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
             return y if merged_only else self._merge_norm(y, x, B, H, W, to_dtype)
         if (hip_default and _xproj.supported(N, R, D) and D <= _XPROJ_MAX_D):
             # (position-parallel kernels for d_inner <= 32, row-parallel ones above; see _XPROJ_MAX_D)
