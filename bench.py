@@ -4,7 +4,7 @@
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A step = one pass of the hot path over one batch of synthetic VCTK-shaped clips resident in
-HBM: generator forward (HIP STFT -> 34 SS2D calls/stream-pair -> HIP iSTFT) under bf16 autocast
+HBM: generator forward (HIP STFT -> 28 SS2D calls -> HIP iSTFT) under bf16 autocast
 (scan fp32, as the reference's forward type v5 forces), MR-STFT + LSGAN + feature losses against
 the 41 M-parameter MPD, backward, AdamW for G and D — `configs/vm_asr_48k_MPD.yaml` of the
 reference as written (per-GPU batch 4, DIMS 16).  N GPUs = N processes, batch sharded by clip,
@@ -173,15 +173,18 @@ def run_point(config, args, device, rank, world, steps, warmup, timing):
     return dt, graphed, per_rank, prof
 
 
-SCAN_KERNELS = ("ss2d_fwd_agg", "ss2d_fwd_apply", "ss2d_bwd_agg", "ss2d_bwd_apply", "ss2d_carry")
-SCAN_BYTES_IN = ("sscan_fwd", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_apply", "ss2d_fwd_apply", "ss2d_bwd_apply")
+SCAN_KERNELS = ("ss2d_fwd_agg", "ss2d_fwd_apply", "ss2d_bwd_agg", "ss2d_bwd_apply", "ss2d_carry", "ss2d_deep_fwd", "ss2d_deep_bwd")
+SCAN_BYTES_IN = ("sscan_fwd", "sscan_fwd_apply", "sscan_bwd", "sscan_bwd_apply", "ss2d_fwd_apply", "ss2d_bwd_apply", "ss2d_deep_fwd",
+                 "ss2d_deep_bwd")
 
 
 def scan_summary(prof, steps):
     """(kernel table, dominant scan kernel name, op-level dict) from the library's event records.
-    The selective-scan operator = sscan.hip's kernels (deep stages) + the scan kernels of the fused SS2D core (ss2d.hip:
-    aggregate / carry / apply; its transpose and pair-merge kernels are what is left of cross-scan / cross-merge and are
-    listed in the table, not counted here); algorithmic bytes are counted once per op (the apply / single-pass kernels carry them)."""
+    The selective-scan operator = the scan kernels of the two fused SS2D cores (ss2d.hip: aggregate / carry / apply — its
+    transpose and pair-merge kernels are what is left of cross-scan / cross-merge and are listed in the table, not counted here;
+    ss2d_deep.hip: the whole-row forward / backward kernels — its x_proj kernels are listed, not counted) + sscan.hip's kernels
+    where a call still takes the unfused path; algorithmic bytes are counted once per op (the apply / single-pass kernels carry
+    them)."""
     kern = {k: dict(v, avg_us=v["ms"] / v["launches"] * 1e3, gbs=v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)
             for k, v in prof.items()}
     scan = {k: v for k, v in kern.items() if k.startswith("sscan") or k in SCAN_KERNELS}

@@ -44,6 +44,9 @@ int main(void){
          offsetof(vmasr_sscan_params, A_ptr), offsetof(vmasr_sscan_params, x_ptr),
          sizeof(vmasr_sscan_bwd_params), offsetof(vmasr_sscan_bwd_params, ws_bytes),
          sizeof(vmasr_spectral_item), offsetof(vmasr_spectral_item, R), offsetof(vmasr_spectral_item, col_tile_start));
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(vmasr_ss2d_params), offsetof(vmasr_ss2d_params, x), offsetof(vmasr_ss2d_params, dDs),
+         sizeof(vmasr_ss2d_deep_params), offsetof(vmasr_ss2d_deep_params, x), offsetof(vmasr_ss2d_deep_params, g32),
+         offsetof(vmasr_ss2d_deep_params, gpos));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -56,6 +59,8 @@ int main(void){
     # vmasr_spectral_item is written from numpy (vm_asr_amd/discriminator.py:SpectralBatch): 5 pointers + 4 int32
     want = [ctypes.sizeof(P), P.A_d_stride.offset, P.A_ptr.offset, P.x_ptr.offset, ctypes.sizeof(Q), Q.ws_bytes.offset,
             56, 40, 52]
+    S, D = _lib.SS2DParams, _lib.SS2DDeepParams
+    want += [ctypes.sizeof(S), S.x.offset, S.dDs.offset, ctypes.sizeof(D), D.x.offset, D.g32.offset, D.gpos.offset]
     assert got == want
 
 

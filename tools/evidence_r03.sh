@@ -20,6 +20,7 @@ python bench.py --batch 8 --no-cpu-baseline --no-extra-points > $O/bench_b8.json
 python bench.py --workload vm_asr_48k --no-cpu-baseline > $O/bench_gonly_b35.json 2> /dev/null
 python bench.py --amp-scope step --no-cpu-baseline --no-extra-points > $O/bench_amp_step.json 2> /dev/null
 B=4 python tools/bench_ss2d.py > $O/ss2d_microbench.log 2>&1
+B=4 python tools/bench_ss2d_deep.py 2>&1 | grep -v amdgpu > $O/ss2d_deep_microbench.log
 python tools/bench_mlp.py 2>&1 | grep -v amdgpu > $O/mlp_microbench.log
 for B in 4 32; do SWEEP=0 B=$B timeout 300 python tools/bench_scan.py 2>&1 | grep -v amdgpu; done > $O/scan_microbench.log
 python tools/accuracy_probe.py --ops --core-shapes --families "" --cases "" 2>&1 | grep -v amdgpu > $O/accuracy_ops.log

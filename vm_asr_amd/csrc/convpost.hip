@@ -10,7 +10,7 @@
 //   bwd : dx[s, q, c] = sum_j gy[s, q - j + 1] w[s, j, c]                  one pass: reads x (for dw) and gy, writes dx
 //         dw[s, j, c] += sum_r gy[s, r] x[s, r + j - 1, c],  db[s] += sum_r gy[s, r]
 // A wave owns a run of consecutive rows; lane l holds channels {4l..4l+3} + 256 i of the three taps in registers
-// (C = 256 VPL, VPL <= 4), walks its rows once with three rotating per-lane partial sums (the row just read completes the
+// (C = 256 VPL, VPL <= 4), walks its rows (8 .. 32 of them) once with three rotating per-lane partial sums (the row just read completes the
 // output one row up) and reduces each finished output over the wave with DPP.  HBM-bound streaming, no LDS.
 #include <algorithm>
 
@@ -20,8 +20,11 @@ namespace vmasr {
 namespace {
 
 constexpr int kCpSlots = 8;
-constexpr int kCpRunFwd = 32;    // rows per wave
-constexpr int kCpRunBwd = 64;
+// rows per wave (a launch argument): the maps are only ~10^4 rows per slot, so long runs leave the chip with < 6 waves per CU
+// and one row load in flight per wave — measured 2.0 TB/s at 32 / 64 rows per wave.  Short runs re-read two neighbour rows per
+// run (L2 hits); the weight-gradient variant folds 3 C sums per workgroup into atomics, so it keeps longer runs.
+constexpr int kCpRunFwd = 8;
+constexpr int kCpRunBwdDx = 8, kCpRunBwdDw = 32;
 
 struct CpSlots {
     long M[kCpSlots];
@@ -39,12 +42,12 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (
 // grid (ceil(rows / (4 * RUN)), n), 4 waves per block
 template <int VPL>
 __global__ __launch_bounds__(256) void conv_post_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
-                                                            float *__restrict__ y, const CpSlots t, const long rows) {
+                                                            float *__restrict__ y, const CpSlots t, const long rows, const int run) {
     constexpr int C = VPL * 256;
     const int s = blockIdx.y, lane = threadIdx.x & 63;
-    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kCpRunFwd;
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * run;
     if (r0 >= rows) return;
-    const long M = t.M[s], r1 = std::min(rows, r0 + kCpRunFwd);
+    const long M = t.M[s], r1 = std::min(rows, r0 + run);
     const int H = t.H[s];
     const float *xs = x + (size_t)s * rows * C;
     float *ys = y + (size_t)s * rows;
@@ -80,11 +83,11 @@ __global__ __launch_bounds__(256) void conv_post_fwd_kernel(const float *__restr
 template <int VPL>
 __global__ __launch_bounds__(256) void conv_post_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ gy,
                                                             float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db,
-                                                            const CpSlots t, const long rows) {
+                                                            const CpSlots t, const long rows, const int run) {
     constexpr int C = VPL * 256;
     const int s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long r0 = ((long)blockIdx.x * 4 + wave) * kCpRunBwd;
-    const long M = t.M[s], r1 = std::min(rows, r0 + kCpRunBwd);
+    const long r0 = ((long)blockIdx.x * 4 + wave) * run;
+    const long M = t.M[s], r1 = std::min(rows, r0 + run);
     const int H = t.H[s];
     const float *xs = x + (size_t)s * rows * C, *gs = gy + (size_t)s * rows;
     float4 w0[VPL], w1[VPL], w2[VPL], d0[VPL], d1[VPL], d2[VPL];
@@ -177,10 +180,10 @@ VMASR_EXPORT int vmasr_conv_post_fwd(const float *x, const float *w, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double bytes = (double)n * rows * (C + 1) * 4.0;
     switch (C / 256) {
-        case 1: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_fwd_kernel<1>, grid, dim3(256), 0, st, x, w, b, y, t, (long)rows); break;
-        case 2: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_fwd_kernel<2>, grid, dim3(256), 0, st, x, w, b, y, t, (long)rows); break;
-        case 3: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_fwd_kernel<3>, grid, dim3(256), 0, st, x, w, b, y, t, (long)rows); break;
-        default: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_fwd_kernel<4>, grid, dim3(256), 0, st, x, w, b, y, t, (long)rows); break;
+        case 1: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_fwd_kernel<1>, grid, dim3(256), 0, st, x, w, b, y, t, (long)rows, kCpRunFwd); break;
+        case 2: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_fwd_kernel<2>, grid, dim3(256), 0, st, x, w, b, y, t, (long)rows, kCpRunFwd); break;
+        case 3: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_fwd_kernel<3>, grid, dim3(256), 0, st, x, w, b, y, t, (long)rows, kCpRunFwd); break;
+        default: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_fwd_kernel<4>, grid, dim3(256), 0, st, x, w, b, y, t, (long)rows, kCpRunFwd); break;
     }
     return check_launch("conv_post_fwd");
 }
@@ -193,14 +196,15 @@ VMASR_EXPORT int vmasr_conv_post_bwd(const float *x, const float *w, const float
     VMASR_REQUIRE(aligned_to(x, 16) && aligned_to(w, 16) && (!dx || aligned_to(dx, 16)) && (!dw || aligned_to(dw, 16)), VMASR_EINVAL,
                   "conv_post_bwd: unaligned");
     if (!dx && !dw && !db) return VMASR_OK;
-    const dim3 grid((unsigned)((rows + 4 * kCpRunBwd - 1) / (4 * kCpRunBwd)), n);
+    const int run = dw ? kCpRunBwdDw : kCpRunBwdDx;
+    const dim3 grid((unsigned)((rows + 4 * run - 1) / (4 * run)), n);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double bytes = (double)n * rows * ((dw ? C : 0) + (dx ? C : 0) + 1.0) * 4.0;
     switch (C / 256) {
-        case 1: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<1>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows); break;
-        case 2: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<2>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows); break;
-        case 3: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<3>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows); break;
-        default: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<4>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows); break;
+        case 1: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<1>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run); break;
+        case 2: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<2>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run); break;
+        case 3: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<3>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run); break;
+        default: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<4>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run); break;
     }
     return check_launch("conv_post_bwd");
 }

@@ -7,7 +7,7 @@
 // skip convolution, fp32 elsewhere) with d in {8, 16, 32, 64, 128} and hidden = 4 d — every Mlp of every shipped
 // config except the d_model = 1 block (csrc/linear.hip) and dims-32's deepest stage.  Under bf16 autocast the reference
 // runs this as LayerNorm -> cast -> GEMM -> bias -> GELU -> GEMM -> bias -> add: 6-7 launches forward and ~13 backward
-// per block over tensors of 0.1-8 MB, i.e. at the launch-latency floor (34 blocks per generator pass).
+// per block over tensors of 0.1-8 MB, i.e. at the launch-latency floor (28 blocks per generator pass).
 //
 // MI355X-first design (not a GEMM library call): a WAVE owns 32 rows of x and never talks to another wave.  Both
 // products run TRANSPOSED on v_mfma_f32_32x32x16_bf16 so that the data row is the accumulator's lane (column) index:

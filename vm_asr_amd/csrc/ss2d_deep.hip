@@ -1,6 +1,6 @@
 // ss2d_deep.hip — the SS2D core of the DEEP stages as one operator for gfx950: d_state 1, dt_rank 2 / 4 / 8,
-// d_inner 64 .. 512, H*W in {256, 512, 1024, 2048, 4096} (the 64x64, 32x32 and 16x16 stages of every shipped config: 24 of the
-// 34 SS2D calls of a training step).
+// d_inner 64 .. 512, H*W in {256, 512, 1024, 2048, 4096} (the 64x64, 32x32 and 16x16 stages of every shipped config: 18 of the
+// 28 SS2D calls of a training step).
 //
 // Replaces, for those calls, the chain of SS2D.forward_corev2 (model/vmamba.py:1472-1497):
 //     xs = CrossScan(x)                                     model/csm_triton.py:7-79
@@ -28,6 +28,9 @@
 // Numerics: as ss2d.hip (fp32 everywhere, activations converted on load, decay_f / softplus_f of scan_prims.h).
 #include "common.h"
 #include "scan_prims.h"
+
+#include <mutex>
+#include <unordered_set>
 
 namespace vmasr {
 namespace {
@@ -125,19 +128,21 @@ __device__ __forceinline__ float carry_in(const float2 *tot, const int q, const 
     return h;
 }
 
-// padded LDS image of one row: element (h, w) at h W + w + (h >> 2) — the column-wise readers (4 consecutive h per lane,
-// lanes 4 rows apart) land on consecutive banks instead of one
-__host__ __device__ __forceinline__ int img_floats(const int H, const int W) { return (H * W + H / 4 + 7) & ~3; }
+// padded LDS image of one row: element (h, w) at h W + w + (h >> 2) S with S = max(1, 128 / H) — the column-wise readers (4
+// consecutive h per lane, 32 lanes = 128 / H columns of H / 4 lanes) land on 32 different banks instead of one
+__host__ __device__ __forceinline__ int img_pad(const int H) { return H >= 128 ? 1 : 128 / H; }
+__host__ __device__ __forceinline__ int img_floats(const int H, const int W) { return (H * W + (H / 4) * img_pad(H) + 7) & ~3; }
 struct Img {
     int base_r, idx_c[4];   // row-phase: base_r + i ; column-phase: idx_c[i]
 };
 __device__ __forceinline__ Img img_index(const DeepGeo &g, const int l0) {
     Img m;
+    const int S = img_pad(g.H);
     const int hr = l0 / g.W;
-    m.base_r = l0 + (hr >> 2);
+    m.base_r = l0 + (hr >> 2) * S;
     const int wc = l0 / g.H, h0 = l0 - wc * g.H;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m.idx_c[i] = (h0 + i) * g.W + wc + (h0 >> 2);
+    for (int i = 0; i < 4; ++i) m.idx_c[i] = (h0 + i) * g.W + wc + (h0 >> 2) * S;
     return m;
 }
 
@@ -521,9 +526,16 @@ size_t scan_lds(const DeepCfg &c, int H, int W, int images, int tots) {
     return ((size_t)c.RG * images * IMG) * 4 + (size_t)c.RG * tots * c.WR * 8;
 }
 
+// workgroups above 64 KB of dynamic LDS (the backward's six row images at H*W = 4096: 99 KB of the CU's 160 KB) need the
+// function attribute; set once per kernel
 template <typename K>
 void allow_lds(K kernel, size_t bytes) {
-    if (bytes > 32 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (bytes <= 32 * 1024) return;
+    static std::mutex mu;
+    static std::unordered_set<const void *> done;
+    const void *f = reinterpret_cast<const void *>(kernel);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert(f).second) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 #define DEEP_WRRG(KERNEL, T, R, ...)                                              \

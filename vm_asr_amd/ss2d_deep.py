@@ -2,7 +2,7 @@
 
 `ss2d_deep(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)` = lines 1472-1497 of
 SS2D.forward_corev2 (model/vmamba.py: CrossScan -> x_proj / dt_proj einsums -> selective_scan -> CrossMerge) for d_state 1,
-dt_rank 2 / 4 / 8, d_inner 64..512, H*W <= 4096: the 64x64, 32x32 and 16x16 stages — 24 of the 34 SS2D calls of a training step,
+dt_rank 2 / 4 / 8, d_inner 64..512, H*W <= 4096: the 64x64, 32x32 and 16x16 stages — 18 of the 28 SS2D calls of a training step,
 which vm_asr_amd/ss2d_core.py (d_inner <= 32, dt_rank 1) does not take.  Forward = 2 launches, backward = 3 launches + one small
 GEMM (dW_x) and one sum (the per-wave parameter sums) — where the unfused chain ran 4 + 6 launches and their ATen glue.
 """
