@@ -372,7 +372,7 @@ int vmasr_ss2d_bwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
 
 /* ---- the SS2D core of the deep stages (vm_asr_amd/csrc/ss2d_deep.hip) -------------------------------------------------
  * The same operator as vmasr_ss2d_fwd/bwd (model/vmamba.py:1472-1497, model/csm_triton.py:7-154,
- * cus/selective_scan_{fwd,bwd}_kernel.cuh) for d_state 1, dt_rank R in {2,4,8}, d_inner 64..512 (a multiple of 32),
+ * cus/selective_scan_{fwd,bwd}_kernel.cuh) for d_state 1, dt_rank R in {2,4,8} (16 for H*W <= 512), d_inner 64..512 (a multiple of 32),
  * H and W multiples of 4, H*W in {256,512,1024,2048,4096} (vmasr_ss2d_deep_supported): a workgroup owns whole (b, d) rows,
  * cross-scan / cross-merge are LDS index computations, x_proj runs as a small kernel in front (and its adjoint behind).
  * All buffers are caller-owned device memory; `dtype` (VMASR_F32 or VMASR_BF16) is the type of x, dx, tp, tb, tc, gpos:
@@ -381,7 +381,7 @@ int vmasr_ss2d_bwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
  *   xdbl (B,4,R+2,H*W) fp32: written by the forward, read by the backward (directions 1/3 in (w,h) order);
  *   y (B,D,H*W) fp32 = the merged output.
  * backward: dy (B,D,H*W) fp32 in;  du (B,D,H*W) fp32, tp / tb / tc (B,4,D,H*W) scratch;
- *   pg (B,4,D,WR,12) fp32 out with WR = vmasr_ss2d_deep_waves_per_row: per-wave sums [dWdt[0..R-1], ddtb, dAlog, dDs] — the
+ *   pg (B,4,D,WR,20) fp32 out with WR = vmasr_ss2d_deep_waves_per_row: per-wave sums [dWdt[0..R-1], ddtb, dAlog, dDs] — the
  *   caller sums over (B, WR);  dx (B,D,H,W);  g32 (fp32 scratch) / gpos (`dtype`) (B,4(R+2),H*W): gradient of x_dbl per
  *   row-major position — dWx[k][c][d] = sum_{b,p} gpos[b][k(R+2)+c][p] x[b][d][p] (one GEMM on the caller's side). */
 typedef struct vmasr_ss2d_deep_params {

@@ -1,4 +1,4 @@
-// ss2d_deep.hip — the SS2D core of the DEEP stages as one operator for gfx950: d_state 1, dt_rank 2 / 4 / 8,
+// ss2d_deep.hip — the SS2D core of the DEEP stages as one operator for gfx950: d_state 1, dt_rank 2 / 4 / 8 (16 for H*W <= 512),
 // d_inner 64 .. 512, H*W in {256, 512, 1024, 2048, 4096} (the 64x64, 32x32 and 16x16 stages of every shipped config: 18 of the
 // 28 SS2D calls of a training step).
 //
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * WR * RG) void deep_fwd_kernel(const DeepFwdArg
 // x_dbl:  tp = d(loss)/d(pre-softplus delta)  (d dt_r = sum_d W_dt[d][r] tp),  tb = g delta u (dB = sum_d tb),
 // tc = dy h (dC = sum_d tc).  All four directions' terms are written in ROW-MAJOR position order (the column-wise
 // directions go back through the LDS image), so the adjoint of x_proj (deep_xg_kernel) is position-parallel and coalesced.
-constexpr int kPG = 12;   // per-(b, direction, row, wave) parameter sums: dWdt[0..R-1], dbias, dAlog, dD (R + 3 <= 11)
+constexpr int kPG = 20;   // per-(b, direction, row, wave) parameter sums: dWdt[0..R-1], dbias, dAlog, dD (R + 3 <= 19)
 struct DeepBwdArgs {
     const void *x;
     const float *xdbl, *dy;   // dy (B, D, L) fp32: gradient of the merged output
@@ -342,15 +342,18 @@ __device__ __forceinline__ void bwd_dir(const int k, const int q, const int lane
         v[R] = accBias; v[R + 1] = accA * w.A; v[R + 2] = accD;    // dA_log = dA * A
         const float s8 = wave_sum8(v, lane);
         if (lane < R + 3) pg[lane] = s8;
-    } else {
-        float v[8];
+    } else {                                   // R = 8, 16: butterflies of 8 for dWdt, one of 4 for the rest
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = accDt[r];
-        const float s8 = wave_sum8(v, lane);
+        for (int r0 = 0; r0 < R; r0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = accDt[r0 + r];
+            const float s8 = wave_sum8(v, lane);
+            if (lane < 8) pg[r0 + lane] = s8;
+        }
         const float v4[4] = {accBias, accA * w.A, accD, 0.f};
         const float s4 = wave_sum4(v4, lane);
-        if (lane < 8) pg[lane] = s8;
-        else if (lane < 11) pg[lane] = s4;     // lane 8, 9, 10 hold the totals of v4[0], v4[1], v4[2]
+        if (lane < 3) pg[R + lane] = s4;       // lane l holds the total of v4[l & 3]
     }
 }
 
@@ -509,13 +512,14 @@ struct DeepCfg {
     int WR, RG, NW;
 };
 bool deep_cfg(int R, int D, int H, int W, DeepCfg &c) {
-    if (!(R == 2 || R == 4 || R == 8)) return false;
+    if (!(R == 2 || R == 4 || R == 8 || R == 16)) return false;
     if (D < 64 || D > 512 || D % 32) return false;
     if (H % 4 || W % 4) return false;
     const long L = (long)H * W;
     if (L % kTile || L > 4096) return false;
     const int WR = (int)(L / kTile);
     if (!(WR == 1 || WR == 2 || WR == 4 || WR == 8 || WR == 16)) return false;
+    if (R == 16 && WR > 2) return false;     // (dt_rank 16 = d_inner 512: the 16 x 16 stage of the DIMS-32 configs)
     c.WR = WR;
     c.RG = WR >= 8 ? 1 : (WR >= 2 ? 2 : 4);
     c.NW = D >= 256 ? 16 : 8;
@@ -550,7 +554,9 @@ void allow_lds(K kernel, size_t bytes) {
     do {                                                                          \
         if (p.R == 2) DEEP_WRRG(KERNEL, T, 2, __VA_ARGS__);                       \
         else if (p.R == 4) DEEP_WRRG(KERNEL, T, 4, __VA_ARGS__);                  \
-        else DEEP_WRRG(KERNEL, T, 8, __VA_ARGS__);                                \
+        else if (p.R == 8) DEEP_WRRG(KERNEL, T, 8, __VA_ARGS__);                  \
+        else if (c.WR == 1) { DEEP_GO((KERNEL<T, 16, 1, 4>), __VA_ARGS__); }      \
+        else { DEEP_GO((KERNEL<T, 16, 2, 2>), __VA_ARGS__); }   /* dt_rank 16: H*W <= 512 only (deep_cfg) */ \
     } while (0)
 #define DEEP_NW(KERNEL, T, R, ...)                                                \
     do {                                                                          \
@@ -561,7 +567,8 @@ void allow_lds(K kernel, size_t bytes) {
     do {                                                                          \
         if (p.R == 2) DEEP_NW(KERNEL, T, 2, __VA_ARGS__);                         \
         else if (p.R == 4) DEEP_NW(KERNEL, T, 4, __VA_ARGS__);                    \
-        else DEEP_NW(KERNEL, T, 8, __VA_ARGS__);                                  \
+        else if (p.R == 8) DEEP_NW(KERNEL, T, 8, __VA_ARGS__);                    \
+        else DEEP_NW(KERNEL, T, 16, __VA_ARGS__);                                 \
     } while (0)
 
 template <typename T>
@@ -616,6 +623,7 @@ int deep_bwd(const vmasr_ss2d_deep_params &p, const DeepCfg &c, hipStream_t st) 
         T *dx = static_cast<T *>(p.dx);
         if (p.R == 2) VMASR_LAUNCH(VMASR_K_SS2D_DEEP_XBWD, bytes, (deep_dx_kernel<T, 2>), grid, block, 0, st, p.g32, p.du, p.WxT, dx, g);
         else if (p.R == 4) VMASR_LAUNCH(VMASR_K_SS2D_DEEP_XBWD, bytes, (deep_dx_kernel<T, 4>), grid, block, 0, st, p.g32, p.du, p.WxT, dx, g);
+        else if (p.R == 16) VMASR_LAUNCH(VMASR_K_SS2D_DEEP_XBWD, bytes, (deep_dx_kernel<T, 16>), grid, block, 0, st, p.g32, p.du, p.WxT, dx, g);
         else VMASR_LAUNCH(VMASR_K_SS2D_DEEP_XBWD, bytes, (deep_dx_kernel<T, 8>), grid, block, 0, st, p.g32, p.du, p.WxT, dx, g);
     }
     return check_launch("ss2d_deep_bwd");

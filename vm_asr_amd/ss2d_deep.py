@@ -73,7 +73,7 @@ class _SS2DDeepFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             du = torch.empty((B, D, L), dtype=torch.float32, device=x.device)
             terms = torch.empty((3, B, 4, D, L), dtype=x.dtype, device=x.device)
-            pg = torch.empty((B, 4, D, WR, 12), dtype=torch.float32, device=x.device)
+            pg = torch.empty((B, 4, D, WR, 20), dtype=torch.float32, device=x.device)
             dx = torch.empty_like(x)
             gpos = torch.empty((B, 4 * C, L), dtype=x.dtype, device=x.device)
             g32 = torch.empty((B, 4 * C, L), dtype=torch.float32, device=x.device)
