@@ -339,6 +339,10 @@ int vmasr_masked_l1_fwd(const float *real, const float *gen, void *sgn, double *
                         int32_t n, int64_t rows_r, int64_t rows_g, int32_t N, vmasr_stream_t stream);
 int vmasr_masked_l1_bwd(const void *sgn, const float *gout, float *dgen, const int64_t *valid, const float *scale, int32_t n,
                         int64_t rows_g, int32_t N, vmasr_stream_t stream);
+/* the same with an addend: dgen = add + gout * scale[s] * sgn (add (n, rows_g, N) fp32 or NULL) — the feature map's whole
+ * gradient (next layer's + the loss's) in one pass */
+int vmasr_masked_l1_bwd_add(const void *sgn, const float *gout, const float *add, float *dgen, const int64_t *valid, const float *scale,
+                            int32_t n, int64_t rows_g, int32_t N, vmasr_stream_t stream);
 
 /* ---- fused SS2D core (vm_asr_amd/csrc/ss2d.hip) ---------------------------------------------------------
  * One operator for  y = CrossMerge(selective_scan(CrossScan(x), dt_proj(x_proj(.)), A, B, C, D, dt_bias, softplus))

@@ -543,7 +543,7 @@ def test_masked_l1_kernels_match_float64(n, rows_g, rows_r, N, valid):
     gen[0, 0, 0] = real[0, 0, 0]                                              # sign(0) = 0
     gen.requires_grad_()
     scale = tuple(1.0 / (m * N * 7) for m in valid)
-    loss = _MaskedL1Fn.apply(real, gen, valid, scale)
+    loss = _MaskedL1Fn.apply(real, gen, valid, scale, None, None)
     (loss * 3.0).backward()
     g64 = gen.detach().double().requires_grad_()
     R = min(rows_g, rows_r)
@@ -554,6 +554,38 @@ def test_masked_l1_kernels_match_float64(n, rows_g, rows_r, N, valid):
     assert abs(loss.item() - want.item()) <= 2e-6 * abs(want.item())
     assert torch.allclose(gen.grad.double(), g64.grad, rtol=1e-6, atol=0)
     assert gen.grad[0, 0, 0] == 0 and not gen.grad[1, valid[1]:].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rows,N,valid", [(5, 512, 128, (500, 512, 1, 257, 300)), (3, 256, 36, (256, 100, 33))])
+def test_feature_tap_gradient_equals_loss_backward_plus_autograd_sum(n, rows, N, valid):
+    """_FeatTapFn (the feature map's gradient = next layer's gradient + feature-matching loss's gradient in ONE pass,
+    vmasr_masked_l1_bwd_add) against the untapped graph, where _MaskedL1Fn's own backward and autograd's add produce it:
+    bit-equal (one fused multiply-add per element instead of a multiply and an add: equal to 1 ulp) — and a tap nobody feeds
+    passes the gradient through."""
+    from vm_asr_amd.discriminator import _FeatTapFn, _MaskedL1Fn
+    torch.manual_seed(n + N)
+    real = torch.randn(n, rows, N, device="cuda")
+    x = torch.randn(n, rows, N, device="cuda")
+    w = torch.randn(n, rows, N, device="cuda")              # stands for the next layer: consumes the map linearly
+    scale = tuple(1.0 / (m * N * 7) for m in valid)
+    grads = []
+    for tapped in (True, False):
+        xi = x.clone().requires_grad_()
+        y = xi * 2.0
+        if tapped:
+            holder = {}
+            y, tok = _FeatTapFn.apply(y, holder)
+            fm = _MaskedL1Fn.apply(real, y.detach(), valid, scale, tok, holder)
+        else:
+            fm = _MaskedL1Fn.apply(real, y, valid, scale, None, None)
+        ((y * w).sum() + 3.0 * fm).backward()
+        grads.append(xi.grad.clone())
+    assert torch.allclose(grads[0], grads[1], rtol=2e-7, atol=1e-9)
+    xi = x.clone().requires_grad_()
+    y, tok = _FeatTapFn.apply(xi * 2.0, {})
+    (y * w).sum().backward()
+    assert torch.equal(xi.grad, 2.0 * w)
 
 
 @pytest.mark.gpu

@@ -6,7 +6,8 @@
 //     sum_s scale[s] * sum_{r < valid[s], c} |gen[s, r, c] - real[s, r, c]|,   scale[s] = 1 / (valid[s] * N * n_maps).
 // As ATen ops that is sub, abs, mul (mask), sum forward and sgn, mul, mul backward: 7 passes, ~52 B per element, over
 // 170 M elements per training step.  Here: one forward pass (r 8 B, w 1 B: the sign, kept for the backward) and one
-// backward pass (r 1 B, w 4 B).  Pure HBM-bound streaming; the valid part of a slot is one contiguous range in both
+// backward pass (r 1 B, w 4 B — or, with the gradient arriving from the next layer as addend, r 5 B, w 4 B for the map's WHOLE
+// gradient: vmasr_masked_l1_bwd_add).  Pure HBM-bound streaming; the valid part of a slot is one contiguous range in both
 // tensors, so the kernels are flat grid-stride loops with 16-byte accesses.
 //
 // Determinism: per-workgroup partial sums in fp64 land in a workspace that the host side adds up (no atomics).
@@ -60,23 +61,27 @@ __global__ __launch_bounds__(256) void masked_l1_fwd_kernel(const float *__restr
     if (threadIdx.x == 0) partials[(size_t)s * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * (double)t.scale[s];
 }
 
-// dgen[s, e] = gout * scale[s] * sgn[s, e] for e < valid_elems[s], 0 on the padding rows; grid (blocks, n)
+// dgen[s, e] = add[s, e] + gout * scale[s] * sgn[s, e] for e < valid_elems[s], add[s, e] on the padding rows (add == NULL: 0);
+// grid (blocks, n).  With `add` = the gradient arriving from the next layer this is the whole gradient of the feature map in
+// one pass (r 5 B, w 4 B) where a separate loss backward (r 1, w 4) + autograd's sum of the two (r 8, w 4) moved 17 B.
 __global__ __launch_bounds__(256) void masked_l1_bwd_kernel(const signed char *__restrict__ sgn, const float *__restrict__ gout,
-                                                            float *__restrict__ dgen, const L1Slots t, const size_t stride_g) {
+                                                            const float *__restrict__ add, float *__restrict__ dgen, const L1Slots t,
+                                                            const size_t stride_g) {
     const int s = blockIdx.y;
     const signed char *__restrict__ q = sgn + (size_t)s * stride_g;
+    const float *__restrict__ a = add ? add + (size_t)s * stride_g : nullptr;
     float *__restrict__ o = dgen + (size_t)s * stride_g;
     const float k = gout[0] * t.scale[s];
     const long n = t.valid_elems[s], total4 = (long)(stride_g / 4);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = a ? reinterpret_cast<const float4 *>(a)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         const long e = i * 4;
         if (e + 3 < n) {
             const char4 c = reinterpret_cast<const char4 *>(q)[i];
-            v = make_float4(k * (float)c.x, k * (float)c.y, k * (float)c.z, k * (float)c.w);
+            v.x = fmaf(k, (float)c.x, v.x); v.y = fmaf(k, (float)c.y, v.y); v.z = fmaf(k, (float)c.z, v.z); v.w = fmaf(k, (float)c.w, v.w);
         } else if (e < n) {
-            float w[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < 4 && e + j < n; ++j) w[j] = k * (float)q[e + j];
+            float w[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 4 && e + j < n; ++j) w[j] = fmaf(k, (float)q[e + j], w[j]);
             v = make_float4(w[0], w[1], w[2], w[3]);
         }
         reinterpret_cast<float4 *>(o)[i] = v;
@@ -119,18 +124,23 @@ VMASR_EXPORT int vmasr_masked_l1_fwd(const float *real, const float *gen, void *
     return check_launch("masked_l1_fwd");
 }
 
-VMASR_EXPORT int vmasr_masked_l1_bwd(const void *sgn, const float *gout, float *dgen, const int64_t *valid, const float *scale, int32_t n,
-                                     int64_t rows_g, int32_t N, vmasr_stream_t stream) {
+VMASR_EXPORT int vmasr_masked_l1_bwd_add(const void *sgn, const float *gout, const float *add, float *dgen, const int64_t *valid,
+                                         const float *scale, int32_t n, int64_t rows_g, int32_t N, vmasr_stream_t stream) {
     VMASR_REQUIRE(sgn && gout && dgen && valid && scale, VMASR_EINVAL, "masked_l1_bwd: null argument");
     VMASR_REQUIRE(n > 0 && n <= kMaxSlots && rows_g > 0 && N > 0, VMASR_EINVAL, "masked_l1_bwd: bad shape");
-    VMASR_REQUIRE(((size_t)rows_g * N) % 4 == 0 && aligned_to(dgen, 16) && aligned_to(sgn, 4), VMASR_EINVAL,
+    VMASR_REQUIRE(((size_t)rows_g * N) % 4 == 0 && aligned_to(dgen, 16) && aligned_to(sgn, 4) && (!add || aligned_to(add, 16)), VMASR_EINVAL,
                   "masked_l1_bwd: slots must be 16-byte aligned (rows * N %% 4 == 0)");
     L1Slots t{};
     if (int e = fill_slots(t, valid, scale, n, N, rows_g, rows_g, "masked_l1_bwd")) return e;
     const long total4 = (long)rows_g * N / 4;
     const int blocks = (int)std::min<long>((total4 + 255) / 256, 256L * 8);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    VMASR_LAUNCH(VMASR_K_FEAT_L1, 5.0 * n * (double)rows_g * N, masked_l1_bwd_kernel, dim3(blocks, n), dim3(256), 0, st,
-                 static_cast<const signed char *>(sgn), gout, dgen, t, (size_t)rows_g * N);
+    VMASR_LAUNCH(VMASR_K_FEAT_L1, (add ? 9.0 : 5.0) * n * (double)rows_g * N, masked_l1_bwd_kernel, dim3(blocks, n), dim3(256), 0, st,
+                 static_cast<const signed char *>(sgn), gout, add, dgen, t, (size_t)rows_g * N);
     return check_launch("masked_l1_bwd");
+}
+
+VMASR_EXPORT int vmasr_masked_l1_bwd(const void *sgn, const float *gout, float *dgen, const int64_t *valid, const float *scale, int32_t n,
+                                     int64_t rows_g, int32_t N, vmasr_stream_t stream) {
+    return vmasr_masked_l1_bwd_add(sgn, gout, nullptr, dgen, valid, scale, n, rows_g, N, stream);
 }
