@@ -420,6 +420,15 @@ int vmasr_ln_gate_fwd(const float *y, const void *sz, const float *gamma, const 
 int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta, const float *mean,
                       const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta, int32_t B, int32_t D, int32_t L,
                       int32_t dtype, vmasr_stream_t stream);
+/* ln_gate_bwd for d_inner >= 64 with a workspace instead of atomics on dgamma / dbeta (up to 1 024 workgroups adding to the same D
+ * addresses serialise): ws holds vmasr_ln_gate_bwd_workspace(...) floats = per-workgroup partials [dgamma (D) | dbeta (D)]
+ * (0: this shape uses the direct variant, call vmasr_ln_gate_bwd).  dgamma / dbeta given: reduced at once into them (plain
+ * stores, no zero-initialisation needed); both NULL: partials only, to be summed later (vmasr_layer_norm_bwd_reduce_multi with
+ * nblk = workspace / (2 D), C = D). */
+int64_t vmasr_ln_gate_bwd_workspace(int32_t B, int32_t D, int32_t L, int32_t dtype);
+int vmasr_ln_gate_bwd_ws(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta, const float *mean,
+                         const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta, float *ws, int32_t B, int32_t D,
+                         int32_t L, int32_t dtype, vmasr_stream_t stream);
 /* ln_gate on the two PAIR outputs of the fused core: y = y02 (B, D, H*W in (h,w) order) + transpose(y13 (B, D, W*H in (w,h)
  * order)) is formed on the fly — what is left of CrossMerge (model/vmamba.py:50-73) never becomes a tensor; the backward
  * writes the gradient in both orders (dy02, dy13: the inputs of vmasr_ss2d_bwd with VMASR_SS2D_PAIRS).  D in {2,4,8,16,32},

@@ -122,6 +122,8 @@ SYMBOLS = {
     "vmasr_ss2d_pre_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_ln_gate_fwd": (ctypes.c_int, [c_vp] * 7 + [c_i32, c_i32, c_i32, ctypes.c_float, c_i32, c_vp]),
     "vmasr_ln_gate_bwd": (ctypes.c_int, [c_vp] * 11 + [c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_ln_gate_bwd_workspace": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "vmasr_ln_gate_bwd_ws": (ctypes.c_int, [c_vp] * 12 + [c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_ln_gate_pair_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "vmasr_ln_gate_pair_fwd": (ctypes.c_int, [c_vp] * 8 + [c_i32, c_i32, c_i32, c_i32, ctypes.c_float, c_i32, c_vp]),
     "vmasr_ln_gate_pair_bwd": (ctypes.c_int, [c_vp] * 13 + [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float *__restric
                                                           const float *__restrict__ beta, const float *__restrict__ mean,
                                                           const float *__restrict__ rstd, float *__restrict__ dy,
                                                           T *__restrict__ dsz, float *__restrict__ dgamma,
-                                                          float *__restrict__ dbeta, const GlueGeom g) {
+                                                          float *__restrict__ dbeta, float *__restrict__ part, const GlueGeom g) {
     extern __shared__ float lds[];
     float *tile = lds, *acc = lds + g.D * (g.P + 1);   // acc: dgamma[D], dbeta[D]
     const int b = blockIdx.y, l0 = blockIdx.x * g.P;
@@ -237,9 +237,16 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float *__restric
     }
     __syncthreads();
     tile_to_rows<float>(tile, dy, g, b, l0);
-    for (int d = threadIdx.x; d < g.D; d += blockDim.x) {
-        atomicAdd(dgamma + d, acc[d]);
-        atomicAdd(dbeta + d, acc[g.D + d]);
+    if (part) {
+        // per-workgroup partials [dgamma (D) | dbeta (D)], summed by ln.hip's reduce kernel: with up to 1 024 workgroups adding to
+        // the same D addresses the atomics serialise (~13 ns each per address: 13 us of a 27 us launch at 64 x 64 x 64)
+        float *dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * g.D;
+        for (int d = threadIdx.x; d < 2 * g.D; d += blockDim.x) dst[d] = acc[d];
+    } else {
+        for (int d = threadIdx.x; d < g.D; d += blockDim.x) {
+            atomicAdd(dgamma + d, acc[d]);
+            atomicAdd(dbeta + d, acc[g.D + d]);
+        }
     }
 }
 
@@ -631,14 +638,45 @@ VMASR_EXPORT int vmasr_ln_gate_fwd(const float *y, const void *sz, const float *
     return check_launch("ln_gate_fwd");
 }
 
+VMASR_EXPORT int64_t vmasr_ln_gate_bwd_workspace(int32_t B, int32_t D, int32_t L, int32_t dtype) {
+    GlueGeom g;
+    int CH;
+    if (direct_ok(D) || B <= 0 || D <= 0 || L <= 0) return 0;      // (the direct variants fold per workgroup and use few atomics)
+    if (plan(B, D, L, dtype == VMASR_F32 ? 4 : 2, g, CH, "ln_gate_bwd_workspace")) return 0;
+    return (int64_t)B * (L / g.P) * 2 * D;
+}
+
+static int ln_gate_bwd_impl(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta, const float *mean,
+                            const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta, float *part, int32_t B, int32_t D,
+                            int32_t L, int32_t dtype, vmasr_stream_t stream);
+
 VMASR_EXPORT int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta,
                                    const float *mean, const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta,
                                    int32_t B, int32_t D, int32_t L, int32_t dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(dgamma && dbeta, VMASR_EINVAL, "ln_gate_bwd: null tensor");
+    return ln_gate_bwd_impl(y, sz, dout, gamma, beta, mean, rstd, dy, dsz, dgamma, dbeta, nullptr, B, D, L, dtype, stream);
+}
+
+VMASR_EXPORT int vmasr_ln_gate_bwd_ws(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta,
+                                      const float *mean, const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta, float *ws,
+                                      int32_t B, int32_t D, int32_t L, int32_t dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(ws && vmasr_ln_gate_bwd_workspace(B, D, L, dtype) > 0, VMASR_EINVAL, "ln_gate_bwd_ws: no workspace variant for this shape");
+    if (int e = ln_gate_bwd_impl(y, sz, dout, gamma, beta, mean, rstd, dy, dsz, nullptr, nullptr, ws, B, D, L, dtype, stream)) return e;
+    if (!dgamma && !dbeta) return VMASR_OK;                        // partials only: the caller reduces them later
+    const float *parts[1] = {ws};
+    float *dgs[1] = {dgamma}, *dbs[1] = {dbeta};
+    const int32_t nblk[1] = {(int32_t)(vmasr_ln_gate_bwd_workspace(B, D, L, dtype) / (2 * D))}, Cs[1] = {D};
+    return vmasr_layer_norm_bwd_reduce_multi(parts, dgs, dbs, nblk, Cs, 1, stream);
+}
+
+static int ln_gate_bwd_impl(const float *y, const void *sz, const void *dout, const float *gamma, const float *beta, const float *mean,
+                            const float *rstd, float *dy, void *dsz, float *dgamma, float *dbeta, float *part, int32_t B, int32_t D,
+                            int32_t L, int32_t dtype, vmasr_stream_t stream) {
     GlueGeom g;
     int CH;
     const int esz = dtype == VMASR_F32 ? 4 : 2;
     if (int e = plan(B, D, L, esz, g, CH, "ln_gate_bwd")) return e;
-    VMASR_REQUIRE(y && sz && dout && gamma && beta && mean && rstd && dy && dsz && dgamma && dbeta, VMASR_EINVAL,
+    VMASR_REQUIRE(y && sz && dout && gamma && beta && mean && rstd && dy && dsz && (part || (dgamma && dbeta)), VMASR_EINVAL,
                   "ln_gate_bwd: null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t sm = ((size_t)D * (g.P + 1) + 2 * D) * sizeof(float);
@@ -650,7 +688,7 @@ VMASR_EXPORT int vmasr_ln_gate_bwd(const float *y, const void *sz, const void *d
 #undef GLUE_ARGS
         return check_launch("ln_gate_bwd");
     }
-#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta
+#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta, part
     GLUE_DISPATCH(ln_gate_bwd_kernel, VMASR_K_LN_GATE, bytes, sm);
 #undef GLUE_ARGS
     return check_launch("ln_gate_bwd");

@@ -76,16 +76,18 @@ def _flush_pending():
                 param.grad.copy_(torch.empty(0, dtype=torch.float32, device=dev).set_(st, 0, (C,)).view_as(param.grad))
 
 
-def defer_reduction(ws, dg, db, rows, C, weight=None, bias=None):
+def defer_reduction(ws, dg, db, rows, C, weight=None, bias=None, nblk=None):
     """Queue (partials -> dg, db) for the end of the running backward pass; False if deferral does not apply.
     Only the STORAGES of dg / db are kept (a second reference to the tensors themselves would make autograd clone them
-    instead of adopting them as .grad)."""
+    instead of adopting them as .grad).  nblk: rows of 2 C partials in ws (default: LayerNorm's own grid for `rows`)."""
     if not DEFER_REDUCE:
         return False
     if not _pending:
         torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
     ref = lambda t: (None, 0) if t is None else (t.untyped_storage(), t.data_ptr())   # noqa: E731
-    _pending.append((ws, ref(dg), ref(db), int(_lib.lib().vmasr_layer_norm_bwd_blocks(rows, C)), C, weight, bias))
+    if nblk is None:
+        nblk = int(_lib.lib().vmasr_layer_norm_bwd_blocks(rows, C))
+    _pending.append((ws, ref(dg), ref(db), int(nblk), C, weight, bias))
     return True
 
 

@@ -12,6 +12,7 @@ import os
 import torch
 
 from . import _lib
+from . import layernorm as _ln
 
 __all__ = ["ss2d_pre", "ln_gate", "ln_gate_pairs", "pairs_supported", "supported"]
 
@@ -71,6 +72,10 @@ class _LNGateFn(torch.autograd.Function):
                        "ln_gate_fwd")
         ctx.save_for_backward(y, sz, g32, b32, stats)
         ctx.meta = (gamma.dtype, beta.dtype)
+        if any(ctx.needs_input_grad[2:4]):
+            _ln.note_use(gamma, beta)
+        ctx.fresh = lambda: (all(getattr(t, "grad", None) is None for t in (gamma, beta)) and _ln.used_once(gamma, beta))
+        ctx.params = (gamma, beta)
         return out
 
     @staticmethod
@@ -79,13 +84,26 @@ class _LNGateFn(torch.autograd.Function):
         B, H, W, D = sz.shape
         L = H * W
         dout = dout.to(sz.dtype).contiguous()
+        lib, code = _lib.lib(), _lib.torch_dtype_code(sz.dtype)
         with torch.cuda.device(sz.device):
             dy = torch.empty_like(y)
             dsz = torch.empty_like(sz)
+            nws = int(lib.vmasr_ln_gate_bwd_workspace(B, D, L, code))
+            if nws:
+                # d_inner >= 64: per-workgroup partials of dgamma / dbeta, reduced at once or — in the trainer's flat-gradient
+                # mode — by the one reduce launch at the end of the backward pass (layernorm.defer_reduction)
+                ws = torch.empty(nws, dtype=torch.float32, device=sz.device)
+                dg = torch.empty(D, dtype=torch.float32, device=sz.device)
+                db = torch.empty(D, dtype=torch.float32, device=sz.device)
+                later = (_ln.DEFER_REDUCE and ctx.meta == (torch.float32, torch.float32) and ctx.fresh()
+                         and _ln.defer_reduction(ws, dg, db, None, D, *ctx.params, nblk=nws // (2 * D)))
+                _lib.check(lib.vmasr_ln_gate_bwd_ws(_p(y), _p(sz), _p(dout), _p(g32), _p(b32), _p(stats[0]), _p(stats[1]), _p(dy), _p(dsz),
+                                                    None if later else _p(dg), None if later else _p(db), _p(ws), B, D, L, code,
+                                                    _lib.current_stream(sz.device)), "ln_gate_bwd_ws")
+                return dy, dsz, dg.to(ctx.meta[0]), db.to(ctx.meta[1]), None
             dgb = torch.zeros((2, D), dtype=torch.float32, device=sz.device)
-            _lib.check(_lib.lib().vmasr_ln_gate_bwd(_p(y), _p(sz), _p(dout), _p(g32), _p(b32), _p(stats[0]), _p(stats[1]), _p(dy), _p(dsz),
-                                                    _p(dgb[0]), _p(dgb[1]), B, D, L, _lib.torch_dtype_code(sz.dtype),
-                                                    _lib.current_stream(sz.device)), "ln_gate_bwd")
+            _lib.check(lib.vmasr_ln_gate_bwd(_p(y), _p(sz), _p(dout), _p(g32), _p(b32), _p(stats[0]), _p(stats[1]), _p(dy), _p(dsz),
+                                             _p(dgb[0]), _p(dgb[1]), B, D, L, code, _lib.current_stream(sz.device)), "ln_gate_bwd")
         return dy, dsz, dgb[0].to(ctx.meta[0]), dgb[1].to(ctx.meta[1]), None
 
 
