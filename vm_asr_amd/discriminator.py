@@ -605,7 +605,8 @@ def _split_mode(K, N, cdt):
     """Which GEMMs of the fp32 discriminator run as error-compensated bf16 triples: the compute-bound ones
     (K*N >= 2^18: the 128->512, 512->1024 and 1024->1024 convolutions, 98 % of the FLOPs); the two small-K layers
     are memory-bound and stay plain fp32 GEMMs.  VMASR_MPD_GEMM=fp32 switches the triples off."""
-    return cdt == torch.float32 and K * N >= (1 << 18) and os.environ.get("VMASR_MPD_GEMM", "bf16x3") == "bf16x3"
+    return (cdt == torch.float32 and K * N >= int(os.environ.get("VMASR_MPD_SPLIT_MIN", str(1 << 18)))
+            and os.environ.get("VMASR_MPD_GEMM", "bf16x3") == "bf16x3")
 
 
 class _BatchedLinearSplitFn(torch.autograd.Function):
