@@ -6,7 +6,7 @@
 // of the inverse wrt (mag, phase) that training needs (the forward STFT input is the
 // wave itself: no gradient flows there).
 //
-// One workgroup owns FR consecutive frames of one clip.  Per PAIR of frames one complex
+// One workgroup owns FR = 2 consecutive frames of one clip.  Per PAIR of frames one complex
 // radix-2 Stockham FFT runs in LDS (two real frames packed as re/im and separated by
 // Hermitian symmetry), twiddles and the hann window are built once per workgroup with
 // sincospi, and the epilogue (log2/atan2, or the exp2/cos/sin chain) is fused.  Results
@@ -17,7 +17,14 @@
 namespace vmasr {
 namespace {
 
-constexpr int kFR = 8;  // frames per workgroup
+// frames per workgroup (one packed pair).  Measured at B = 4 (tools: make VARIANT=fr8 DEFS=-DVMASR_STFT_FR=8 + VMASR_LIB): with 8
+// frames a launch is 240-1000 workgroups each walking four pair-FFTs (40 barriers) in sequence — stft 40.5 us, istft_bwd 67 us
+// per launch; with 2 the same work is four times as many independent workgroups: 35 / 36 us (istft_frames 37.6 -> 31.5).  The
+// shorter runs along the frame axis (8 B instead of 32 B per frequency row and workgroup) are merged in L2.
+#ifndef VMASR_STFT_FR
+#define VMASR_STFT_FR 2
+#endif
+constexpr int kFR = VMASR_STFT_FR;
 constexpr float kLn2 = 0.6931471805599453f;
 
 struct FftSmem {
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float *__restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FftSmem s = carve(smem, n, false);
     const int F = n / 2 + 1;
-    // Frame groups that are neighbours in m read the same 128-byte lines of the (B, F, M) spectra (kFR frames = 32 bytes
+    // Frame groups that are neighbours in m read the same 128-byte lines of the (B, F, M) spectra (kFR frames = 8 bytes
     // per bin): under round-robin dispatch they would sit on different XCDs and each L2 would fetch the line again
     // (PMC: 243 MB fetched per launch for 17 MB of spectra).  Give each XCD a contiguous run of frame groups.
     const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
