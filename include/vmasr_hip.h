@@ -484,6 +484,18 @@ int vmasr_inproj_bwd(const void *x, const float *gamma, const float *beta, float
                      const void *dsz, void *dxn, void *xn, void *gpre, float *mean, float *rstd, int64_t rows, int32_t L, int32_t d,
                      int32_t x_dtype, vmasr_stream_t stream);
 
+/* ---- the output side of SS2D.forwardv2 as one MFMA kernel (vm_asr_amd/csrc/mlp.hip: outproj_kernel) ----------------------
+ * y = x + scale * (g . W^T): out_proj (model/vmamba.py:1551, no bias, dropout p = 0) + the VSSBlock's DropPath + residual add
+ * (:1826-1827) for g (rows, 2d) bf16 = ln_gate's output, W (d, 2d) bf16 = out_proj.weight, x / y (rows, d) the residual stream
+ * (fp32 or bf16), d in {8,16,32,64}; scale: per-sample residual scale (one float per rows_per_sample rows) or NULL.
+ * vmasr_outproj_bwd: gy (rows, d) -> dg (rows, 2d) bf16 = scale * gy . W (ln_gate's incoming gradient) and gys (rows, d) bf16 =
+ * scale * gy (dW = gys^T . g is one GEMM on the caller's side); wt (2d, d) = W^T contiguous.  The stream's own gradient is gy. */
+int vmasr_outproj_supported(int32_t d, int32_t d_inner);
+int vmasr_outproj_fwd(const void *g, const void *w, const void *x, const float *scale, int32_t rows_per_sample, void *y, int64_t rows,
+                      int32_t d, int32_t x_dtype, vmasr_stream_t stream);
+int vmasr_outproj_bwd(const void *gy, const void *wt, const float *scale, int32_t rows_per_sample, void *dg, void *gys, int64_t rows,
+                      int32_t d, int32_t x_dtype, vmasr_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents
  * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
@@ -543,6 +555,8 @@ enum {
     VMASR_K_SS2D_DEEP_FWD,      /* dt_proj + the four directional scans of whole rows + cross-merge, one launch */
     VMASR_K_SS2D_DEEP_BWD,      /* its backward: du, per-row terms of d(x_dbl), parameter sums                  */
     VMASR_K_SS2D_DEEP_XBWD,     /* adjoint of x_proj: terms -> d(x_dbl) -> dx                                   */
+    VMASR_K_OUTPROJ_FWD,        /* out_proj + DropPath + residual of a VSS block's SS2D branch as one MFMA kernel */
+    VMASR_K_OUTPROJ_BWD,
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

@@ -155,3 +155,53 @@ def test_fused_in_proj_matches_float64_as_well_as_torch_autocast(d, shape, with_
         print(f"d={d} {shape} norm={with_norm} {n}: fused {e_f:.2e}  torch autocast {e_a:.2e}")
         assert a.shape == c.shape and torch.isfinite(a).all(), n
         assert e_f <= tol and e_f <= 1.5 * e_a + 3e-3, (n, e_f, e_a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d,shape,scaled", [(8, (2, 16, 16), True), (16, (1, 32, 32), False), (32, (2, 8, 16), True), (64, (1, 16, 16), False),
+                                            (64, (3, 8, 4), True)])
+def test_fused_out_proj_residual_matches_float64_as_well_as_torch_autocast(d, shape, scaled, xdt):
+    """out_proj + DropPath scale + residual add as one MFMA kernel (vm_asr_amd/outproj.py; model/vmamba.py:1551, 1826-1827)
+    against float64, with torch's bf16 autocast of the same lines as the yardstick; fp32 and bf16 streams, with and without the
+    per-sample stochastic-depth scale, row counts that are not a multiple of the 32-row tile."""
+    from vm_asr_amd.linear import Linear
+    from vm_asr_amd.outproj import fused_out_proj_residual, supported
+    torch.manual_seed(d + shape[1])
+    dev = "cuda"
+    proj = Linear(2 * d, d, bias=False).to(dev)
+    B, H, W = shape
+    g = torch.randn(B, H, W, 2 * d, device=dev).to(torch.bfloat16)
+    x = torch.randn(B, H, W, d, device=dev).to(xdt)
+    gy = torch.randn(B, H, W, d, device=dev)
+    scale = (torch.rand(B, 1, 1, 1, device=dev) > 0.3).float() / 0.7 if scaled else None
+
+    def ref(dtype):
+        c = lambda t: t.detach().to(dtype).requires_grad_()       # noqa: E731
+        gi, xi, w = c(g), c(x), c(proj.weight)
+        y = xi + F.linear(gi, w) * (1.0 if scale is None else scale.to(dtype))
+        (y * gy.to(dtype)).sum().backward()
+        return [y.detach(), gi.grad, xi.grad, w.grad]
+
+    def run(fn):
+        gi, xi = g.clone().requires_grad_(), x.clone().requires_grad_()
+        proj.weight.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fn(gi, xi)
+        assert y.dtype == xdt
+        (y.float() * gy).sum().backward()
+        return [y.detach().double(), gi.grad.double(), xi.grad.double(), proj.weight.grad.double()]
+
+    def plain(gi, xi):
+        out = proj(gi)
+        return xi + out if scale is None else torch.addcmul(xi, out, scale.to(torch.promote_types(xi.dtype, out.dtype)))
+
+    def fused(gi, xi):
+        assert supported(gi, proj, xi)
+        return fused_out_proj_residual(gi, proj, xi, scale)
+    want, got, auto = ref(torch.float64), run(fused), run(plain)
+    for n, a, b, c in zip(["y", "dg", "dx", "dW"], got, auto, want):
+        sc = max(c.abs().max().item(), 1e-12)
+        e_f, e_a = (a - c).abs().max().item() / sc, (b - c).abs().max().item() / sc
+        print(f"d={d} {xdt} {n}: fused {e_f:.2e}  autocast {e_a:.2e}")
+        assert e_f <= 1.5 * e_a + 2e-3, (n, e_f, e_a)

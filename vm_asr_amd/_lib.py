@@ -74,6 +74,9 @@ SYMBOLS = {
     "vmasr_mlp_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_mlp_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "vmasr_outproj_supported": (ctypes.c_int, [c_i32, c_i32]),
+    "vmasr_outproj_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "vmasr_outproj_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_inproj_supported": (ctypes.c_int, [c_i32, c_i32, c_i64]),
     "vmasr_inproj_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_inproj_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -196,7 +199,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 52
+K_COUNT = 54
 
 
 def zeros_f32(device, *shapes):

@@ -646,3 +646,135 @@ VMASR_EXPORT int vmasr_inproj_bwd(const void *x, const float *gamma, const float
     return x_dtype == VMASR_F32 ? launch_inproj<true, float>(a, d, static_cast<hipStream_t>(stream))
                                 : launch_inproj<true, bf16_t>(a, d, static_cast<hipStream_t>(stream));
 }
+
+// ---- the output side of SS2D.forwardv2: out_proj + DropPath + residual on the same scheme ----------------------------------------
+//     y = x + s * (g . W_out^T)        model/vmamba.py:1551 (out_proj, no bias; dropout p = 0) + :1826-1827 (VSSBlock residual)
+// g (rows, 2D) bf16 = the gated LayerNorm output of ln_gate, W_out (D, 2D) bf16, x / y (rows, D) the residual stream (TX).
+// Y^T (D x rows) = W_out . g^T: A = rows of W_out as stored, B = the lane's own row of g (contiguous 16-byte fragments); the
+// accumulator has the data row on the lane, so the residual add and the store are the Mlp kernel's epilogue.  Replaces GEMM +
+// add (+ DropPath multiply).  Backward: dg^T (2D x rows) = W_out^T . (s gy)^T -> dg (rows, 2D) bf16 (ln_gate's incoming
+// gradient) and gys = s gy in bf16 (operand of dW = gys^T . g, one split-K GEMM on the host side); the stream's gradient is gy.
+namespace vmasr {
+namespace {
+
+struct OutProjArgs {
+    const bf16_t *g;      // (rows, 2D)
+    const bf16_t *w;      // (D, 2D)   out_proj.weight           (backward: (2D, D) its transpose)
+    const void *x;        // (rows, D) TX residual stream        (backward: gy)
+    const float *scale;   // per-sample residual scale or null
+    void *y;              // (rows, D) TX                        (backward: unused)
+    bf16_t *dg, *gys;     // backward outputs (rows, 2D), (rows, D)
+    long rows;
+    int rows_per_sample;
+};
+
+template <int D, typename TX, bool BWD>
+__global__ __launch_bounds__(256) void outproj_kernel(const OutProjArgs a) {
+    constexpr int DI = 2 * D;
+    constexpr int KIN = BWD ? D : DI, NOUT = BWD ? DI : D;          // contraction length, output features
+    constexpr int KS = (KIN + 15) / 16, OT = (NOUT + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile * 32 < a.rows; tile += (long)gridDim.x * 4) {
+        const long row = tile * 32 + r;
+        const bool ok = row < a.rows;
+        const float sc = a.scale ? a.scale[ok ? row / a.rows_per_sample : 0] : 1.f;
+        bf16x8 b[KS];
+        if constexpr (BWD) {
+            float gv[KS][8];
+            load_row<D, KS, TX>(static_cast<const TX *>(a.x) + row * D, ok, h, gv);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[s][j] = (bf16_t)(sc * gv[s][j]);
+                const int f0 = 16 * s + 8 * h;
+                if (ok && f0 < D) *reinterpret_cast<bf16x8 *>(a.gys + row * D + f0) = b[s];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int f0 = 16 * s + 8 * h;
+                b[s] = (ok && f0 < DI) ? *reinterpret_cast<const bf16x8 *>(a.g + row * DI + f0) : zero8();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < OT; ++u) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const int o = 32 * u + r;                                 // the A operand's row = output feature
+            const bf16_t *wr = a.w + (size_t)o * KIN;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int f0 = 16 * s + 8 * h;
+                const bf16x8 av = (o < NOUT && f0 < KIN) ? *reinterpret_cast<const bf16x8 *>(wr + f0) : zero8();
+                acc = mfma_bf16(av, b[s], acc);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int o0 = 32 * u + 8 * g4 + 4 * h;
+                if (!ok || o0 >= NOUT) continue;
+                if constexpr (BWD) {
+                    store_bf16x4(a.dg + row * DI + o0, acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+                } else {
+                    float xq[4];
+                    load4x<TX>(static_cast<const TX *>(a.x) + row * D + o0, xq);
+                    store4x<TX>(static_cast<TX *>(a.y) + row * D + o0, fmaf(sc, acc[4 * g4], xq[0]), fmaf(sc, acc[4 * g4 + 1], xq[1]),
+                                fmaf(sc, acc[4 * g4 + 2], xq[2]), fmaf(sc, acc[4 * g4 + 3], xq[3]));
+                }
+            }
+        }
+    }
+}
+
+template <bool BWD, typename TX>
+int launch_outproj(const OutProjArgs &a, int d, hipStream_t st) {
+    const dim3 grid(grid_for(a.rows, 4)), block(256);
+    const double sx = sizeof(TX);
+    const double bytes = (double)a.rows * d * (BWD ? sx + 2.0 + 4.0 : 4.0 + 2 * sx);
+#define VMASR_OUTP_CASE(DD)                                                                                           \
+    case DD:                                                                                                          \
+        VMASR_LAUNCH(BWD ? VMASR_K_OUTPROJ_BWD : VMASR_K_OUTPROJ_FWD, bytes, (outproj_kernel<DD, TX, BWD>), grid, block, 0, st, a); \
+        break;
+    switch (d) {
+        VMASR_OUTP_CASE(8) VMASR_OUTP_CASE(16) VMASR_OUTP_CASE(32) VMASR_OUTP_CASE(64)
+        default: set_error("outproj: unsupported width %d", d); return VMASR_EINVAL;
+    }
+#undef VMASR_OUTP_CASE
+    return check_launch(BWD ? "outproj_bwd" : "outproj_fwd");
+}
+
+}  // namespace
+}  // namespace vmasr
+
+VMASR_EXPORT int vmasr_outproj_supported(int32_t d, int32_t d_inner) {
+    return ((d == 8 || d == 16 || d == 32 || d == 64) && d_inner == 2 * d) ? 1 : 0;
+}
+
+VMASR_EXPORT int vmasr_outproj_fwd(const void *g, const void *w, const void *x, const float *scale, int32_t rows_per_sample, void *y,
+                                   int64_t rows, int32_t d, int32_t x_dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(g && w && x && y, VMASR_EINVAL, "outproj_fwd: null tensor");
+    VMASR_REQUIRE(vmasr_outproj_supported(d, 2 * d) && rows > 0 && (!scale || rows_per_sample > 0), VMASR_EINVAL,
+                  "outproj_fwd: need d in {8,16,32,64}");
+    VMASR_REQUIRE(x_dtype == VMASR_F32 || x_dtype == VMASR_BF16, VMASR_EINVAL, "outproj_fwd: x must be fp32 or bf16");
+    VMASR_REQUIRE(aligned_to(g, 16) && aligned_to(w, 16) && aligned_to(x, 8) && aligned_to(y, 8), VMASR_EINVAL, "outproj_fwd: unaligned");
+    OutProjArgs a{};
+    a.g = static_cast<const bf16_t *>(g); a.w = static_cast<const bf16_t *>(w); a.x = x; a.scale = scale; a.y = y; a.rows = rows;
+    a.rows_per_sample = rows_per_sample;
+    return x_dtype == VMASR_F32 ? launch_outproj<false, float>(a, d, static_cast<hipStream_t>(stream))
+                                : launch_outproj<false, bf16_t>(a, d, static_cast<hipStream_t>(stream));
+}
+
+VMASR_EXPORT int vmasr_outproj_bwd(const void *gy, const void *wt, const float *scale, int32_t rows_per_sample, void *dg, void *gys,
+                                   int64_t rows, int32_t d, int32_t x_dtype, vmasr_stream_t stream) {
+    VMASR_REQUIRE(gy && wt && dg && gys, VMASR_EINVAL, "outproj_bwd: null tensor");
+    VMASR_REQUIRE(vmasr_outproj_supported(d, 2 * d) && rows > 0 && (!scale || rows_per_sample > 0), VMASR_EINVAL,
+                  "outproj_bwd: need d in {8,16,32,64}");
+    VMASR_REQUIRE(x_dtype == VMASR_F32 || x_dtype == VMASR_BF16, VMASR_EINVAL, "outproj_bwd: gy must be fp32 or bf16");
+    VMASR_REQUIRE(aligned_to(gy, 16) && aligned_to(wt, 16) && aligned_to(dg, 8) && aligned_to(gys, 16), VMASR_EINVAL, "outproj_bwd: unaligned");
+    OutProjArgs a{};
+    a.w = static_cast<const bf16_t *>(wt); a.x = gy; a.scale = scale; a.dg = static_cast<bf16_t *>(dg); a.gys = static_cast<bf16_t *>(gys);
+    a.rows = rows; a.rows_per_sample = rows_per_sample;
+    return x_dtype == VMASR_F32 ? launch_outproj<true, float>(a, d, static_cast<hipStream_t>(stream))
+                                : launch_outproj<true, bf16_t>(a, d, static_cast<hipStream_t>(stream));
+}

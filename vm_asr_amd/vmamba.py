@@ -37,6 +37,7 @@ from . import ss2d_glue as _glue
 from . import xproj as _xproj
 from . import mlp as _mlp
 from . import inproj as _inproj
+from . import outproj as _outproj
 from .dwconv import dwconv3x3_silu
 from .layernorm import LayerNorm
 from .linear import Linear as _Linear
@@ -380,9 +381,20 @@ class SS2D(nn.Module):
                 and fc.keywords.get("SelectiveScan") is SelectiveScanCore and fc.keywords.get("CrossScan") is CrossScanHIP
                 and fc.keywords.get("CrossMerge") is CrossMergeHIP and fc.keywords.get("force_fp32", False))
 
-    def forward(self, x: torch.Tensor, pre_norm=None, **kwargs):
+    def _finish(self, y, residual):
+        """out_proj (+ dropout) and — when the calling block handed over (stream, DropPath) — its stochastic-depth residual
+        add: one MFMA kernel where vm_asr_amd/outproj.py applies (model/vmamba.py:1551 + :1826-1827)."""
+        if residual is None:
+            return self.dropout(self.out_proj(y))
+        res, dp = residual
+        if y.dim() == 4 and _outproj.supported(y, self.out_proj, res, self.dropout):
+            return _outproj.fused_out_proj_residual(y, self.out_proj, res, dp._mask(res) if dp.active() else None)
+        return dp.residual(res, self.dropout(self.out_proj(y)))
+
+    def forward(self, x: torch.Tensor, pre_norm=None, residual=None, **kwargs):
         """pre_norm: the block's LayerNorm (or nn.Identity) when the caller hands over the UN-normalised stream, so that
-        LayerNorm + in_proj + chunk + SiLU(z) + the channel-first copy can run as one MFMA kernel (vm_asr_amd/inproj.py)."""
+        LayerNorm + in_proj + chunk + SiLU(z) + the channel-first copy can run as one MFMA kernel (vm_asr_amd/inproj.py).
+        residual: (stream, DropPath) of the calling VSSBlock — the result is then stream + drop_path(branch)."""
         fused_in = (pre_norm is not None and x.dim() == 4 and self._fused_glue_ok(x) and _inproj.supported(x, pre_norm, self.in_proj)
                     and _glue.supported(self.d_inner, x.shape[1] * x.shape[2], torch.bfloat16))
         if not fused_in:
@@ -401,7 +413,7 @@ class SS2D(nn.Module):
             else:
                 y = self.forward_core(u, merged_only=True)                        # (B, D, L) fp32
                 y = _glue.ln_gate(y, sz, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
-            return self.dropout(self.out_proj(y))
+            return self._finish(y, residual)
         z = None
         if not self.disable_z:
             x, z = x.chunk(2, dim=(1 if self.channel_first else -1))
@@ -416,7 +428,7 @@ class SS2D(nn.Module):
         y = self.forward_core(x)
         if z is not None:
             y = y * z
-        return self.dropout(self.out_proj(y))
+        return self._finish(y, residual)
 
     forwardv2 = forward
 
@@ -456,7 +468,7 @@ class VSSBlock(nn.Module):
             if self.post_norm:
                 x = input + self.drop_path(self.norm(self.op(input)))
             else:
-                x = self.drop_path.residual(input, self.op(input, pre_norm=self.norm))
+                x = self.op(input, pre_norm=self.norm, residual=(input, self.drop_path))
         if self.mlp_branch:
             if self.post_norm:
                 x = x + self.drop_path(self.norm2(self.mlp(x)))
