@@ -15,7 +15,10 @@ def kid(name):
     for k, v in (("ss2d_carry_kernel", "ss2d_carry"), ("ss2d_bwd_reduce_kernel", "ss2d_carry"), ("transpose_hw_kernel", "ss2d_transpose"),
                  ("merge_pairs_kernel", "ss2d_merge"), ("split_bf16_kernel", "split_bf16"), ("gelu_bwd_split_kernel", "gelu_bwd_split"),
                  ("bias_gelu_fwd_kernel", "bias_gelu_fwd"), ("im2col_split_kernel", "im2col_split"), ("im2col_kernel", "im2col_kx1"),
-                 ("col2im_kernel", "col2im_kx1")):
+                 ("col2im_kernel", "col2im_kx1"), ("deep_bwd_kernel", "ss2d_deep_bwd"), ("deep_fwd_kernel", "ss2d_deep_fwd"),
+                 ("deep_xproj_kernel", "ss2d_deep_xproj"), ("deep_xg_kernel", "ss2d_deep_xbwd"), ("deep_dx_kernel", "ss2d_deep_xbwd"),
+                 ("mlp_fwd_kernel", "mlp_fwd"), ("mlp_bwd_kernel", "mlp_bwd"), ("inproj_kernel", "inproj"), ("outproj_kernel", "outproj"),
+                 ("ln_gate_pair", "ln_gate_pair"), ("ln_gate", "ln_gate")):
         if k in name:
             return v
     for k in ("sscan_carry_kernel<false>", "sscan_carry_kernel<true>", "sscan_bwd_reduce_kernel", "cross_scan_kernel",
