@@ -496,6 +496,18 @@ int vmasr_outproj_fwd(const void *g, const void *w, const void *x, const float *
 int vmasr_outproj_bwd(const void *gy, const void *wt, const float *scale, int32_t rows_per_sample, void *dg, void *gys, int64_t rows,
                       int32_t d, int32_t x_dtype, vmasr_stream_t stream);
 
+/* ---- one resolution of the multi-resolution STFT loss on (re, im) spectra (vm_asr_amd/csrc/stftloss.hip) ----------------------
+ * model/loss.py:17-45,137-184: mag = sqrt(clamp(re^2 + im^2, 1e-7)); sc = ||mag_y - mag_x||_F / ||mag_y||_F; ml = mean |log mag_y -
+ * log mag_x| for the generated signal x and the target y, n elements each (fp32, 16-byte aligned).
+ * fwd: partials (vmasr_stft_loss_blocks() x 3 fp64, scratch), out[0] = sc, out[1] = ml, out[2..3] = factors kept for the backward.
+ * bwd: fin = the forward's `out`; g_sc / g_ml: device scalars (upstream gradients; NULL = 0); d_re / d_im (n) = gradient wrt x's
+ * spectrum (exact zeros where re^2 + im^2 < 1e-7: clamp's gradient). */
+int32_t vmasr_stft_loss_blocks(void);
+int vmasr_stft_loss_fwd(const float *re_x, const float *im_x, const float *re_y, const float *im_y, int64_t n, double *partials, float *out,
+                        vmasr_stream_t stream);
+int vmasr_stft_loss_bwd(const float *re_x, const float *im_x, const float *re_y, const float *im_y, int64_t n, const float *fin,
+                        const float *g_sc, const float *g_ml, float *d_re, float *d_im, vmasr_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---------------------
  * When enabled, every kernel launch of this library is bracketed by two hipEvents
  * recorded on the stream the kernel is launched on; vmasr_prof_collect() waits for the
@@ -557,6 +569,7 @@ enum {
     VMASR_K_SS2D_DEEP_XBWD,     /* adjoint of x_proj: terms -> d(x_dbl) -> dx                                   */
     VMASR_K_OUTPROJ_FWD,        /* out_proj + DropPath + residual of a VSS block's SS2D branch as one MFMA kernel */
     VMASR_K_OUTPROJ_BWD,
+    VMASR_K_STFT_LOSS,          /* one resolution of the MR-STFT loss: three sums in one pass, finish, one backward pass */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

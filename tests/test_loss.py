@@ -49,3 +49,32 @@ def test_stft_bwd_vs_oracle_full_clip():
         want = oracle.stft_bwd(gr.numpy(), gi.numpy(), 122640, n_fft, hop, win)
         err = np.abs(x.grad.cpu().numpy() - want).max()
         assert err < 1e-4 * np.abs(want).max(), (n_fft, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 513, 37), (1, 257, 5), (3, 1025, 64)])
+def test_stft_loss_kernels_match_float64(shape):
+    """csrc/stftloss.hip (one pass for the three sums of sc / mag, one backward pass) against the float64 torch expression of
+    model/loss.py:17-45,137-184 on random spectra — including bins below the clamp (exact zero gradient there), sizes that are
+    not multiples of 4, and only one of the two upstream gradients."""
+    from vm_asr_amd.loss import _STFTLossFn
+    torch.manual_seed(shape[1])
+    rx, ix, ry, iy = (torch.randn(shape, device="cuda:0") for _ in range(4))
+    rx[0, :3, 0] = 1e-5; ix[0, :3, 0] = -2e-5                                   # below the clamp: re^2 + im^2 < 1e-7
+    ry[0, 5, 1] = 0.0; iy[0, 5, 1] = 0.0
+    for wsc, wml in ((0.7, 1.3), (1.0, 0.0), (0.0, 2.0)):
+        a, b = rx.clone().requires_grad_(), ix.clone().requires_grad_()
+        sc, ml = _STFTLossFn.apply(a, b, ry, iy)
+        terms = ([wsc * sc] if wsc else []) + ([wml * ml] if wml else [])
+        sum(terms).backward()
+        a64, b64 = rx.double().requires_grad_(), ix.double().requires_grad_()
+        mx = torch.sqrt(torch.clamp(a64 ** 2 + b64 ** 2, min=1e-7))
+        my = torch.sqrt(torch.clamp(ry.double() ** 2 + iy.double() ** 2, min=1e-7))
+        sc64 = torch.norm(my - mx, p="fro") / torch.norm(my, p="fro")
+        ml64 = torch.nn.functional.l1_loss(torch.log(my), torch.log(mx))
+        (wsc * sc64 + wml * ml64).backward()
+        assert abs(sc.item() - sc64.item()) <= 2e-6 * abs(sc64.item()) and abs(ml.item() - ml64.item()) <= 2e-6 * abs(ml64.item())
+        for got, want in ((a.grad, a64.grad), (b.grad, b64.grad)):
+            err = (got.double() - want).abs().max().item()
+            assert err <= 2e-5 * want.abs().max().item(), (shape, wsc, wml, err, want.abs().max().item())
+        assert not a.grad[0, :3, 0].any() and not b.grad[0, :3, 0].any()

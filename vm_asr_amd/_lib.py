@@ -74,6 +74,9 @@ SYMBOLS = {
     "vmasr_mlp_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_mlp_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "vmasr_stft_loss_blocks": (c_i32, []),
+    "vmasr_stft_loss_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vmasr_stft_loss_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vmasr_outproj_supported": (ctypes.c_int, [c_i32, c_i32]),
     "vmasr_outproj_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_outproj_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
@@ -199,7 +202,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 54
+K_COUNT = 55
 
 
 def zeros_f32(device, *shapes):
