@@ -33,7 +33,8 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"total self device time {tot / 1e3:.2f} ms over {sum(r[1] for r in rows)} op calls")
-for dt, n, k, sh in rows[:top]:
+flt = os.environ.get("TAIL_FILTER")        # comma-separated op names: list only those, all shapes
+for dt, n, k, sh in (rows[:top] if not flt else [r for r in rows if r[2] in flt.split(",")][:top]):
     print(f"{dt / 1e3:8.3f} ms {n:5d}  {k:40s} {sh}")
 
 if os.environ.get("TAIL_BY_NAME"):
