@@ -282,7 +282,8 @@ int vmasr_gelu_bwd(const float *pre, const float *g, float *gx, float *db, int32
  * reference; non-amsgrad, decoupled weight decay, bias correction).  `items` is a DEVICE array, one entry per tensor;
  * `chunks` a DEVICE array of (item index, chunk index) int32 pairs, one per workgroup, chunk = vmasr_adamw_chunk() elements;
  * lr and step (the step count AFTER this update, as float) are DEVICE scalars read at run time.  lp (may be NULL): bf16
- * copy of the updated parameter, written in the same pass.  vec: set when p, g, m, v are 16-byte and lp 8-byte aligned. */
+ * copy of the updated parameter, written in the same pass (lpt: the same transposed, for 2-D weights whose backward kernels read
+ * W^T rows — vm_asr_amd/mlp.py, inproj.py, outproj.py).  vec: set when p, g, m, v are 16-byte and lp 8-byte aligned. */
 typedef struct vmasr_adamw_item {
     float *p;
     const float *g;
@@ -292,6 +293,8 @@ typedef struct vmasr_adamw_item {
     int64_t n;
     float weight_decay;
     int32_t vec;
+    void *lpt;            /* (may be NULL) bf16 copy of the updated 2-D parameter TRANSPOSED: lpt[c * rows + r] = p[r * cols + c] */
+    int32_t rows, cols;
 } vmasr_adamw_item;
 int32_t vmasr_adamw_chunk(void);
 int vmasr_adamw_step(const vmasr_adamw_item *items, const int32_t *chunks, int32_t nchunks, int64_t total_elems, const float *lr,
@@ -343,6 +346,11 @@ int vmasr_masked_l1_bwd(const void *sgn, const float *gout, float *dgen, const i
  * gradient (next layer's + the loss's) in one pass */
 int vmasr_masked_l1_bwd_add(const void *sgn, const float *gout, const float *add, float *dgen, const int64_t *valid, const float *scale,
                             int32_t n, int64_t rows_g, int32_t N, vmasr_stream_t stream);
+/* LSGAN terms (model/loss.py:190-213): out[0] = sum_i mean((x_i - targets[i])^2) over `count` <= 16 fp32 score tensors of ns[i]
+ * elements (xs, ns, targets: HOST arrays), one launch; bwd: ds[i] (ns[i]) = 2 (x_i - targets[i]) gout[0] / ns[i], one launch. */
+int vmasr_lsgan_fwd(const void *const *xs, const int64_t *ns, const float *targets, int32_t count, float *out, vmasr_stream_t stream);
+int vmasr_lsgan_bwd(const void *const *xs, void *const *ds, const int64_t *ns, const float *targets, int32_t count, const float *gout,
+                    vmasr_stream_t stream);
 
 /* ---- fused SS2D core (vm_asr_amd/csrc/ss2d.hip) ---------------------------------------------------------
  * One operator for  y = CrossMerge(selective_scan(CrossScan(x), dt_proj(x_proj(.)), A, B, C, D, dt_bias, softplus))

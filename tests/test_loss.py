@@ -78,3 +78,26 @@ def test_stft_loss_kernels_match_float64(shape):
             err = (got.double() - want).abs().max().item()
             assert err <= 2e-5 * want.abs().max().item(), (shape, wsc, wml, err, want.abs().max().item())
         assert not a.grad[0, :3, 0].any() and not b.grad[0, :3, 0].any()
+
+
+@pytest.mark.gpu
+def test_lsgan_terms_kernel_matches_torch():
+    """HiFiGANLoss('lsgan') discriminator / generator losses through csrc/featloss.hip's one-launch LSGAN kernels against the
+    per-tensor torch expression of model/loss.py:190-213 in float64: values and the gradient of every score tensor."""
+    from vm_asr_amd.loss import HiFiGANLoss
+    torch.manual_seed(0)
+    L = HiFiGANLoss("lsgan")
+    sizes = [(4, 7013), (4, 4675), (4, 2805), (4, 2004), (4, 1276)]
+    real = [torch.randn(s, device="cuda:0").requires_grad_() for s in sizes]
+    gen = [torch.randn(s, device="cuda:0").requires_grad_() for s in sizes]
+    d = L.discriminator_loss(real, gen)
+    g = L.generator_loss(gen)
+    (1.5 * d + 0.5 * g).backward()
+    r64 = [t.detach().double().requires_grad_() for t in real]
+    g64 = [t.detach().double().requires_grad_() for t in gen]
+    d64 = sum(torch.mean((a - 1) ** 2) + torch.mean(b ** 2) for a, b in zip(r64, g64))
+    gg64 = sum(torch.mean((1 - b) ** 2) for b in g64)
+    (1.5 * d64 + 0.5 * gg64).backward()
+    assert abs(d.item() - d64.item()) <= 1e-6 * d64.item() and abs(g.item() - gg64.item()) <= 1e-6 * gg64.item()
+    for a, b in zip(real + gen, r64 + g64):       # (the two terms' gradients of a generated score partly cancel: absolute bound)
+        assert (a.grad.double() - b.grad).abs().max().item() <= 2e-6 * b.grad.abs().max().item()

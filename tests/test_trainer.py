@@ -153,7 +153,7 @@ def test_train_step_gpu_lp_shadows(monkeypatch):
     """bf16 autocast step on the GPU (HIP kernels): the trainer's bf16 shadow weights give the same update
     as casting every weight in every forward, stay equal to the fp32 weights' bf16 rounding, and the
     HIP-graph replay of the step matches the eager step."""
-    from vm_asr_amd.linear import LP_ATTR
+    from vm_asr_amd.linear import LP_ATTR, LPT_ATTR
     cfg = _tiny_config()
     batch = [t.cuda() for t in _batch(cfg, 2)]
     results = {}
@@ -170,8 +170,40 @@ def test_train_step_gpu_lp_shadows(monkeypatch):
         if shadows == "1":
             for p in tr.models["generator"].parameters():
                 assert torch.equal(getattr(p, LP_ATTR), p.detach().to(torch.bfloat16))
+                if p.dim() == 2:     # the transposed shadows (operands of the fused kernels' backward) follow too
+                    assert torch.equal(getattr(p, LPT_ATTR), p.detach().to(torch.bfloat16).t())
     worst = max((results["1"][k] - results["0"][k]).abs().max().item() for k in results["1"])
     assert worst <= 2e-3, worst       # AdamW steps are lr-sized (1e-4..1e-3): same update direction everywhere
+
+
+@pytest.mark.gpu
+def test_shadows_follow_the_hip_adamw_kernel():
+    """Capturable optimisers + flat gradient buffers: the one-launch HIP AdamW (csrc/adamw.hip) writes the bf16 shadow AND the
+    transposed bf16 shadow of every weight it updates; after three steps both equal the bf16 rounding of the fp32 weights."""
+    from vm_asr_amd.linear import LP_ATTR, LPT_ATTR
+    cfg = _tiny_config()
+    batch = [t.cuda() for t in _batch(cfg, 2)]
+    tr = _gpu_trainer(cfg, amp=True, capturable=True)
+    for m in tr.models.values():
+        m.train()
+    assert tr.enable_graphs(batch, warmup=3)          # flat gradient buffers + the HIP AdamW table live in the graphed step
+    before = {n: p.detach().clone() for n, p in tr.models["generator"].named_parameters()}
+    for p in tr.models["generator"].parameters():     # (after the warm-up's restore the shadows match the restored weights)
+        assert torch.equal(getattr(p, LP_ATTR), p.detach().to(torch.bfloat16))
+    for _ in range(3):
+        tr.train_step(*batch)
+    torch.cuda.synchronize()
+    assert getattr(tr, "_hip_adamw", None), "the HIP AdamW path did not engage"
+    moved = n2d = 0
+    for n, p in tr.models["generator"].named_parameters():
+        if p.grad is None:
+            continue
+        moved += int(not torch.equal(p.detach(), before[n]))
+        assert torch.equal(getattr(p, LP_ATTR), p.detach().to(torch.bfloat16)), n
+        if p.dim() == 2:
+            n2d += 1
+            assert torch.equal(getattr(p, LPT_ATTR), p.detach().to(torch.bfloat16).t()), n
+    assert moved > 0 and n2d > 0
 
 
 @pytest.mark.gpu

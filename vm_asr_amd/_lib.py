@@ -119,6 +119,8 @@ SYMBOLS = {
     "vmasr_masked_l1_blocks": (c_i32, []),
     "vmasr_masked_l1_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "vmasr_masked_l1_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "vmasr_lsgan_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "vmasr_lsgan_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "vmasr_masked_l1_bwd_add": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_sum_parts": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "vmasr_weight_prep_split": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

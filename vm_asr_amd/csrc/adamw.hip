@@ -32,6 +32,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(const vmasr_adamw_item *__re
     float *p = it.p + base, *m = it.m + base, *v = it.v + base;
     const float *g = it.g + base;
     bf16_t *lp = it.lp ? static_cast<bf16_t *>(it.lp) + base : nullptr;
+    bf16_t *lpt = static_cast<bf16_t *>(it.lpt);            // transposed shadow (2-D weights): scattered 2-byte stores, few MB in all
+    const int rows = it.rows, cols = it.cols;
+    auto put_t = [&](const long i, const float P) {        // i: index within this chunk
+        const long gi = base + i;
+        const int r = (int)(gi / cols), c = (int)(gi - (long)r * cols);
+        lpt[(size_t)c * rows + r] = (bf16_t)P;
+    };
     auto upd = [&](float &pp, float gg, float &mm, float &vv) {
         pp *= decay;
         mm = fmaf(1.f - b1, gg - mm, mm);
@@ -52,12 +59,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(const vmasr_adamw_item *__re
                 o.b[0] = (bf16_t)P.x; o.b[1] = (bf16_t)P.y; o.b[2] = (bf16_t)P.z; o.b[3] = (bf16_t)P.w;
                 reinterpret_cast<uint2 *>(lp)[i] = o.raw;
             }
+            if (lpt) { put_t(4 * i, P.x); put_t(4 * i + 1, P.y); put_t(4 * i + 2, P.z); put_t(4 * i + 3, P.w); }
         }
         for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
             float P = p[i], M = m[i], V = v[i];
             upd(P, g[i], M, V);
             p[i] = P; m[i] = M; v[i] = V;
             if (lp) lp[i] = (bf16_t)P;
+            if (lpt) put_t(i, P);
         }
     } else {
         for (long i = threadIdx.x; i < n; i += 256) {
@@ -65,6 +74,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const vmasr_adamw_item *__re
             upd(P, g[i], M, V);
             p[i] = P; m[i] = M; v[i] = V;
             if (lp) lp[i] = (bf16_t)P;
+            if (lpt) put_t(i, P);
         }
     }
 }

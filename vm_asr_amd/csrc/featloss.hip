@@ -144,3 +144,93 @@ VMASR_EXPORT int vmasr_masked_l1_bwd(const void *sgn, const float *gout, float *
                                      int64_t rows_g, int32_t N, vmasr_stream_t stream) {
     return vmasr_masked_l1_bwd_add(sgn, gout, nullptr, dgen, valid, scale, n, rows_g, N, stream);
 }
+
+// ---- LSGAN terms over a list of score tensors ---------------------------------------------------------------------------------
+// model/loss.py:190-213: sum_i mean((t_i - c_i)^2) over the discriminators' score tensors (5 per signal; c = 1 for "real", 0 for
+// "generated" targets).  As ATen ops: sub, pow, mean and an add per tensor forward, ~6 more backward — ~135 launches of 3-5 us per
+// training step over ~6 000-element tensors.  One workgroup walks all tensors (fixed order: deterministic), one launch forms all
+// gradients 2 (t_i - c_i) g / n_i.
+namespace vmasr {
+namespace {
+
+constexpr int kGanMax = 16;
+struct GanItems {
+    const float *x[kGanMax];
+    float *d[kGanMax];
+    long n[kGanMax];
+    float c[kGanMax];
+    int count;
+};
+
+__global__ __launch_bounds__(1024) void lsgan_fwd_kernel(const GanItems t, float *__restrict__ out) {
+    __shared__ double ws[16];
+    double total = 0.0;                                  // (thread 0 only)
+    for (int it = 0; it < t.count; ++it) {
+        const float *__restrict__ x = t.x[it];
+        const float c = t.c[it];
+        double acc = 0.0;
+        for (long i = threadIdx.x; i < t.n[it]; i += blockDim.x) {
+            const float d = x[i] - c;
+            acc += (double)(d * d);
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < 16; ++w) s += ws[w];
+            total += s / (double)t.n[it];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)total;
+}
+
+// grid (blocks, count)
+__global__ __launch_bounds__(256) void lsgan_bwd_kernel(const GanItems t, const float *__restrict__ gout) {
+    const int it = blockIdx.y;
+    const float *__restrict__ x = t.x[it];
+    float *__restrict__ d = t.d[it];
+    const float c = t.c[it], k = 2.f * gout[0] / (float)t.n[it];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t.n[it]; i += (long)gridDim.x * blockDim.x) d[i] = k * (x[i] - c);
+}
+
+int gan_fill(GanItems &t, const void *const *xs, void *const *ds, const int64_t *ns, const float *cs, int count, const char *what) {
+    VMASR_REQUIRE(xs && ns && cs && count > 0 && count <= kGanMax, VMASR_EINVAL, "%s: 1..%d tensors", what, kGanMax);
+    t.count = count;
+    for (int i = 0; i < count; ++i) {
+        VMASR_REQUIRE(xs[i] && ns[i] > 0 && (!ds || ds[i]), VMASR_EINVAL, "%s: tensor %d null / empty", what, i);
+        t.x[i] = static_cast<const float *>(xs[i]);
+        t.d[i] = ds ? static_cast<float *>(ds[i]) : nullptr;
+        t.n[i] = ns[i];
+        t.c[i] = cs[i];
+    }
+    return 0;
+}
+
+}  // namespace
+}  // namespace vmasr
+
+VMASR_EXPORT int vmasr_lsgan_fwd(const void *const *xs, const int64_t *ns, const float *targets, int32_t count, float *out,
+                                 vmasr_stream_t stream) {
+    VMASR_REQUIRE(out, VMASR_EINVAL, "lsgan_fwd: null output");
+    GanItems t{};
+    if (int e = gan_fill(t, xs, nullptr, ns, targets, count, "lsgan_fwd")) return e;
+    double bytes = 0;
+    for (int i = 0; i < count; ++i) bytes += 4.0 * ns[i];
+    VMASR_LAUNCH(VMASR_K_FEAT_L1, bytes, lsgan_fwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), t, out);
+    return check_launch("lsgan_fwd");
+}
+
+VMASR_EXPORT int vmasr_lsgan_bwd(const void *const *xs, void *const *ds, const int64_t *ns, const float *targets, int32_t count,
+                                 const float *gout, vmasr_stream_t stream) {
+    VMASR_REQUIRE(gout && ds, VMASR_EINVAL, "lsgan_bwd: null argument");
+    GanItems t{};
+    if (int e = gan_fill(t, xs, ds, ns, targets, count, "lsgan_bwd")) return e;
+    long nmax = 0;
+    double bytes = 0;
+    for (int i = 0; i < count; ++i) { nmax = std::max<long>(nmax, ns[i]); bytes += 8.0 * ns[i]; }
+    const int blocks = (int)std::min<long>((nmax + 255) / 256, 64);
+    VMASR_LAUNCH(VMASR_K_FEAT_L1, bytes, lsgan_bwd_kernel, dim3(blocks, count), dim3(256), 0, static_cast<hipStream_t>(stream), t, gout);
+    return check_launch("lsgan_bwd");
+}

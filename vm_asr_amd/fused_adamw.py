@@ -14,15 +14,16 @@ from . import _lib
 
 __all__ = ["HipAdamWStep"]
 
-_ITEM = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("lp", "u8"), ("n", "i8"), ("wd", "f4"), ("vec", "i4")])
+_ITEM = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("lp", "u8"), ("n", "i8"), ("wd", "f4"), ("vec", "i4"),
+                  ("lpt", "u8"), ("rows", "i4"), ("cols", "i4")])
 
 
 class HipAdamWStep:
     """step() == optimizer.step() for a capturable torch.optim.AdamW (non-amsgrad, no maximize) whose parameters'
     `.grad` are fixed views (the trainer's flat gradient buffers).  `shadows`: {id(param): bf16 tensor} refreshed in
-    the same pass.  Raises ValueError if the optimiser does not qualify (the caller keeps optimizer.step())."""
+    the same pass; `shadows_t`: {id(2-D param): bf16 tensor of the transposed shape}, likewise.  Raises ValueError if the optimiser does not qualify (the caller keeps optimizer.step())."""
 
-    def __init__(self, optimizer, shadows=None):
+    def __init__(self, optimizer, shadows=None, shadows_t=None):
         if not isinstance(optimizer, torch.optim.AdamW):
             raise ValueError("not an AdamW")
         groups = optimizer.param_groups
@@ -38,7 +39,7 @@ class HipAdamWStep:
         if self.lr is None:
             raise ValueError("learning-rate tensor must be float32")
         self.betas, self.eps = (float(g0["betas"][0]), float(g0["betas"][1])), float(g0["eps"])
-        shadows = shadows or {}
+        shadows, shadows_t = shadows or {}, shadows_t or {}
         chunk = _lib.lib().vmasr_adamw_chunk()
         items, chunks, steps, keep = [], [], [], []
         for g in groups:
@@ -55,13 +56,19 @@ class HipAdamWStep:
                       and (lp is None or (lp.is_contiguous() and lp.dtype == torch.bfloat16 and lp.shape == p.shape)))
                 if not ok:
                     raise ValueError("a parameter / state tensor does not qualify (dtype, device or layout)")
+                lpt = shadows_t.get(id(p))
+                if lpt is not None and not (p.dim() == 2 and lpt.is_contiguous() and lpt.dtype == torch.bfloat16
+                                            and tuple(lpt.shape) == (p.shape[1], p.shape[0])):
+                    raise ValueError("a transposed shadow does not match its parameter")
                 ptrs = [p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr()]
                 vec = all(q % 16 == 0 for q in ptrs) and (lp is None or lp.data_ptr() % 8 == 0)
                 idx = len(items)
-                items.append((*ptrs, lp.data_ptr() if lp is not None else 0, p.numel(), float(g["weight_decay"]), int(vec)))
+                items.append((*ptrs, lp.data_ptr() if lp is not None else 0, p.numel(), float(g["weight_decay"]), int(vec),
+                              lpt.data_ptr() if lpt is not None else 0, p.shape[0] if lpt is not None else 0,
+                              p.shape[1] if lpt is not None else 0))
                 chunks.extend((idx, c) for c in range(-(-p.numel() // chunk)))
                 steps.append(step)
-                keep.append((p, p.grad, m, v, lp))
+                keep.append((p, p.grad, m, v, (lp, lpt)))
         if not items:
             raise ValueError("no parameter with a gradient")
         # the kernel takes ONE step count for the bias corrections (torch uses each tensor's own): every state must be at

@@ -16,6 +16,7 @@ import torch
 from . import _lib
 from . import layernorm as _ln
 from .linear import LP_ATTR, weight_grad
+from .mlp import _bf16_t
 
 __all__ = ["fused_in_proj", "supported"]
 
@@ -66,6 +67,7 @@ class _InProjFn(torch.autograd.Function):
         ctx.save_for_backward(x2, g32 if g32 is not None else torch.empty(0, device=x.device),
                               b32 if b32 is not None else torch.empty(0, device=x.device), wb)
         ctx.meta = (x.shape, eps, gamma is not None, None if gamma is None else gamma.dtype, None if beta is None else beta.dtype, weight.dtype)
+        ctx.wt = _bf16_t(weight, wb)
         if gamma is not None and any(ctx.needs_input_grad[1:3]):
             _ln.note_use(gamma, beta)
         ctx.fresh = lambda: gamma is not None and gamma.grad is None and beta.grad is None and _ln.used_once(gamma, beta)
@@ -84,7 +86,7 @@ class _InProjFn(torch.autograd.Function):
         dxT = (torch.zeros((B, 2 * d, H, W), **bf) if dxT is None else dxT.to(torch.bfloat16)).contiguous()
         dsz = (torch.zeros((B, H, W, 2 * d), **bf) if dsz is None else dsz.to(torch.bfloat16)).contiguous()
         with torch.cuda.device(dev):
-            wt = wb.t().contiguous()
+            wt = ctx.wt if ctx.wt is not None else wb.t().contiguous()
             dxn = torch.empty((rows, d), **bf)
             xn = torch.empty((rows, d), **bf)
             gpre = torch.empty((rows, 4 * d), **bf)

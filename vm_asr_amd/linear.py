@@ -122,6 +122,7 @@ def weight_grad(gy2, x2, splits=None):
 
 
 LP_ATTR = "_vmasr_lp"   # parameter attribute: low-precision (autocast dtype) shadow copy kept by the trainer
+LPT_ATTR = "_vmasr_lpT"  # the same TRANSPOSED (2-D weights): operand of the fused kernels' backward (mlp.py, inproj.py, outproj.py)
 
 
 def _shadow(t, like, cdt):

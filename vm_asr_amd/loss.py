@@ -116,11 +116,57 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         return self.factor_sc * sc_loss / n, self.factor_mag * mag_loss / n
 
 
+class _LSGANFn(torch.autograd.Function):
+    """sum_i mean((t_i - c_i)^2) over a list of fp32 score tensors in one launch, all gradients in one (csrc/featloss.hip)."""
+
+    @staticmethod
+    def forward(ctx, targets, *ts):
+        ts = tuple(t.contiguous() for t in ts)
+        n, dev = len(ts), ts[0].device
+        xs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ns = (ctypes.c_int64 * n)(*[t.numel() for t in ts])
+        cs = (ctypes.c_float * n)(*targets)
+        with torch.cuda.device(dev):
+            out = torch.empty(1, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().vmasr_lsgan_fwd(xs, ns, cs, n, _p(out), _lib.current_stream(dev)), "lsgan_fwd")
+        ctx.save_for_backward(*ts)
+        ctx.targets = targets
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ts = ctx.saved_tensors
+        n, dev = len(ts), ts[0].device
+        g = g.float().reshape(1).contiguous()
+        with torch.cuda.device(dev):
+            ds = [torch.empty_like(t) for t in ts]
+            xs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in ds])
+            ns = (ctypes.c_int64 * n)(*[t.numel() for t in ts])
+            cs = (ctypes.c_float * n)(*ctx.targets)
+            _lib.check(_lib.lib().vmasr_lsgan_bwd(xs, dp, ns, cs, n, _p(g), _lib.current_stream(dev)), "lsgan_bwd")
+        return (None, *ds)
+
+
+def _lsgan_terms(pairs):
+    """sum over (tensor, target) pairs of mean((tensor - target)^2); one HIP launch when every tensor is fp32 on the GPU."""
+    ts = [t for t, _ in pairs]
+    if (ts and len(ts) <= 16 and all(t.is_cuda and t.dtype == torch.float32 and t.numel() > 0 for t in ts)
+            and os.environ.get("VMASR_LSGAN", "1") == "1"):
+        return _LSGANFn.apply(tuple(float(c) for _, c in pairs), *ts)
+    loss = 0
+    for t, c in pairs:
+        loss = loss + torch.mean((t - c) ** 2)
+    return loss
+
+
 class HiFiGANLoss:
     def __init__(self, gan_loss_type, gp_weight=10):
         self.gan_loss_type, self.gp_weight = gan_loss_type, gp_weight
 
     def discriminator_loss(self, real_data, generated_data):
+        if self.gan_loss_type == "lsgan":
+            return _lsgan_terms([(dr, 1.0) for dr in real_data] + [(dg, 0.0) for dg in generated_data])
         loss = 0
         for dr, dg in zip(real_data, generated_data):
             if self.gan_loss_type == "lsgan":
@@ -130,6 +176,8 @@ class HiFiGANLoss:
         return loss
 
     def generator_loss(self, disc_outputs):
+        if self.gan_loss_type == "lsgan":
+            return _lsgan_terms([(dg, 1.0) for dg in disc_outputs])
         loss = 0
         for dg in disc_outputs:
             if self.gan_loss_type == "lsgan":

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from . import layernorm as _ln
-from .linear import LP_ATTR, weight_grad
+from .linear import LP_ATTR, LPT_ATTR, weight_grad
 
 __all__ = ["fused_mlp_residual", "supported"]
 
@@ -50,6 +50,16 @@ def _bf16(w):
     return sh if (sh is not None and sh.dtype == torch.bfloat16) else w.detach().to(torch.bfloat16)
 
 
+def _bf16_t(w, wb):
+    """W^T (bf16, contiguous) for the backward kernels when the trainer keeps a transposed shadow of parameter `w` and the
+    forward used its shadow `wb` (both are refreshed together by the AdamW kernel); None -> the caller transposes `wb` itself."""
+    sh = getattr(w, LPT_ATTR, None)
+    if (sh is not None and getattr(w, LP_ATTR, None) is wb and sh.dtype == torch.bfloat16 and wb.dim() == 2
+            and tuple(sh.shape) == (wb.shape[1], wb.shape[0])):
+        return sh
+    return None
+
+
 class _FusedMlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, w1, b1, w2, b2, scale, eps):
@@ -68,6 +78,7 @@ class _FusedMlpFn(torch.autograd.Function):
             _lib.check(_lib.lib().vmasr_mlp_fwd(_p(x2), _p(g32), _p(be32), float(eps), _p(w1b), _p(b1f), _p(w2b), _p(b2f), _p(sc), rps,
                                                 _p(y), rows, d, _lib.torch_dtype_code(x2.dtype), _lib.current_stream(x.device)), "mlp_fwd")
         ctx.save_for_backward(x2, g32, be32, w1b, b1f, w2b, sc)
+        ctx.wts = (_bf16_t(w1, w1b), _bf16_t(w2, w2b))
         ctx.meta = (x.shape, eps, rps, gamma.dtype, beta.dtype, w1.dtype, b1.dtype, w2.dtype, b2.dtype)
         if any(ctx.needs_input_grad[1:3]):
             _ln.note_use(gamma, beta)
@@ -88,7 +99,8 @@ class _FusedMlpFn(torch.autograd.Function):
         dev = x2.device
         bf = dict(dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
-            w1t, w2t = w1b.t().contiguous(), w2b.t().contiguous()
+            w1t = ctx.wts[0] if ctx.wts[0] is not None else w1b.t().contiguous()
+            w2t = ctx.wts[1] if ctx.wts[1] is not None else w2b.t().contiguous()
             dxn = torch.empty((rows, d), **bf)
             xn_aug = torch.empty((rows, d + 8), **bf)
             gys = torch.empty((rows, d), **bf)

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from .linear import weight_grad
-from .mlp import _bf16
+from .mlp import _bf16, _bf16_t
 
 __all__ = ["fused_out_proj_residual", "supported"]
 
@@ -60,6 +60,7 @@ class _OutProjFn(torch.autograd.Function):
             _lib.check(_lib.lib().vmasr_outproj_fwd(_p(g2), _p(wb), _p(x2), _p(sc), rps, _p(y), rows, d, _lib.torch_dtype_code(x2.dtype),
                                                     _lib.current_stream(x.device)), "outproj_fwd")
         ctx.save_for_backward(g2, wb, sc)
+        ctx.wt = _bf16_t(w, wb)
         ctx.meta = (g.shape, x.shape, x2.dtype, rps, w.dtype)
         return y.view(x.shape)
 
@@ -76,7 +77,7 @@ class _OutProjFn(torch.autograd.Function):
             gy2 = gy2.contiguous()
         dev = g2.device
         with torch.cuda.device(dev):
-            wt = wb.t().contiguous()                                        # (2d, d)
+            wt = ctx.wt if ctx.wt is not None else wb.t().contiguous()      # (2d, d)
             dg = torch.empty((rows, di), dtype=torch.bfloat16, device=dev)
             gys = torch.empty((rows, d), dtype=torch.bfloat16, device=dev)
             _lib.check(_lib.lib().vmasr_outproj_bwd(_p(gy2), _p(wt), _p(sc), rps, _p(dg), _p(gys), rows, d, _lib.torch_dtype_code(gy2.dtype),

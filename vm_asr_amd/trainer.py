@@ -746,7 +746,7 @@ class Trainer(BaseTrainer):
             return None
         shadows = {id(src): dst for src, dst in zip(self._shadow_params, self._shadow_dst)}
         try:
-            built = [HipAdamWStep(o, shadows) for _, o in opts]
+            built = [HipAdamWStep(o, shadows, getattr(self, "_shadow_t", None)) for _, o in opts]
         except ValueError as e:
             if "not initialised" in str(e):
                 return None                       # first step: torch creates the state, the next call builds the table
@@ -767,8 +767,9 @@ class Trainer(BaseTrainer):
         """Under AMP on the GPU every parameter gets a bf16 shadow copy (attribute linear.LP_ATTR) that
         vm_asr_amd.linear uses instead of casting the fp32 weight in every forward (300 cast kernels
         per step); the copies are refreshed by one multi-tensor copy after the optimiser steps."""
-        from .linear import LP_ATTR
+        from .linear import LP_ATTR, LPT_ATTR
         self._shadow_src, self._shadow_dst, self._shadow_params = [], [], []
+        self._shadow_t, self._shadow_t_view, self._shadow_t_src = {}, [], []      # transposed shadows of the 2-D weights
         if not (self.amp and self.device.type == "cuda") or os.environ.get("VMASR_LP_SHADOWS", "1") != "1":
             return
         for key, m in self.models.items():
@@ -783,11 +784,19 @@ class Trainer(BaseTrainer):
                     self._shadow_src.append(p.detach())
                     self._shadow_dst.append(lp)
                     self._shadow_params.append(p)
+                    if p.dim() == 2 and os.environ.get("VMASR_LP_SHADOWS_T", "1") == "1":
+                        lpt = lp.t().contiguous()          # refreshed with lp: by the AdamW kernel, or _refresh_shadows
+                        setattr(p, LPT_ATTR, lpt)
+                        self._shadow_t[id(p)] = lpt
+                        self._shadow_t_view.append(lpt.t())
+                        self._shadow_t_src.append(p.detach())
 
     def _refresh_shadows(self):
         """bf16 shadows <- fp32 parameters (one multi-tensor copy): after optimizer.step() / load_state_dict."""
         if self._shadow_dst:
             torch._foreach_copy_(self._shadow_dst, self._shadow_src)
+        if getattr(self, "_shadow_t_view", None):
+            torch._foreach_copy_(self._shadow_t_view, self._shadow_t_src)
 
     def train_step(self, wave_input, wave_target, highcut):
         """One optimisation step of G (and D); returns (wave_out, dict of loss tensors)."""
