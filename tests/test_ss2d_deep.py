@@ -7,9 +7,11 @@ import pytest
 import torch
 
 # (B, d_inner, H, W, dt_rank): the three deep call shapes of vm_asr_48k (64x64x64 r2, 128x32x32 r4, 256x16x16 r8) at B = 1 and 2,
-# non-square images, every waves-per-row count (1, 2, 4, 8, 16), the d_inner 512 / dt_rank 16 stage of the DIMS-32 configs
+# non-square images, every waves-per-row count (1, 2, 4, 8, 16), the d_inner 512 / dt_rank 16 stage of the DIMS-32 configs; d_inner in
+# {64, 96, 128, 256, 512} x dt_rank in {2, 4, 8, 16} each covered at least twice
 SHAPES = [(1, 64, 64, 64, 2), (2, 128, 32, 32, 4), (2, 256, 16, 16, 8), (1, 64, 32, 16, 2), (1, 96, 16, 32, 4), (1, 64, 8, 32, 8),
-          (1, 64, 64, 32, 4), (1, 512, 16, 16, 8), (1, 512, 16, 16, 16), (1, 256, 32, 16, 16)]
+          (1, 64, 64, 32, 4), (1, 512, 16, 16, 8), (1, 512, 16, 16, 16), (1, 256, 32, 16, 16), (1, 128, 16, 16, 2), (1, 512, 16, 32, 4),
+          (1, 128, 16, 32, 16), (1, 256, 64, 64, 2)]
 NAMES = ["y", "dx", "dWx", "dWdt", "ddtb", "dA_logs", "dDs"]
 
 
