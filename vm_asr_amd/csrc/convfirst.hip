@@ -192,7 +192,13 @@ VMASR_EXPORT int vmasr_conv_first_bwd(const void *const *xs, const int64_t *Ns, 
     CfSlots t{};
     if (int e = cf_fill(t, xs, Ns, Hs, n, rows, "conv_first_bwd")) return e;
     if (!dcols && !dw && !db) return VMASR_OK;
-    const int blocks = (int)std::min<long>((rows + 31) / 32, 256L * 8);
+    // every workgroup ends in 192 atomics on the SAME 160 + 32 addresses of its slot: they serialise (~13 ns each per address), so few,
+    // long-running workgroups win — measured in the step at B = 4 (average launch of the conv_first / conv_post kernel family, 10 per
+    // step, only this cap varied): 2048 workgroups per slot 82.5 us, 1024 -> 65.8, 512 -> 56.2, 384 -> 57.6, 256 -> 53.5, 128 -> 61.0
+#ifndef VMASR_CF_BWD_BLOCKS
+#define VMASR_CF_BWD_BLOCKS 256L
+#endif
+    const int blocks = (int)std::min<long>((rows + 31) / 32, VMASR_CF_BWD_BLOCKS);
     VMASR_LAUNCH(VMASR_K_CONV_POST, 8.0 * n * (double)rows * kCfN, conv_first_bwd_kernel, dim3(blocks, n), dim3(256), 0,
                  static_cast<hipStream_t>(stream), t, w, pre, g, dcols, dw, db, (long)rows);
     return check_launch("conv_first_bwd");

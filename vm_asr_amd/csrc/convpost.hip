@@ -24,7 +24,10 @@ constexpr int kCpSlots = 8;
 // and one row load in flight per wave — measured 2.0 TB/s at 32 / 64 rows per wave.  Short runs re-read two neighbour rows per
 // run (L2 hits); the weight-gradient variant folds 3 C sums per workgroup into atomics, so it keeps longer runs.
 constexpr int kCpRunFwd = 8;
-constexpr int kCpRunBwdDx = 8, kCpRunBwdDw = 32;
+#ifndef VMASR_CP_RUN_DW
+#define VMASR_CP_RUN_DW 32
+#endif
+constexpr int kCpRunBwdDx = 8, kCpRunBwdDw = VMASR_CP_RUN_DW;
 
 struct CpSlots {
     long M[kCpSlots];

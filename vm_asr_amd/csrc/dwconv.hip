@@ -6,12 +6,19 @@
 // Backward is two passes: (A) recompute the pre-activation, form gp = gy * silu'(pre),
 // store it and reduce dw (9 taps) / db per workgroup -> a handful of float atomics;
 // (B) dx = transposed stencil of gp.
+#include <algorithm>
+
 #include "common.h"
 
 namespace vmasr {
 namespace {
 
-constexpr int kChunk = 4096;  // elements of one (b,c) plane per workgroup
+// elements of one (b,c) plane per workgroup.  Measured in the step (make VARIANT=... DEFS=-DVMASR_DW_CHUNK=...): 4096 -> forward 11.1 us,
+// backward A 17.2, B 8.9 us per launch; 2048 -> 9.2 / 16.9 / 8.3; 1024 -> 8.3 / 21.1 (four times the atomics per channel) / 8.2
+#ifndef VMASR_DW_CHUNK
+#define VMASR_DW_CHUNK 2048
+#endif
+constexpr int kChunk = VMASR_DW_CHUNK;
 
 // v_rcp_f32 (1 ulp) instead of the ~12-instruction IEEE division sequence
 __device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
@@ -35,7 +42,7 @@ __device__ __forceinline__ float conv_at(const T *__restrict__ xp, const float (
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
                                                               const float *__restrict__ bias, T *__restrict__ y,
-                                                              const int C, const int H, const int W) {
+                                                              const int C, const int H, const int W, const int chunk) {
     const int c = blockIdx.y, b = blockIdx.z;
     const int HW = H * W;
     const T *xp = x + ((size_t)b * C + c) * HW;
@@ -44,8 +51,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const T *__restric
 #pragma unroll
     for (int k = 0; k < 9; ++k) wr[k] = w[c * 9 + k];
     const float bv = bias ? bias[c] : 0.f;
-    const int l_end = min(HW, (int)(blockIdx.x + 1) * kChunk);
-    for (int l = blockIdx.x * kChunk + threadIdx.x; l < l_end; l += 256) {
+    const int l_end = min(HW, (int)(blockIdx.x + 1) * chunk);
+    for (int l = blockIdx.x * chunk + threadIdx.x; l < l_end; l += 256) {
         const int h = l / W, ww = l - h * W;
         float taps[9];
         const float pre = conv_at(xp, wr, bv, h, ww, H, W, taps);
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_a_kernel(const T *__restr
                                                                 const float *__restrict__ bias,
                                                                 const T *__restrict__ gy, float *__restrict__ gp,
                                                                 float *__restrict__ dw, float *__restrict__ db,
-                                                                const int C, const int H, const int W) {
+                                                                const int C, const int H, const int W, const int chunk) {
     __shared__ float s_part[4][10];
     const int c = blockIdx.y, b = blockIdx.z;
     const int HW = H * W;
@@ -71,8 +78,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_a_kernel(const T *__restr
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.f;
     const float bv = bias ? bias[c] : 0.f;
-    const int l_end = min(HW, (int)(blockIdx.x + 1) * kChunk);
-    for (int l = blockIdx.x * kChunk + threadIdx.x; l < l_end; l += 256) {
+    const int l_end = min(HW, (int)(blockIdx.x + 1) * chunk);
+    for (int l = blockIdx.x * chunk + threadIdx.x; l < l_end; l += 256) {
         const int h = l / W, ww = l - h * W;
         float taps[9];
         const float pre = conv_at(xp, wr, bv, h, ww, H, W, taps);
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_a_kernel(const T *__restr
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_silu_bwd_b_kernel(const float *__restrict__ gp, const float *__restrict__ w,
                                                                 T *__restrict__ dx, const int C, const int H,
-                                                                const int W) {
+                                                                const int W, const int chunk) {
     const int c = blockIdx.y, b = blockIdx.z;
     const int HW = H * W;
     const float *gpp = gp + ((size_t)b * C + c) * HW;
@@ -108,8 +115,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_b_kernel(const float *__r
     float wr[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wr[k] = w[c * 9 + k];
-    const int l_end = min(HW, (int)(blockIdx.x + 1) * kChunk);
-    for (int l = blockIdx.x * kChunk + threadIdx.x; l < l_end; l += 256) {
+    const int l_end = min(HW, (int)(blockIdx.x + 1) * chunk);
+    for (int l = blockIdx.x * chunk + threadIdx.x; l < l_end; l += 256) {
         const int h = l / W, ww = l - h * W;
         float acc = 0.f;
 #pragma unroll
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_vec_kernel(const T *__restric
                                                               const float *__restrict__ bias, const T *__restrict__ gy,
                                                               T *__restrict__ y, float *__restrict__ gp,
                                                               float *__restrict__ dw, float *__restrict__ db,
-                                                              const int C, const int H, const int W) {
+                                                              const int C, const int H, const int W, const int chunk) {
     __shared__ float s_part[4][10];
     const int c = blockIdx.y, b = blockIdx.z;
     const int HW = H * W;
@@ -161,8 +168,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_vec_kernel(const T *__restric
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.f;
     const float bv = bias ? bias[c] : 0.f;
-    const int l_end = min(HW, (int)(blockIdx.x + 1) * kChunk);
-    for (int l = blockIdx.x * kChunk + threadIdx.x * 4; l < l_end; l += 1024) {
+    const int l_end = min(HW, (int)(blockIdx.x + 1) * chunk);
+    for (int l = blockIdx.x * chunk + threadIdx.x * 4; l < l_end; l += 1024) {
         const int h = l / W, w0 = l - h * W;
         float r0[6], r1[6], r2[6];
         load_row6(xp + (size_t)(h - 1) * W, h > 0, w0, W, r0);
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_vec_kernel(const T *__restric
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_silu_bwd_b_vec_kernel(const float *__restrict__ gp, const float *__restrict__ w,
                                                                     T *__restrict__ dx, const int C, const int H,
-                                                                    const int W) {
+                                                                    const int W, const int chunk) {
     const int c = blockIdx.y, b = blockIdx.z;
     const int HW = H * W;
     const size_t plane = ((size_t)b * C + c) * HW;
@@ -219,8 +226,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_b_vec_kernel(const float 
     float wr[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wr[k] = w[c * 9 + k];
-    const int l_end = min(HW, (int)(blockIdx.x + 1) * kChunk);
-    for (int l = blockIdx.x * kChunk + threadIdx.x * 4; l < l_end; l += 1024) {
+    const int l_end = min(HW, (int)(blockIdx.x + 1) * chunk);
+    for (int l = blockIdx.x * chunk + threadIdx.x * 4; l < l_end; l += 1024) {
         const int h = l / W, w0 = l - h * W;
         float r0[6], r1[6], r2[6];  // gp rows h+1, h, h-1 pair with kernel rows 0, 1, 2
         load_row6(gpp + (size_t)(h + 1) * W, h + 1 < H, w0, W, r0);
@@ -258,7 +265,8 @@ VMASR_EXPORT int vmasr_dwconv_silu_fwd(const void *x, const float *w, const floa
                                        int32_t C, int32_t H, int32_t W, int32_t dtype, vmasr_stream_t stream) {
     if (int e = check_shape(B, C, H, W, dtype, "dwconv_silu_fwd")) return e;
     VMASR_REQUIRE(x && w && y, VMASR_EINVAL, "dwconv_silu_fwd: null tensor");
-    const dim3 grid((H * W + kChunk - 1) / kChunk, C, B);
+    const int chunk = kChunk;
+    const dim3 grid((H * W + chunk - 1) / chunk, C, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double bytes = 2.0 * B * C * H * W * (dtype == VMASR_F32 ? 4 : 2);  // read x, write y
     const size_t al = dtype == VMASR_F32 ? 16 : 8;
@@ -267,9 +275,9 @@ VMASR_EXPORT int vmasr_dwconv_silu_fwd(const void *x, const float *w, const floa
     do {                                                                                                             \
         if (vec) VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, (dwconv_silu_vec_kernel<TT, 0>), grid, dim3(256), 0, st,     \
                               (const TT *)x, w, bias, (const TT *)nullptr, (TT *)y, (float *)nullptr, (float *)nullptr, \
-                              (float *)nullptr, C, H, W);                                                            \
+                              (float *)nullptr, C, H, W, chunk);                                                     \
         else VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<TT>, grid, dim3(256), 0, st, (const TT *)x, w, \
-                          bias, (TT *)y, C, H, W);                                                                   \
+                          bias, (TT *)y, C, H, W, chunk);                                                            \
     } while (0)
     switch (dtype) {
         case VMASR_F32: VMASR_DW_FWD(float); break;
@@ -285,7 +293,10 @@ VMASR_EXPORT int vmasr_dwconv_silu_bwd(const void *x, const float *w, const floa
                                        int32_t dtype, vmasr_stream_t stream) {
     if (int e = check_shape(B, C, H, W, dtype, "dwconv_silu_bwd")) return e;
     VMASR_REQUIRE(x && w && gy && dx && dw && ws, VMASR_EINVAL, "dwconv_silu_bwd: null tensor");
-    const dim3 grid((H * W + kChunk - 1) / kChunk, C, B);
+    // pass A ends in 10 atomics per workgroup on the channel's dw / db: at most 64 workgroups per plane (same-address atomics
+    // serialise at ~13 ns each); pass B has no reduction and keeps the small chunk
+    const int chunk = kChunk, chunk_a = std::max(kChunk, ((H * W / 64 + 1023) / 1024) * 1024);
+    const dim3 grid((H * W + chunk - 1) / chunk, C, B), grid_a((H * W + chunk_a - 1) / chunk_a, C, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double n = (double)B * C * H * W, es = dtype == VMASR_F32 ? 4 : 2;
     const double bytes_a = n * (2 * es + 4), bytes_b = n * (4 + es);  // a: read x, gy, write gp;  b: read gp, write dx
@@ -294,15 +305,15 @@ VMASR_EXPORT int vmasr_dwconv_silu_bwd(const void *x, const float *w, const floa
 #define VMASR_DW_BWD(TT)                                                                                              \
     do {                                                                                                              \
         if (vec) {                                                                                                    \
-            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, (dwconv_silu_vec_kernel<TT, 1>), grid, dim3(256), 0, st,        \
-                         (const TT *)x, w, bias, (const TT *)gy, (TT *)nullptr, ws, dw, db, C, H, W);                   \
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, (dwconv_silu_vec_kernel<TT, 1>), grid_a, dim3(256), 0, st,      \
+                         (const TT *)x, w, bias, (const TT *)gy, (TT *)nullptr, ws, dw, db, C, H, W, chunk_a);          \
             VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_vec_kernel<TT>, grid, dim3(256), 0, st, ws, w, \
-                         (TT *)dx, C, H, W);                                                                          \
+                         (TT *)dx, C, H, W, chunk);                                                                   \
         } else {                                                                                                      \
-            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<TT>, grid, dim3(256), 0, st, (const TT *)x, \
-                         w, bias, (const TT *)gy, ws, dw, db, C, H, W);                                               \
+            VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<TT>, grid_a, dim3(256), 0, st, (const TT *)x, \
+                         w, bias, (const TT *)gy, ws, dw, db, C, H, W, chunk_a);                                      \
             VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<TT>, grid, dim3(256), 0, st, ws, w,    \
-                         (TT *)dx, C, H, W);                                                                          \
+                         (TT *)dx, C, H, W, chunk);                                                                   \
         }                                                                                                             \
     } while (0)
     switch (dtype) {
