@@ -392,7 +392,8 @@ int vmasr_ss2d_bwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
  *   Alog (4D);  Ds (4D)                                                                                  weights fp32
  *   xdbl (B,4,R+2,H*W) fp32: written by the forward, read by the backward (directions 1/3 in (w,h) order);
  *   y (B,D,H*W) fp32 = the merged output.
- * backward: dy (B,D,H*W) fp32 in;  du (B,D,H*W) fp32, tp / tb / tc (B,4,D,H*W) scratch;
+ * backward: dy (B,D,H*W) fp32 in;  du (B,D,H*W) fp32, tp / tb / tc (B,4,D,H*W) scratch (per-row terms of d(x_dbl), each direction
+ *   in its own scan order);
  *   pg (B,4,D,WR,20) fp32 out with WR = vmasr_ss2d_deep_waves_per_row: per-wave sums [dWdt[0..R-1], ddtb, dAlog, dDs] — the
  *   caller sums over (B, WR);  dx (B,D,H,W);  g32 (fp32 scratch) / gpos (`dtype`) (B,4(R+2),H*W): gradient of x_dbl per
  *   row-major position — dWx[k][c][d] = sum_{b,p} gpos[b][k(R+2)+c][p] x[b][d][p] (one GEMM on the caller's side). */

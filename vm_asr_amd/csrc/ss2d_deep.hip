@@ -248,8 +248,9 @@ __global__ __launch_bounds__(64 * WR * RG) void deep_fwd_kernel(const DeepFwdArg
 // ---- backward ---------------------------------------------------------------------------------------------------------------
 // Per (direction, row, position) the scan's backward yields du and three TERMS whose sums over the rows are the gradient of
 // x_dbl:  tp = d(loss)/d(pre-softplus delta)  (d dt_r = sum_d W_dt[d][r] tp),  tb = g delta u (dB = sum_d tb),
-// tc = dy h (dC = sum_d tc).  All four directions' terms are written in ROW-MAJOR position order (the column-wise
-// directions go back through the LDS image), so the adjoint of x_proj (deep_xg_kernel) is position-parallel and coalesced.
+// tc = dy h (dC = sum_d tc).  The terms are written in the direction's own scan order (row-major for 0 / 2, column-major for
+// 1 / 3: contiguous stores either way); the adjoint of x_proj (deep_xg_kernel) reads them in that order, coalesced, and puts its
+// small result g at the row-major position.
 constexpr int kPG = 20;   // per-(b, direction, row, wave) parameter sums: dWdt[0..R-1], dbias, dAlog, dD (R + 3 <= 19)
 struct DeepBwdArgs {
     const void *x;
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(64 * WR * RG) void deep_bwd_kernel(const DeepBwdArg
     const int lane = threadIdx.x & 63, wave = rfl(threadIdx.x >> 6);
     const int rg = wave / WR, q = wave % WR;
     const int IMG = img_floats(g.H, g.W);
-    float *uimg = s_lds + (size_t)rg * 6 * IMG, *dyimg = uimg + IMG, *duimg = uimg + 2 * IMG, *timg = uimg + 3 * IMG;
-    float2 *tot = reinterpret_cast<float2 *>(s_lds + (size_t)RG * 6 * IMG) + (size_t)rg * 8 * WR, *adj = tot + 4 * WR;
+    float *uimg = s_lds + (size_t)rg * 3 * IMG, *dyimg = uimg + IMG, *duimg = uimg + 2 * IMG;
+    float2 *tot = reinterpret_cast<float2 *>(s_lds + (size_t)RG * 3 * IMG) + (size_t)rg * 8 * WR, *adj = tot + 4 * WR;
     const int b = blockIdx.y, d = blockIdx.x * RG + rg, D = g.D, L = g.L;
     const int l0 = q * kTile + lane * kItems;
     const Img m = img_index(g, l0);
@@ -405,27 +406,14 @@ __global__ __launch_bounds__(64 * WR * RG) void deep_bwd_kernel(const DeepBwdArg
         float tp[4], tb[4], tc[4];
         bwd_dir<R, WR>(k, q, lane, uc, dc, s, w, tot + k * WR, adj + k * WR, duc, tp, tb, tc,
                        a.pg + ((((size_t)b * 4 + k) * D + d) * WR + q) * kPG);
-        if (kk == 1) lds_barrier();            // the previous direction's term images have been read
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            timg[m.idx_c[i]] = tp[i];
-            timg[IMG + m.idx_c[i]] = tb[i];
-            timg[2 * IMG + m.idx_c[i]] = tc[i];
-        }
-        if (kk == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) duimg[m.idx_c[i]] += duc[i];
-        }
-        lds_barrier();
-        const size_t trow = (((size_t)b * 4 + k) * D + d) * L;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = timg[j * IMG + m.base_r + i];
-            store4<T, true>(static_cast<T *>(j == 0 ? a.tp : (j == 1 ? a.tb : a.tc)) + trow, l0, L, v);
-        }
+        const size_t trow = (((size_t)b * 4 + k) * D + d) * L;      // (column-major order, like the scan: deep_xg_kernel maps back)
+        store4<T, true>(static_cast<T *>(a.tp) + trow, l0, L, tp);
+        store4<T, true>(static_cast<T *>(a.tb) + trow, l0, L, tb);
+        store4<T, true>(static_cast<T *>(a.tc) + trow, l0, L, tc);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) duimg[m.idx_c[i]] += duc[i];
+    lds_barrier();
     *reinterpret_cast<float4 *>(a.du + row + l0) =
         make_float4(duimg[m.base_r], duimg[m.base_r + 1], duimg[m.base_r + 2], duimg[m.base_r + 3]);
 }
@@ -470,9 +458,11 @@ __global__ __launch_bounds__(64 * NW) void deep_xg_kernel(const DeepXgArgs a, co
     for (int c = 0; c < C; ++c) s_red[(wave * C + c) * 64 + lane] = acc[0][c] + acc[1][c];
     lds_barrier();
     T *gp = static_cast<T *>(a.gpos);
+    // directions 1 / 3: the terms (and this tile) are in column-major order q = w H + h; g goes to the row-major position h W + w
+    const int pos = (k & 1) ? (p % g.H) * g.W + p / g.H : p;
     for (int c = wave; c < C; c += NW) {
         const float s = tree_sum<NW>(s_red + c * 64 + lane, C * 64);
-        const size_t o = (((size_t)b * 4 + k) * C + c) * L + p;
+        const size_t o = (((size_t)b * 4 + k) * C + c) * L + pos;
         a.g32[o] = s;
         gp[o] = from_f32<T>(s);
     }
@@ -603,7 +593,7 @@ int deep_bwd(const vmasr_ss2d_deep_params &p, const DeepCfg &c, hipStream_t st) 
     const double el = (double)p.B * p.D * g.L, pos = (double)p.B * g.L;
     {
         const dim3 grid(p.D / c.RG, p.B), block(64 * c.WR * c.RG);
-        const size_t sm = scan_lds(c, p.H, p.W, 6, 8);
+        const size_t sm = scan_lds(c, p.H, p.W, 3, 8);
         const DeepBwdArgs a{p.x, p.xdbl, p.dy, {p.Wdt, p.dtb, p.Alog, p.Ds}, p.du, p.tp, p.tb, p.tc, p.pg};
 #define DEEP_GO(K, ...) do { allow_lds(K, sm); VMASR_LAUNCH(VMASR_K_SS2D_DEEP_BWD, (5.0 * 4 * el + 4.0 * 4 * pos) * 4, K, grid, block, sm, st, __VA_ARGS__); } while (0)
         DEEP_R(deep_bwd_kernel, T, a, g);
