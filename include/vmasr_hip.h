@@ -278,6 +278,37 @@ int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi, void *lo, v
 /* the same pass with the fp32 gradient as output (layers whose GEMMs stay fp32): gx = g * GELU'(pre), db += column sums */
 int vmasr_gelu_bwd(const float *pre, const float *g, float *gx, float *db, int32_t slots, int64_t M, int32_t N, vmasr_stream_t stream);
 
+/* The period discriminator's (k,1) convolutions as implicit GEMMs on the bf16 matrix cores, fp32 operands carried as
+ * error-compensated bf16 pairs (hi, lo) — csrc/convgemm.hip; replaces im2col + three hipBLASLt GEMMs + epilogue passes
+ * behind model/discriminator.py:21-147 (Conv2d (k,1), stride (s,1), zero padding (pad,0), GELU) for the stacked
+ * discriminators ("slots": per slot nseq channel-last sequences of H positions).  Host array of n slot descriptors.
+ *   fwd  : ah/al (>= nseq*H, Cin) bf16 pair of the input rows; bh/bl (Cout, k*Cin) pair of the weight in (tap, channel)
+ *          column order; c0 (rows_out, Cout) pre-activation = conv + bias; act != 0: c1 = GELU(c0) fp32 (may be NULL),
+ *          ch/cl its bf16 pair (may be NULL).  Rows below nseq*H1 (H1 = (H + 2 pad - k)/s + 1) up to rows_out are zeroed.
+ *   dgrad: ah/al (>= nseq*H1, Cout) pair of the output gradient; bh/bl (Cin, k*Cout) pair of the weight transposed to
+ *          (tap, output channel) column order; c0 = dx (rows_in, Cin) fp32, rows below nseq*H zeroed.  H = INPUT positions.
+ *   wgrad: ah/al = pair of the output gradient g (>= nseq*H1, Cout); bh/bl = pair of the INPUT rows x (>= nseq*H, Cin);
+ *          c0 = dW (splits, Cout, k*Cin) fp32 partial sums over `splits` row ranges ((tap, channel) column order).
+ * Cin, Cout multiples of 128; k <= 8; s <= 3 (vmasr_conv_mfma_supported). */
+typedef struct vmasr_cg_slot {
+    const void *ah, *al;
+    const void *bh, *bl;
+    float *c0;
+    float *c1;
+    void *ch, *cl;
+    const float *bias;
+    int64_t nseq;
+    int32_t H;
+    int32_t reserved;
+} vmasr_cg_slot;
+int vmasr_conv_mfma_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride);
+int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                        int64_t rows_out, int32_t act, vmasr_stream_t stream);
+int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                          int64_t rows_in, vmasr_stream_t stream);
+int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                          int32_t splits, vmasr_stream_t stream);
+
 /* AdamW step of many parameter tensors in one launch (torch.optim.AdamW semantics, utils/optimizer.py:16-50 of the
  * reference; non-amsgrad, decoupled weight decay, bias correction).  `items` is a DEVICE array, one entry per tensor;
  * `chunks` a DEVICE array of (item index, chunk index) int32 pairs, one per workgroup, chunk = vmasr_adamw_chunk() elements;
@@ -579,6 +610,9 @@ enum {
     VMASR_K_OUTPROJ_FWD,        /* out_proj + DropPath + residual of a VSS block's SS2D branch as one MFMA kernel */
     VMASR_K_OUTPROJ_BWD,
     VMASR_K_STFT_LOSS,          /* one resolution of the MR-STFT loss: three sums in one pass, finish, one backward pass */
+    VMASR_K_CONV_MFMA_FWD,      /* discriminator (k,1) convolution as an implicit bf16x3 MFMA GEMM + bias + GELU + split (csrc/convgemm.hip) */
+    VMASR_K_CONV_MFMA_DGRAD,    /* its input gradient (residue classes of the stride, no col2im)                                               */
+    VMASR_K_CONV_MFMA_WGRAD,    /* its weight gradient (transposed LDS reads)                                                                   */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

@@ -48,6 +48,12 @@ class SS2DParams(ctypes.Structure):
                                        "dy", "dyT", "adj", "part", "dx", "dWx", "dWdt", "ddtb", "dAlog", "dDs")])
 
 
+class CgSlot(ctypes.Structure):
+    """POD mirror of vmasr_cg_slot (one stacked discriminator of a convolution launch, csrc/convgemm.hip)."""
+    _fields_ = ([(n, c_vp) for n in ("ah", "al", "bh", "bl", "c0", "c1", "ch", "cl", "bias")]
+                + [("nseq", c_i64), ("H", c_i32), ("reserved", c_i32)])
+
+
 class SS2DDeepParams(ctypes.Structure):
     """POD mirror of vmasr_ss2d_deep_params."""
     _fields_ = ([(n, c_i32) for n in ("B", "D", "H", "W", "R", "dtype")]
@@ -125,6 +131,10 @@ SYMBOLS = {
     "vmasr_sum_parts": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "vmasr_weight_prep_split": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_gelu_bwd_split": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "vmasr_conv_mfma_supported": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
+    "vmasr_conv_mfma_fwd": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
+    "vmasr_conv_mfma_dgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "vmasr_conv_mfma_wgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_ss2d_glue_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "vmasr_ss2d_pre_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_ss2d_pre_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -204,7 +214,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 55
+K_COUNT = 58
 
 
 def zeros_f32(device, *shapes):

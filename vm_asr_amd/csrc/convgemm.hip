@@ -1,0 +1,538 @@
+// convgemm.hip — the period discriminator's (k,1) convolutions as implicit GEMMs on the bf16 matrix cores with the
+// fp32 operands carried as error-compensated bf16 pairs (gfx950, wave64, v_mfma_f32_32x32x16_bf16).
+//
+// Reference: model/discriminator.py:21-147 (PeriodDiscriminator: Conv2d (5,1) stride (3,1) / (1,1) on the folded signal,
+// GELU after each), trainer/trainer.py:369-399 (its four passes per step), run in fp32 there.  csrc/split.hip explains why
+// an fp32 product runs as  a b = a_hi b_hi + a_lo b_hi + a_hi b_lo  on this chip.  Round 2/3 ran each triple as THREE
+// hipBLASLt GEMMs over materialised operands (im2col -> hi/lo columns, partial products, bias + GELU epilogue pass,
+// [hi|lo|hi] gradient operand, col2im): ~7 ms of a 33 ms step were those operand / epilogue passes.  Here a layer is
+//
+//   forward : ONE launch.  A tile = rows of the previous layer's activation (hi, lo) gathered by (sequence, position, tap)
+//             — im2col never exists —, B tile = the (tap, channel)-ordered weight rows (hi, lo); each A/B fragment is read
+//             from LDS once for the three MFMAs of the triple, which accumulate into ONE fp32 accumulator; the epilogue
+//             adds the bias, applies the exact-erf GELU and writes pre-activation, activation and the activation's bf16
+//             pair (the next layer's A operand).
+//   dgrad   : ONE launch.  dx[seq, h, c] = sum over the taps t with (h + pad - t) % stride == 0 of g[seq, (h+pad-t)/stride, :] W[:, t, c]:
+//             the input rows are processed in `stride` residue classes, each of which sees a fixed tap subset, so no MFMA
+//             works on structural zeros and col2im never exists (each dx row is written exactly once, no atomics).
+//   wgrad   : dW[co, (t, c)] = sum over rows of g[row, co] x[row(t), c]: both operands have the contraction index as their
+//             slow axis, so their LDS tiles are read with ds_read_b64_tr_b16 (hardware transpose read).
+//
+// Tiling of the NT kernel (forward, dgrad): 128 x 128 output tile per 256-thread workgroup (2 x 2 waves, 64 x 64 per wave =
+// 2 x 2 accumulators of 32 x 32), K step 32; per K step a wave reads 16 fragments (ds_read_b128) for 24 MFMAs.  LDS: 4 operand
+// tiles (A_hi, A_lo, B_hi, B_lo) of 128 rows x 64 B, double-buffered = 64 KB -> 2 workgroups per CU.  Rows of 64 B would put
+// rows r and r + 4 on the same banks for a ds_read_b128 lane group; the 16-B chunk index is XOR-ed with (row >> 2) & 3 on both
+// the store and the read, which makes the fragment reads conflict-free.  Global -> register -> LDS staging with the next tile's
+// loads in flight during the current tile's MFMAs; one barrier per K step.
+#include <algorithm>
+
+#include "common.h"
+
+namespace vmasr {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: HIP's uint4 struct behind a ?: goes through scratch
+
+constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32;
+constexpr int CG_TILE = CG_BM * CG_BK * 2;            // bytes of one operand tile (8 KB)
+constexpr int CG_STAGE = 4 * CG_TILE;                 // A_hi, A_lo, B_hi, B_lo
+constexpr int CG_MAXP = 24;                           // (slot, residue class) problems per launch
+
+// One GEMM problem of a launch: C[crow(m), :] (+)= sum_j A[arow(m, j), :] . B[:, tap(j) CA + :]^T for m < M.
+struct CgProb {
+    const bf16_t *ah, *al, *bh, *bl;
+    float *c0, *c1;            // c0: pre-activation (forward) / dx (dgrad); c1: activation fp32 (forward, may be null)
+    bf16_t *ch, *cl;           // bf16 pair of the activation (forward, may be null)
+    const float *bias;         // (NB) or null
+    int M, Q;                  // rows, rows per sequence (m = seq Q + q)
+    int HA;                    // positions per sequence on the A side
+    int HC;                    // positions per sequence on the C side
+    int hq_mul, hq_add;        // A position of tap j: q hq_mul + hq_add + j dstep, valid inside [0, HA)
+    int crow_mul, crow_add;    // C row = seq HC + q crow_mul + crow_add
+    int ntaps, tap0, tap_step, dstep;
+    int tile_start, mtiles;    // first tile of the problem in the launch's tile list; its number of 128-row tiles
+    int zero_rows;             // rows m in [M, zero_rows) are written as zeros (padding rows of the stacked C)
+};
+
+struct CgParams {
+    CgProb prob[CG_MAXP];
+    int nprob, ntiles_n, total_tiles;
+    int CA;                    // channels per tap on the A side (K extent per tap)
+    int NB;                    // output columns
+    int KB;                    // row length of B
+};
+
+__device__ __forceinline__ int cg_off(const int row, const int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ float cg_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ f32x16 cg_mfma(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_nt_kernel(const CgParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *crow_tab = reinterpret_cast<int *>(smem + 2 * CG_STAGE);      // C row of each of the tile's 128 rows (-1: none)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+
+    // ---- which tile ------------------------------------------------------------------------------------------------
+    const int t = xcd_remap(blockIdx.x, P.total_tiles);
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.nprob; ++i) pi = (t >= P.prob[i].tile_start) ? i : pi;
+    const CgProb &pr = P.prob[pi];
+    const int local = t - pr.tile_start;
+    const int nt = local % P.ntiles_n, mt = local / P.ntiles_n;
+    const int m0 = mt * CG_BM, n0 = nt * CG_BN;
+    const int M = pr.M, Q = pr.Q, HA = pr.HA, CA = P.CA, NB = P.NB, KB = P.KB;
+
+    if (tid < CG_BM) {
+        const int m = m0 + tid;
+        int cr = -1;
+        if (m < M) {
+            const int seq = m / Q, q = m - seq * Q;
+            cr = seq * pr.HC + q * pr.crow_mul + pr.crow_add;
+        } else if (m < pr.zero_rows) {
+            cr = m;                                                    // padding rows: the stacked tensor's row m itself
+        }
+        crow_tab[tid] = cr;
+    }
+
+    // ---- staging assignment: two A rows and two B rows per thread, one 16-byte chunk of each ---------------------------
+    const int srow = tid >> 2, chunk = tid & 3;
+    int a_base[2], a_hq[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + srow + 64 * i;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int seq = mm / Q, q = mm - seq * Q;
+        a_base[i] = seq * HA;
+        a_hq[i] = q * pr.hq_mul + pr.hq_add;
+    }
+    const bf16_t *bsrc_h[2], *bsrc_l[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const size_t o = (size_t)(n0 + srow + 64 * i) * KB + chunk * 8;
+        bsrc_h[i] = pr.bh + o;
+        bsrc_l[i] = pr.bl + o;
+    }
+    const int cpk = CA / CG_BK;                                        // K steps per tap
+    const int nk = (m0 < M) ? pr.ntaps * cpk : 0;                      // all-padding tiles only write zeros
+
+    // staged registers of the NEXT tile (named scalars: arrays captured by a lambda end up in scratch)
+    u32x4 ra_h0, ra_h1, ra_l0, ra_l1, rb_h0, rb_h1, rb_l0, rb_l1;
+    bool ra_ok0 = false, ra_ok1 = false;      // applied at STORE time: a select right behind the loads would wait for them before the MFMAs
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+#define CG_LOAD_TILE(kt)                                                                                   \
+    do {                                                                                                   \
+        const int j_ = (kt) / cpk, c0_ = ((kt) - j_ * cpk) * CG_BK;                                        \
+        const int koff_ = (pr.tap0 + j_ * pr.tap_step) * CA + c0_;                                         \
+        const int p0_ = a_hq[0] + j_ * pr.dstep, p1_ = a_hq[1] + j_ * pr.dstep;                           \
+        const bool ok0_ = a_ok[0] && p0_ >= 0 && p0_ < HA, ok1_ = a_ok[1] && p1_ >= 0 && p1_ < HA;         \
+        const size_t o0_ = (size_t)(ok0_ ? a_base[0] + p0_ : 0) * CA + c0_ + chunk * 8;                    \
+        const size_t o1_ = (size_t)(ok1_ ? a_base[1] + p1_ : 0) * CA + c0_ + chunk * 8;                    \
+        ra_h0 = *reinterpret_cast<const u32x4 *>(pr.ah + o0_);                                             \
+        ra_l0 = *reinterpret_cast<const u32x4 *>(pr.al + o0_);                                             \
+        ra_h1 = *reinterpret_cast<const u32x4 *>(pr.ah + o1_);                                             \
+        ra_l1 = *reinterpret_cast<const u32x4 *>(pr.al + o1_);                                             \
+        rb_h0 = *reinterpret_cast<const u32x4 *>(bsrc_h[0] + koff_);                                       \
+        rb_l0 = *reinterpret_cast<const u32x4 *>(bsrc_l[0] + koff_);                                       \
+        rb_h1 = *reinterpret_cast<const u32x4 *>(bsrc_h[1] + koff_);                                       \
+        rb_l1 = *reinterpret_cast<const u32x4 *>(bsrc_l[1] + koff_);                                       \
+        ra_ok0 = ok0_; ra_ok1 = ok1_;                                                                      \
+    } while (0)
+#define CG_STORE_TILE(buf)                                                                                 \
+    do {                                                                                                   \
+        unsigned char *s_ = smem + (buf) * CG_STAGE;                                                       \
+        const int o0_ = cg_off(srow, chunk), o1_ = cg_off(srow + 64, chunk);                               \
+        *reinterpret_cast<u32x4 *>(s_ + o0_) = ra_ok0 ? ra_h0 : z4;                                        \
+        *reinterpret_cast<u32x4 *>(s_ + o1_) = ra_ok1 ? ra_h1 : z4;                                        \
+        *reinterpret_cast<u32x4 *>(s_ + CG_TILE + o0_) = ra_ok0 ? ra_l0 : z4;                              \
+        *reinterpret_cast<u32x4 *>(s_ + CG_TILE + o1_) = ra_ok1 ? ra_l1 : z4;                              \
+        *reinterpret_cast<u32x4 *>(s_ + 2 * CG_TILE + o0_) = rb_h0;                                        \
+        *reinterpret_cast<u32x4 *>(s_ + 2 * CG_TILE + o1_) = rb_h1;                                        \
+        *reinterpret_cast<u32x4 *>(s_ + 3 * CG_TILE + o0_) = rb_l0;                                        \
+        *reinterpret_cast<u32x4 *>(s_ + 3 * CG_TILE + o1_) = rb_l1;                                        \
+    } while (0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        CG_LOAD_TILE(0);
+        CG_STORE_TILE(0);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) CG_LOAD_TILE(kt + 1);                                   // in flight during this tile's MFMAs
+        const unsigned char *s = smem + buf * CG_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oa = cg_off(wm * 64 + i * 32 + lr, ks * 2 + lh);
+                const int ob = cg_off(wn * 64 + i * 32 + lr, ks * 2 + lh);
+                ah[i] = *reinterpret_cast<const bf16x8 *>(s + oa);
+                al[i] = *reinterpret_cast<const bf16x8 *>(s + CG_TILE + oa);
+                bh[i] = *reinterpret_cast<const bf16x8 *>(s + 2 * CG_TILE + ob);
+                bl[i] = *reinterpret_cast<const bf16x8 *>(s + 3 * CG_TILE + ob);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = cg_mfma(al[i], bh[j], acc[i][j]);      // the two small products first, the large one last
+                    acc[i][j] = cg_mfma(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = cg_mfma(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (more) CG_STORE_TILE(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator element r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 lh, column lr -----------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + lr;
+        const float bias = pr.bias ? pr.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int cr = crow_tab[row];
+                if (cr < 0) continue;
+                const bool live = m0 + row < M;
+                const size_t o = (size_t)cr * NB + col;
+                const float pre = live ? acc[i][j][r] + bias : 0.f;
+                pr.c0[o] = pre;
+                if constexpr (ACT) {
+                    const float y = live ? cg_gelu(pre) : 0.f;
+                    if (pr.c1) pr.c1[o] = y;
+                    if (pr.ch) {
+                        const bf16_t h = (bf16_t)y;
+                        pr.ch[o] = h;
+                        pr.cl[o] = (bf16_t)(y - (float)h);
+                    }
+                }
+            }
+        }
+    }
+}
+
+#undef CG_LOAD_TILE
+#undef CG_STORE_TILE
+
+// ---- weight gradient: dW[co, t Cin + c] = sum_m g[m, co] x[xrow(m, t), c] ---------------------------------------------------
+// 128 (co) x 128 (c of one tap) output tile, contraction over 32 rows per step.  Both operand tiles are stored as they come
+// from memory ([row][128 elements], 256-B rows) and read TRANSPOSED with ds_read_b64_tr_b16: per 16-lane group the instruction
+// takes a 4-row x 16-column block (lane 4q + p supplies the address of row q, columns 4p .. 4p+3) and hands lane i column i of
+// the 4 rows — exactly 4 consecutive contraction indices of the lane's own output index, i.e. half an MFMA fragment.  The 16-byte
+// chunk index of row r is XOR-ed with ((r & 3) << 2) | ((r >> 2) & 3): the four rows of a block then sit 64 B apart in the
+// 256-B bank row (conflict-free transposed reads), and the staging stores stay 16-byte.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int CW_BR = 32;                              // contraction rows per step
+constexpr int CW_TILE = CW_BR * 256;                   // 8 KB per operand tile
+constexpr int CW_STAGE = 4 * CW_TILE;                  // g_hi, g_lo, x_hi, x_lo
+
+struct CwProb {
+    const bf16_t *gh, *gl, *xh, *xl;
+    float *dw;                 // (splits, Cout, k Cin)
+    int M, Q, H;               // rows of g, g positions per sequence (H1), x positions per sequence
+    int mchunk;                // contraction rows per split (multiple of 32)
+};
+struct CwParams {
+    CwProb prob[8];
+    int nslots, splits, tiles_co, tiles_kc, Cin, Cout, k, stride, pad;
+};
+
+__device__ __forceinline__ int cw_off(const int row, const int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+__device__ __forceinline__ bf16x8 cw_frag(const unsigned char *tile, const int ks, const int colbase, const int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int ch = ((colbase + 16 * (g & 1)) >> 3) + (p >> 1);
+    const int r0 = ks * 16 + 8 * (g >> 1) + q;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + cw_off(r0, ch) + 8 * (p & 1)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + cw_off(r0 + 4, ch) + 8 * (p & 1)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_mfma_wgrad_kernel(const CwParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+
+    const int per_slot = P.splits * P.tiles_co * P.tiles_kc;
+    const int t = xcd_remap(blockIdx.x, P.nslots * per_slot);
+    const int slot = t / per_slot;
+    int rem = t - slot * per_slot;
+    const int split = rem / (P.tiles_co * P.tiles_kc);
+    rem -= split * (P.tiles_co * P.tiles_kc);
+    const int tco = rem / P.tiles_kc, tkc = rem - tco * P.tiles_kc;
+    const CwProb &pr = P.prob[slot];
+    const int Cin = P.Cin, Cout = P.Cout;
+    const int co0 = tco * 128, kc0 = tkc * 128;
+    const int tap = kc0 / Cin, c0 = kc0 - tap * Cin;
+    const int mbeg = split * pr.mchunk, mend = min(pr.M, mbeg + pr.mchunk);
+    const int nk = mend > mbeg ? (mend - mbeg + CW_BR - 1) / CW_BR : 0;
+
+    // staging: rows srow, srow + 16 of the step, 16-byte chunk `ch` of each
+    const int srow = tid >> 4, ch = tid & 15;
+    int m_cur[2], seq[2], q[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        m_cur[i] = mbeg + srow + 16 * i;
+        seq[i] = m_cur[i] / pr.Q;
+        q[i] = m_cur[i] - seq[i] * pr.Q;
+    }
+    u32x4 rg_h0, rg_h1, rg_l0, rg_l1, rx_h0, rx_h1, rx_l0, rx_l1;
+    bool g_ok0 = false, g_ok1 = false, x_ok0 = false, x_ok1 = false;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+#define CW_ADV(i)                                                     \
+    do {                                                              \
+        m_cur[i] += CW_BR; q[i] += CW_BR;                             \
+        while (q[i] >= pr.Q) { q[i] -= pr.Q; ++seq[i]; }              \
+    } while (0)
+#define CW_LOAD()                                                                                              \
+    do {                                                                                                       \
+        const bool gk0_ = m_cur[0] < mend, gk1_ = m_cur[1] < mend;                                             \
+        const int p0_ = q[0] * P.stride + tap - P.pad, p1_ = q[1] * P.stride + tap - P.pad;                    \
+        const bool xk0_ = gk0_ && p0_ >= 0 && p0_ < pr.H, xk1_ = gk1_ && p1_ >= 0 && p1_ < pr.H;               \
+        const size_t go0_ = (size_t)(gk0_ ? m_cur[0] : 0) * Cout + co0 + ch * 8;                               \
+        const size_t go1_ = (size_t)(gk1_ ? m_cur[1] : 0) * Cout + co0 + ch * 8;                               \
+        const size_t xo0_ = (size_t)(xk0_ ? seq[0] * pr.H + p0_ : 0) * Cin + c0 + ch * 8;                      \
+        const size_t xo1_ = (size_t)(xk1_ ? seq[1] * pr.H + p1_ : 0) * Cin + c0 + ch * 8;                      \
+        rg_h0 = *reinterpret_cast<const u32x4 *>(pr.gh + go0_); rg_l0 = *reinterpret_cast<const u32x4 *>(pr.gl + go0_); \
+        rg_h1 = *reinterpret_cast<const u32x4 *>(pr.gh + go1_); rg_l1 = *reinterpret_cast<const u32x4 *>(pr.gl + go1_); \
+        rx_h0 = *reinterpret_cast<const u32x4 *>(pr.xh + xo0_); rx_l0 = *reinterpret_cast<const u32x4 *>(pr.xl + xo0_); \
+        rx_h1 = *reinterpret_cast<const u32x4 *>(pr.xh + xo1_); rx_l1 = *reinterpret_cast<const u32x4 *>(pr.xl + xo1_); \
+        g_ok0 = gk0_; g_ok1 = gk1_; x_ok0 = xk0_; x_ok1 = xk1_;                                                \
+        CW_ADV(0); CW_ADV(1);                                                                                  \
+    } while (0)
+#define CW_STORE(buf)                                                                                          \
+    do {                                                                                                       \
+        unsigned char *s_ = smem + (buf) * CW_STAGE;                                                           \
+        const int o0_ = cw_off(srow, ch), o1_ = cw_off(srow + 16, ch);                                         \
+        *reinterpret_cast<u32x4 *>(s_ + o0_) = g_ok0 ? rg_h0 : z4;                                             \
+        *reinterpret_cast<u32x4 *>(s_ + o1_) = g_ok1 ? rg_h1 : z4;                                             \
+        *reinterpret_cast<u32x4 *>(s_ + CW_TILE + o0_) = g_ok0 ? rg_l0 : z4;                                   \
+        *reinterpret_cast<u32x4 *>(s_ + CW_TILE + o1_) = g_ok1 ? rg_l1 : z4;                                   \
+        *reinterpret_cast<u32x4 *>(s_ + 2 * CW_TILE + o0_) = x_ok0 ? rx_h0 : z4;                               \
+        *reinterpret_cast<u32x4 *>(s_ + 2 * CW_TILE + o1_) = x_ok1 ? rx_h1 : z4;                               \
+        *reinterpret_cast<u32x4 *>(s_ + 3 * CW_TILE + o0_) = x_ok0 ? rx_l0 : z4;                               \
+        *reinterpret_cast<u32x4 *>(s_ + 3 * CW_TILE + o1_) = x_ok1 ? rx_l1 : z4;                               \
+    } while (0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        CW_LOAD();
+        CW_STORE(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) CW_LOAD();
+        const unsigned char *s = smem + buf * CW_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = cw_frag(s, ks, wm * 64 + i * 32, lane);
+                al[i] = cw_frag(s + CW_TILE, ks, wm * 64 + i * 32, lane);
+                bh[i] = cw_frag(s + 2 * CW_TILE, ks, wn * 64 + i * 32, lane);
+                bl[i] = cw_frag(s + 3 * CW_TILE, ks, wn * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = cg_mfma(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = cg_mfma(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = cg_mfma(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (more) CW_STORE(buf ^ 1);
+        __syncthreads();
+    }
+#undef CW_ADV
+#undef CW_LOAD
+#undef CW_STORE
+
+    const int KC = P.k * Cin;
+    float *dw = pr.dw + (size_t)split * Cout * KC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = kc0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                dw[(size_t)row * KC + col] = acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+}  // namespace vmasr
+
+using namespace vmasr;
+
+namespace {
+
+int cg_launch(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
+    int tiles = 0;
+    for (int i = 0; i < P.nprob; ++i) {
+        P.prob[i].tile_start = tiles;
+        tiles += P.prob[i].mtiles * P.ntiles_n;
+    }
+    P.total_tiles = tiles;
+    if (tiles == 0) return 0;
+    const size_t smem = 2 * CG_STAGE + CG_BM * sizeof(int);
+    if (act) {
+        VMASR_LAUNCH(kid, bytes, conv_mfma_nt_kernel<true>, dim3(tiles), dim3(256), smem, st, P);
+    } else {
+        VMASR_LAUNCH(kid, bytes, conv_mfma_nt_kernel<false>, dim3(tiles), dim3(256), smem, st, P);
+    }
+    return check_launch("conv_mfma");
+}
+
+}  // namespace
+
+VMASR_EXPORT int vmasr_conv_mfma_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride) {
+    return Cin % CG_BK == 0 && Cout % CG_BK == 0 && Cin % CG_BN == 0 && Cout % CG_BN == 0 && k >= 1 && k <= 8 && stride >= 1 &&
+           stride <= 3;
+}
+
+VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
+                                     int32_t pad, int64_t rows_out, int32_t act, vmasr_stream_t stream) {
+    VMASR_REQUIRE(slots && n >= 1 && n <= CG_MAXP, VMASR_EINVAL, "conv_mfma_fwd: 1..%d slots", CG_MAXP);
+    VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride), VMASR_EINVAL, "conv_mfma_fwd: unsupported shape (Cin %d, Cout %d, k %d, stride %d)",
+                  Cin, Cout, k, stride);
+    VMASR_REQUIRE(rows_out % CG_BM == 0, VMASR_EINVAL, "conv_mfma_fwd: rows_out must be a multiple of %d", CG_BM);
+    CgParams P = {};
+    P.nprob = n;
+    P.ntiles_n = Cout / CG_BN;
+    P.CA = Cin; P.NB = Cout; P.KB = k * Cin;
+    double bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const vmasr_cg_slot &s = slots[i];
+        VMASR_REQUIRE(s.ah && s.al && s.bh && s.bl && s.c0, VMASR_EINVAL, "conv_mfma_fwd: null tensor in slot %d", i);
+        const int64_t H1 = ((int64_t)s.H + 2 * pad - k) / stride + 1;
+        const int64_t M = s.nseq * H1;
+        VMASR_REQUIRE(H1 >= 1 && M <= rows_out && rows_out < (1LL << 31) / std::max(Cout, k * Cin), VMASR_EINVAL,
+                      "conv_mfma_fwd: slot %d: %lld rows do not fit rows_out %lld (or 32-bit offsets)", i, (long long)M, (long long)rows_out);
+        CgProb &p = P.prob[i];
+        p.ah = (const bf16_t *)s.ah; p.al = (const bf16_t *)s.al; p.bh = (const bf16_t *)s.bh; p.bl = (const bf16_t *)s.bl;
+        p.c0 = s.c0; p.c1 = s.c1; p.ch = (bf16_t *)s.ch; p.cl = (bf16_t *)s.cl; p.bias = s.bias;
+        p.M = (int)M; p.Q = (int)H1; p.HA = s.H; p.HC = (int)H1;
+        p.hq_mul = stride; p.hq_add = -pad; p.crow_mul = 1; p.crow_add = 0;
+        p.ntaps = k; p.tap0 = 0; p.tap_step = 1; p.dstep = 1;
+        p.mtiles = (int)(rows_out / CG_BM);
+        p.zero_rows = (int)rows_out;
+        bytes += (double)s.nseq * s.H * Cin * 4 + (double)Cout * k * Cin * 4 + (double)M * Cout * (act ? 12 : 4);
+    }
+    return cg_launch(P, act != 0, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_FWD, bytes);
+}
+
+VMASR_EXPORT int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
+                                       int32_t pad, int64_t rows_in, vmasr_stream_t stream) {
+    VMASR_REQUIRE(slots && n >= 1 && n * (stride + 1) <= CG_MAXP, VMASR_EINVAL, "conv_mfma_dgrad: too many slots");
+    VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride), VMASR_EINVAL, "conv_mfma_dgrad: unsupported shape (Cin %d, Cout %d, k %d, stride %d)",
+                  Cin, Cout, k, stride);
+    CgParams P = {};
+    P.ntiles_n = Cin / CG_BN;
+    P.CA = Cout; P.NB = Cin; P.KB = k * Cout;
+    double bytes = 0;
+    int np = 0;
+    for (int i = 0; i < n; ++i) {
+        const vmasr_cg_slot &s = slots[i];            // here: A = g (nseq * H1, Cout), B = W^T (Cin, k * Cout), c0 = dx (rows_in, Cin), H = H_in
+        VMASR_REQUIRE(s.ah && s.al && s.bh && s.bl && s.c0, VMASR_EINVAL, "conv_mfma_dgrad: null tensor in slot %d", i);
+        const int64_t H = s.H, H1 = (H + 2 * pad - k) / stride + 1;
+        VMASR_REQUIRE(H1 >= 1 && s.nseq * H <= rows_in && rows_in < (1LL << 31) / std::max(Cin, k * Cout), VMASR_EINVAL,
+                      "conv_mfma_dgrad: slot %d: %lld rows do not fit rows_in %lld (or 32-bit offsets)", i, (long long)(s.nseq * H), (long long)rows_in);
+        for (int r = 0; r < stride; ++r) {
+            const int r0 = ((r - pad) % stride + stride) % stride;          // input positions h = stride q + r0 have (h + pad) % stride == r
+            const int64_t Q = H > r0 ? (H - r0 + stride - 1) / stride : 0;
+            if (Q == 0) continue;
+            CgProb &p = P.prob[np++];
+            p.ah = (const bf16_t *)s.ah; p.al = (const bf16_t *)s.al; p.bh = (const bf16_t *)s.bh; p.bl = (const bf16_t *)s.bl;
+            p.c0 = s.c0; p.c1 = nullptr; p.ch = nullptr; p.cl = nullptr; p.bias = nullptr;
+            p.M = (int)(s.nseq * Q); p.Q = (int)Q; p.HA = (int)H1; p.HC = (int)H;
+            p.hq_mul = 1; p.hq_add = (r0 + pad - r) / stride;               // g position of tap t = r + stride j: q + hq_add - j
+            p.crow_mul = stride; p.crow_add = r0;
+            p.ntaps = r < k ? (k - r + stride - 1) / stride : 0;
+            p.tap0 = r; p.tap_step = stride; p.dstep = -1;
+            p.mtiles = (p.M + CG_BM - 1) / CG_BM;
+            p.zero_rows = 0;
+        }
+        if (s.nseq * H < rows_in) {                                         // zero rows below the slot's data: one pseudo sequence, no taps
+            CgProb &p = P.prob[np++];
+            p.ah = (const bf16_t *)s.ah; p.al = (const bf16_t *)s.al; p.bh = (const bf16_t *)s.bh; p.bl = (const bf16_t *)s.bl;
+            p.c0 = s.c0; p.c1 = nullptr; p.ch = nullptr; p.cl = nullptr; p.bias = nullptr;
+            p.M = (int)(rows_in - s.nseq * H); p.Q = p.M; p.HA = 1; p.HC = 0;
+            p.hq_mul = 0; p.hq_add = 0; p.crow_mul = 1; p.crow_add = (int)(s.nseq * H);
+            p.ntaps = 0; p.tap0 = 0; p.tap_step = 1; p.dstep = 0;
+            p.mtiles = (p.M + CG_BM - 1) / CG_BM;
+            p.zero_rows = 0;
+        }
+        bytes += (double)s.nseq * H1 * Cout * 4 + (double)Cout * k * Cin * 4 + (double)s.nseq * H * Cin * 4;
+    }
+    P.nprob = np;
+    return cg_launch(P, false, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_DGRAD, bytes);
+}
+
+VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
+                                       int32_t pad, int32_t splits, vmasr_stream_t stream) {
+    VMASR_REQUIRE(slots && n >= 1 && n <= 8, VMASR_EINVAL, "conv_mfma_wgrad: 1..8 slots");
+    VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride) && splits >= 1 && splits <= 64, VMASR_EINVAL,
+                  "conv_mfma_wgrad: unsupported shape (Cin %d, Cout %d, k %d, stride %d, splits %d)", Cin, Cout, k, stride, splits);
+    CwParams P = {};
+    P.nslots = n; P.splits = splits; P.tiles_co = Cout / 128; P.tiles_kc = k * Cin / 128;
+    P.Cin = Cin; P.Cout = Cout; P.k = k; P.stride = stride; P.pad = pad;
+    double bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const vmasr_cg_slot &s = slots[i];            // ah/al = g pair, bh/bl = x pair, c0 = dW partials, H = input positions
+        VMASR_REQUIRE(s.ah && s.al && s.bh && s.bl && s.c0, VMASR_EINVAL, "conv_mfma_wgrad: null tensor in slot %d", i);
+        const int64_t H1 = ((int64_t)s.H + 2 * pad - k) / stride + 1, M = s.nseq * H1;
+        VMASR_REQUIRE(H1 >= 1 && M < (1LL << 31) / std::max(Cout, Cin) && s.nseq * (int64_t)s.H < (1LL << 31) / Cin, VMASR_EINVAL,
+                      "conv_mfma_wgrad: slot %d too large for 32-bit row offsets", i);
+        CwProb &p = P.prob[i];
+        p.gh = (const bf16_t *)s.ah; p.gl = (const bf16_t *)s.al; p.xh = (const bf16_t *)s.bh; p.xl = (const bf16_t *)s.bl;
+        p.dw = s.c0; p.M = (int)M; p.Q = (int)H1; p.H = s.H;
+        const int64_t per = (M + splits - 1) / splits;
+        p.mchunk = (int)((per + CW_BR - 1) / CW_BR * CW_BR);
+        bytes += (double)M * Cout * 4 + (double)s.nseq * s.H * Cin * 4 + (double)splits * Cout * k * Cin * 4;
+    }
+    const int tiles = n * splits * P.tiles_co * P.tiles_kc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, conv_mfma_wgrad_kernel, dim3(tiles), dim3(256), 2 * CW_STAGE, st, P);
+    return check_launch("conv_mfma_wgrad");
+}
