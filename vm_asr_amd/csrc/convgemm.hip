@@ -25,6 +25,7 @@
 // the store and the read, which makes the fragment reads conflict-free.  Global -> register -> LDS staging with the next tile's
 // loads in flight during the current tile's MFMAs; one barrier per K step.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -33,7 +34,10 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: HIP's uint4 struct behind a ?: goes through scratch
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void *cg_gptr;
+typedef __attribute__((address_space(3))) void *cg_lptr;
+__device__ uint4 cg_zero_page[4];   // 64 zero bytes: the DMA source of operand rows that do not exist   // a native vector: HIP's uint4 struct behind a ?: goes through scratch
 
 constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32;
 constexpr int CG_TILE = CG_BM * CG_BK * 2;            // bytes of one operand tile (8 KB)
@@ -72,13 +76,25 @@ __device__ __forceinline__ f32x16 cg_mfma(const bf16x8 a, const bf16x8 b, const 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <bool ACT>
-__global__ __launch_bounds__(256, 2) void conv_mfma_nt_kernel(const CgParams P) {
+// Tile configurations of the NT kernel: BM x BN output tile, WM x WN waves, each wave (BM / WM) x (BN / WN) = TI x TJ accumulators
+// of 32 x 32.  128 x 128 / 4 waves: 64 KB of LDS, two workgroups per CU.  256 x 256 / 8 waves (128 x 64 per wave): 128 KB, one
+// workgroup per CU — half the global -> LDS bytes and 3/4 of the LDS fragment reads per MFMA, and a K step lasts twice as long
+// (48 MFMAs per wave), which is what covers the latency of the next tile's DMA; used whenever the output width allows.
+template <int BM, int BN, int WM, int WN, bool ACT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgParams P) {
+    constexpr int NT = 64 * WM * WN;                   // threads
+    constexpr int WTM = BM / WM, WTN = BN / WN;        // per-wave tile
+    constexpr int TI = WTM / 32, TJ = WTN / 32;
+    constexpr int TILE_A = BM * 64, TILE_B = BN * 64;  // bytes of one operand tile (rows of 32 bf16)
+    constexpr int STAGE = 2 * TILE_A + 2 * TILE_B;     // A_hi, A_lo, B_hi, B_lo
+    constexpr int RPP = NT / 4;                        // rows staged per pass (4 threads per 64-byte row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && BM % 128 == 0, "tile / thread geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *crow_tab = reinterpret_cast<int *>(smem + 2 * CG_STAGE);      // C row of each of the tile's 128 rows (-1: none)
+    int *crow_tab = reinterpret_cast<int *>(smem + 2 * STAGE);         // C row of each of the tile's BM rows (-1: none)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
 
     // ---- which tile ------------------------------------------------------------------------------------------------
     const int t = xcd_remap(blockIdx.x, P.total_tiles);
@@ -88,10 +104,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_nt_kernel(const CgParams P) 
     const CgProb &pr = P.prob[pi];
     const int local = t - pr.tile_start;
     const int nt = local % P.ntiles_n, mt = local / P.ntiles_n;
-    const int m0 = mt * CG_BM, n0 = nt * CG_BN;
+    const int m0 = mt * BM, n0 = nt * BN;
     const int M = pr.M, Q = pr.Q, HA = pr.HA, CA = P.CA, NB = P.NB, KB = P.KB;
 
-    if (tid < CG_BM) {
+    if (tid < BM) {
         const int m = m0 + tid;
         int cr = -1;
         if (m < M) {
@@ -103,141 +119,152 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_nt_kernel(const CgParams P) 
         crow_tab[tid] = cr;
     }
 
-    // ---- staging assignment: two A rows and two B rows per thread, one 16-byte chunk of each ---------------------------
-    const int srow = tid >> 2, chunk = tid & 3;
-    int a_base[2], a_hq[2];
-    bool a_ok[2];
+    // ---- staging: LDS-DMA (global_load_lds_dwordx4).  One wave instruction fills 1 KB = 16 rows x 64 B in lane order, so the lane
+    // that owns LDS unit (row, physical chunk c') fetches the row's LOGICAL chunk c' ^ ((row >> 2) & 3) — the swizzle lives on
+    // the source address, the fragment reads apply the same XOR.  Per pass the workgroup fills RPP rows (wave w: rows 16w ..);
+    // rows outside the data (padding taps, rows >= M) read a zero page instead (a DMA cannot be masked).
+    const int srow = tid >> 2, chunk = (tid & 3) ^ ((srow >> 2) & 3);
+    int a_base[PA], a_hq[PA];
+    bool a_ok[PA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + srow + 64 * i;
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + srow + RPP * i;
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         const int seq = mm / Q, q = mm - seq * Q;
         a_base[i] = seq * HA;
         a_hq[i] = q * pr.hq_mul + pr.hq_add;
     }
-    const bf16_t *bsrc_h[2], *bsrc_l[2];
+    const bf16_t *bsrc_h[PB], *bsrc_l[PB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const size_t o = (size_t)(n0 + srow + 64 * i) * KB + chunk * 8;
+    for (int i = 0; i < PB; ++i) {
+        const size_t o = (size_t)(n0 + srow + RPP * i) * KB + chunk * 8;
         bsrc_h[i] = pr.bh + o;
         bsrc_l[i] = pr.bl + o;
     }
     const int cpk = CA / CG_BK;                                        // K steps per tap
     const int nk = (m0 < M) ? pr.ntaps * cpk : 0;                      // all-padding tiles only write zeros
+    const int wbase = wave * 16 * 64;                                  // this wave's 1 KB of each pass
+    const bf16_t *zp = reinterpret_cast<const bf16_t *>(cg_zero_page);
 
-    // staged registers of the NEXT tile (named scalars: arrays captured by a lambda end up in scratch)
-    u32x4 ra_h0, ra_h1, ra_l0, ra_l1, rb_h0, rb_h1, rb_l0, rb_l1;
-    bool ra_ok0 = false, ra_ok1 = false;      // applied at STORE time: a select right behind the loads would wait for them before the MFMAs
-    const u32x4 z4 = {0u, 0u, 0u, 0u};
-#define CG_LOAD_TILE(kt)                                                                                   \
-    do {                                                                                                   \
-        const int j_ = (kt) / cpk, c0_ = ((kt) - j_ * cpk) * CG_BK;                                        \
-        const int koff_ = (pr.tap0 + j_ * pr.tap_step) * CA + c0_;                                         \
-        const int p0_ = a_hq[0] + j_ * pr.dstep, p1_ = a_hq[1] + j_ * pr.dstep;                           \
-        const bool ok0_ = a_ok[0] && p0_ >= 0 && p0_ < HA, ok1_ = a_ok[1] && p1_ >= 0 && p1_ < HA;         \
-        const size_t o0_ = (size_t)(ok0_ ? a_base[0] + p0_ : 0) * CA + c0_ + chunk * 8;                    \
-        const size_t o1_ = (size_t)(ok1_ ? a_base[1] + p1_ : 0) * CA + c0_ + chunk * 8;                    \
-        ra_h0 = *reinterpret_cast<const u32x4 *>(pr.ah + o0_);                                             \
-        ra_l0 = *reinterpret_cast<const u32x4 *>(pr.al + o0_);                                             \
-        ra_h1 = *reinterpret_cast<const u32x4 *>(pr.ah + o1_);                                             \
-        ra_l1 = *reinterpret_cast<const u32x4 *>(pr.al + o1_);                                             \
-        rb_h0 = *reinterpret_cast<const u32x4 *>(bsrc_h[0] + koff_);                                       \
-        rb_l0 = *reinterpret_cast<const u32x4 *>(bsrc_l[0] + koff_);                                       \
-        rb_h1 = *reinterpret_cast<const u32x4 *>(bsrc_h[1] + koff_);                                       \
-        rb_l1 = *reinterpret_cast<const u32x4 *>(bsrc_l[1] + koff_);                                       \
-        ra_ok0 = ok0_; ra_ok1 = ok1_;                                                                      \
-    } while (0)
-#define CG_STORE_TILE(buf)                                                                                 \
-    do {                                                                                                   \
-        unsigned char *s_ = smem + (buf) * CG_STAGE;                                                       \
-        const int o0_ = cg_off(srow, chunk), o1_ = cg_off(srow + 64, chunk);                               \
-        *reinterpret_cast<u32x4 *>(s_ + o0_) = ra_ok0 ? ra_h0 : z4;                                        \
-        *reinterpret_cast<u32x4 *>(s_ + o1_) = ra_ok1 ? ra_h1 : z4;                                        \
-        *reinterpret_cast<u32x4 *>(s_ + CG_TILE + o0_) = ra_ok0 ? ra_l0 : z4;                              \
-        *reinterpret_cast<u32x4 *>(s_ + CG_TILE + o1_) = ra_ok1 ? ra_l1 : z4;                              \
-        *reinterpret_cast<u32x4 *>(s_ + 2 * CG_TILE + o0_) = rb_h0;                                        \
-        *reinterpret_cast<u32x4 *>(s_ + 2 * CG_TILE + o1_) = rb_h1;                                        \
-        *reinterpret_cast<u32x4 *>(s_ + 3 * CG_TILE + o0_) = rb_l0;                                        \
-        *reinterpret_cast<u32x4 *>(s_ + 3 * CG_TILE + o1_) = rb_l1;                                        \
-    } while (0)
+#define CG_DMA(src, dst) __builtin_amdgcn_global_load_lds((cg_gptr)(src), (cg_lptr)(dst), 16, 0, 0)
+    auto stage_tile = [&](const int kt, const int buf) {
+        const int j = kt / cpk, c0 = (kt - j * cpk) * CG_BK;
+        const int koff = (pr.tap0 + j * pr.tap_step) * CA + c0;
+        unsigned char *d = smem + buf * STAGE + wbase;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int pos = a_hq[i] + j * pr.dstep;
+            const bool ok = a_ok[i] && pos >= 0 && pos < HA;
+            const size_t o = (size_t)(a_base[i] + pos) * CA + c0 + chunk * 8;
+            CG_DMA(ok ? pr.ah + o : zp, d + i * RPP * 64);
+            CG_DMA(ok ? pr.al + o : zp, d + TILE_A + i * RPP * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            CG_DMA(bsrc_h[i] + koff, d + 2 * TILE_A + i * RPP * 64);
+            CG_DMA(bsrc_l[i] + koff, d + 2 * TILE_A + TILE_B + i * RPP * 64);
+        }
+    };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 0) {
-        CG_LOAD_TILE(0);
-        CG_STORE_TILE(0);
-    }
+    if (nk > 0) stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) CG_LOAD_TILE(kt + 1);                                   // in flight during this tile's MFMAs
-        const unsigned char *s = smem + buf * CG_STAGE;
+        if (kt + 1 < nk) stage_tile(kt + 1, buf ^ 1);                  // lands during this tile's MFMAs (every wave left buf ^ 1 at the last barrier)
+        const unsigned char *s = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            bf16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int oa = cg_off(wm * 64 + i * 32 + lr, ks * 2 + lh);
-                const int ob = cg_off(wn * 64 + i * 32 + lr, ks * 2 + lh);
+            for (int i = 0; i < TI; ++i) {
+                const int oa = cg_off(wm * WTM + i * 32 + lr, ks * 2 + lh);
                 ah[i] = *reinterpret_cast<const bf16x8 *>(s + oa);
-                al[i] = *reinterpret_cast<const bf16x8 *>(s + CG_TILE + oa);
-                bh[i] = *reinterpret_cast<const bf16x8 *>(s + 2 * CG_TILE + ob);
-                bl[i] = *reinterpret_cast<const bf16x8 *>(s + 3 * CG_TILE + ob);
+                al[i] = *reinterpret_cast<const bf16x8 *>(s + TILE_A + oa);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TJ; ++j) {
+                const int ob = cg_off(wn * WTN + j * 32 + lr, ks * 2 + lh);
+                bh[j] = *reinterpret_cast<const bf16x8 *>(s + 2 * TILE_A + ob);
+                bl[j] = *reinterpret_cast<const bf16x8 *>(s + 2 * TILE_A + TILE_B + ob);
+            }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
                     acc[i][j] = cg_mfma(al[i], bh[j], acc[i][j]);      // the two small products first, the large one last
                     acc[i][j] = cg_mfma(ah[i], bl[j], acc[i][j]);
                     acc[i][j] = cg_mfma(ah[i], bh[j], acc[i][j]);
                 }
         }
-        if (more) CG_STORE_TILE(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+#undef CG_DMA
 
-    // ---- epilogue: accumulator element r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 lh, column lr -----------------
+    // ---- epilogue: the fp32 tile goes through LDS (the staging buffers are free now), 128 rows at a time, so that every thread
+    // finishes 4 consecutive columns of a row: 16-byte stores, a wave covers whole 512-byte row segments.
+    // Accumulator element r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 lh, column lr.
+    float *ct = reinterpret_cast<float *>(smem);
+    static_assert(128 * BN * 4 <= 2 * STAGE, "epilogue tile must fit the staging buffers");
+    constexpr int C4 = BN / 4;                         // float4 per row
+    constexpr int RPI = NT / C4;                       // rows per iteration of the store loop
+    const int c4 = tid % C4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pr.bias) bias4 = *reinterpret_cast<const float4 *>(pr.bias + n0 + 4 * c4);
+#pragma unroll 1
+    for (int h = 0; h < BM / 128; ++h) {
+        if (h > 0) __syncthreads();
+        if ((wm * WTM) / 128 == h) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + lr;
-        const float bias = pr.bias ? pr.bias[col] : 0.f;
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int cr = crow_tab[row];
-                if (cr < 0) continue;
-                const bool live = m0 + row < M;
-                const size_t o = (size_t)cr * NB + col;
-                const float pre = live ? acc[i][j][r] + bias : 0.f;
-                pr.c0[o] = pre;
-                if constexpr (ACT) {
-                    const float y = live ? cg_gelu(pre) : 0.f;
-                    if (pr.c1) pr.c1[o] = y;
-                    if (pr.ch) {
-                        const bf16_t h = (bf16_t)y;
-                        pr.ch[o] = h;
-                        pr.cl[o] = (bf16_t)(y - (float)h);
+                    for (int r = 0; r < 16; ++r)
+                        ct[((wm * WTM) % 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + lr] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 128 / RPI; ++it) {
+            const int row = it * RPI + tid / C4;
+            const int cr = crow_tab[h * 128 + row];
+            if (cr < 0) continue;
+            const bool live = m0 + h * 128 + row < M;
+            const size_t o = (size_t)cr * NB + n0 + 4 * c4;
+            float4 v = *reinterpret_cast<const float4 *>(ct + row * BN + 4 * c4);
+            if (live) { v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w; }
+            else v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(pr.c0 + o) = v;
+            if constexpr (ACT) {
+                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) y = make_float4(cg_gelu(v.x), cg_gelu(v.y), cg_gelu(v.z), cg_gelu(v.w));
+                if (pr.c1) *reinterpret_cast<float4 *>(pr.c1 + o) = y;
+                if (pr.ch) {
+                    union { uint2 raw; bf16_t e[4]; } hh, ll;
+                    const float yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hh.e[e] = (bf16_t)yy[e];
+                        ll.e[e] = (bf16_t)(yy[e] - (float)hh.e[e]);
                     }
+                    *reinterpret_cast<uint2 *>(pr.ch + o) = hh.raw;
+                    *reinterpret_cast<uint2 *>(pr.cl + o) = ll.raw;
                 }
             }
         }
     }
 }
-
-#undef CG_LOAD_TILE
-#undef CG_STORE_TILE
 
 // ---- weight gradient: dW[co, t Cin + c] = sum_m g[m, co] x[xrow(m, t), c] ---------------------------------------------------
 // 128 (co) x 128 (c of one tap) output tile, contraction over 32 rows per step.  Both operand tiles are stored as they come
@@ -294,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wgrad_kernel(const CwParams 
     const int mbeg = split * pr.mchunk, mend = min(pr.M, mbeg + pr.mchunk);
     const int nk = mend > mbeg ? (mend - mbeg + CW_BR - 1) / CW_BR : 0;
 
+    // (register staging: an LDS-DMA version of this loop measured 20-25 % SLOWER, profiles/r04_convgemm_microbench_v1.log)
     // staging: rows srow, srow + 16 of the step, 16-byte chunk `ch` of each
     const int srow = tid >> 4, ch = tid & 15;
     int m_cur[2], seq[2], q[2];
@@ -407,21 +435,39 @@ using namespace vmasr;
 
 namespace {
 
-int cg_launch(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
+template <int BM, int BN, int WM, int WN>
+int cg_launch_cfg(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
     int tiles = 0;
+    P.ntiles_n = P.NB / BN;
     for (int i = 0; i < P.nprob; ++i) {
         P.prob[i].tile_start = tiles;
+        P.prob[i].mtiles = (std::max(P.prob[i].M, P.prob[i].zero_rows) + BM - 1) / BM;
         tiles += P.prob[i].mtiles * P.ntiles_n;
     }
     P.total_tiles = tiles;
     if (tiles == 0) return 0;
-    const size_t smem = 2 * CG_STAGE + CG_BM * sizeof(int);
+    constexpr size_t smem = 2 * (2 * BM * 64 + 2 * BN * 64) + BM * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done && smem > 65536) {      // > 64 KB of dynamic LDS needs the opt-in attribute
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
     if (act) {
-        VMASR_LAUNCH(kid, bytes, conv_mfma_nt_kernel<true>, dim3(tiles), dim3(256), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, true>), dim3(tiles), dim3(64 * WM * WN), smem, st, P);
     } else {
-        VMASR_LAUNCH(kid, bytes, conv_mfma_nt_kernel<false>, dim3(tiles), dim3(256), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, false>), dim3(tiles), dim3(64 * WM * WN), smem, st, P);
     }
     return check_launch("conv_mfma");
+}
+
+// 256 x 256 tiles when the output width allows and there are enough of them to fill the chip; VMASR_CONV_TILE=128 forces the small tile
+int cg_launch(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
+    static const int forced = [] { const char *e = getenv("VMASR_CONV_TILE"); return e ? atoi(e) : 0; }();
+    bool big = P.NB % 256 == 0;
+    if (forced == 128) big = false;
+    if (big) return cg_launch_cfg<256, 256, 2, 4>(P, act, st, kid, bytes);
+    return cg_launch_cfg<128, 128, 2, 2>(P, act, st, kid, bytes);
 }
 
 }  // namespace
@@ -436,10 +482,9 @@ VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int3
     VMASR_REQUIRE(slots && n >= 1 && n <= CG_MAXP, VMASR_EINVAL, "conv_mfma_fwd: 1..%d slots", CG_MAXP);
     VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride), VMASR_EINVAL, "conv_mfma_fwd: unsupported shape (Cin %d, Cout %d, k %d, stride %d)",
                   Cin, Cout, k, stride);
-    VMASR_REQUIRE(rows_out % CG_BM == 0, VMASR_EINVAL, "conv_mfma_fwd: rows_out must be a multiple of %d", CG_BM);
+    VMASR_REQUIRE(rows_out % 256 == 0, VMASR_EINVAL, "conv_mfma_fwd: rows_out must be a multiple of 256");
     CgParams P = {};
     P.nprob = n;
-    P.ntiles_n = Cout / CG_BN;
     P.CA = Cin; P.NB = Cout; P.KB = k * Cin;
     double bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -455,7 +500,6 @@ VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int3
         p.M = (int)M; p.Q = (int)H1; p.HA = s.H; p.HC = (int)H1;
         p.hq_mul = stride; p.hq_add = -pad; p.crow_mul = 1; p.crow_add = 0;
         p.ntaps = k; p.tap0 = 0; p.tap_step = 1; p.dstep = 1;
-        p.mtiles = (int)(rows_out / CG_BM);
         p.zero_rows = (int)rows_out;
         bytes += (double)s.nseq * s.H * Cin * 4 + (double)Cout * k * Cin * 4 + (double)M * Cout * (act ? 12 : 4);
     }
@@ -468,7 +512,6 @@ VMASR_EXPORT int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, in
     VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride), VMASR_EINVAL, "conv_mfma_dgrad: unsupported shape (Cin %d, Cout %d, k %d, stride %d)",
                   Cin, Cout, k, stride);
     CgParams P = {};
-    P.ntiles_n = Cin / CG_BN;
     P.CA = Cout; P.NB = Cin; P.KB = k * Cout;
     double bytes = 0;
     int np = 0;
@@ -490,7 +533,6 @@ VMASR_EXPORT int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, in
             p.crow_mul = stride; p.crow_add = r0;
             p.ntaps = r < k ? (k - r + stride - 1) / stride : 0;
             p.tap0 = r; p.tap_step = stride; p.dstep = -1;
-            p.mtiles = (p.M + CG_BM - 1) / CG_BM;
             p.zero_rows = 0;
         }
         if (s.nseq * H < rows_in) {                                         // zero rows below the slot's data: one pseudo sequence, no taps
@@ -500,7 +542,6 @@ VMASR_EXPORT int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, in
             p.M = (int)(rows_in - s.nseq * H); p.Q = p.M; p.HA = 1; p.HC = 0;
             p.hq_mul = 0; p.hq_add = 0; p.crow_mul = 1; p.crow_add = (int)(s.nseq * H);
             p.ntaps = 0; p.tap0 = 0; p.tap_step = 1; p.dstep = 0;
-            p.mtiles = (p.M + CG_BM - 1) / CG_BM;
             p.zero_rows = 0;
         }
         bytes += (double)s.nseq * H1 * Cout * 4 + (double)Cout * k * Cin * 4 + (double)s.nseq * H * Cin * 4;

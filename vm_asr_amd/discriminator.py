@@ -788,6 +788,65 @@ class _StackedConvSplitFn(torch.autograd.Function):
         return (None, None, None, None, None, None, dw, db, *dxs)
 
 
+class _StackedConvMfmaFn(torch.autograd.Function):
+    """One stacked (k,1) convolution + bias + GELU of the n period discriminators as ONE implicit bf16x3 MFMA GEMM launch
+    each way (csrc/convgemm.hip, vm_asr_amd/convgemm.py) — no im2col operand, no partial products, no col2im.
+    x (n, rows_in, C) fp32 stacked input (slot i: N_i sequences of H_i positions), pair = its bf16 (hi, lo) split if the
+    producing layer already wrote it; W (n, Cout, k*C) fp32 in (tap, channel) order; returns y = GELU(conv + bias) stacked
+    (n, rows, Cout) and leaves the pair of y in `out_pair` for the next layer.  wcache: dict shared by the passes of a step
+    while the weights are frozen (the split / transposed-split operands of W are built once per step)."""
+
+    @staticmethod
+    def forward(ctx, k, stride, pad, rows, geom, wcache, out_pair, weight, bias, x, xh, xl):
+        from . import convgemm as cg
+        x = x.float().contiguous()
+        if xh is None:
+            xh, xl = split_bf16(x)
+        w = weight.detach().float().contiguous()
+        ops = wcache.get("ops") if wcache is not None else None
+        if ops is None:
+            ops = {"w": split_bf16(w)}
+            if wcache is not None:
+                wcache["ops"] = ops
+        wh, wl = ops["w"]
+        pre, y, yh, yl = cg.conv_fwd(xh, xl, wh, wl, bias.detach().float().contiguous(), geom, k, stride, pad, rows, act=True)
+        out_pair.append((yh, yl))
+        ctx.save_for_backward(xh, xl, pre, w)
+        ctx.meta = (k, stride, pad, tuple(geom), ops, weight.dtype, bias.dtype, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import convgemm as cg
+        xh, xl, pre, w = ctx.saved_tensors
+        k, stride, pad, geom, ops, wdt, bdt, xshape = ctx.meta
+        gy = gy.float().contiguous()
+        n, M, N = gy.shape
+        C = xshape[2]
+        lib = _lib.lib()
+        skip_w = _PHASE["skip_weight_grads"]
+        want_db = ctx.needs_input_grad[8] and not skip_w
+        with torch.cuda.device(gy.device):
+            gh = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
+            gl = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
+            db32 = torch.zeros((n, N), dtype=torch.float32, device=gy.device) if want_db else None
+            _lib.check(lib.vmasr_gelu_bwd_split(pre.data_ptr(), gy.data_ptr(), gh.data_ptr(), gl.data_ptr(), None,
+                                                db32.data_ptr() if want_db else None, n, M, N, _lib.current_stream(gy.device)),
+                       "gelu_bwd_split")
+        dx = dw = db = None
+        if ctx.needs_input_grad[9]:
+            if "wt" not in ops:      # (n, Cout, k, C) -> (n, C, k*Cout): the dgrad GEMM's B operand, (tap, output channel) order
+                ops["wt"] = split_bf16(w.view(n, N, k, C).permute(0, 3, 2, 1).reshape(n, C, k * N).contiguous())
+            wth, wtl = ops["wt"]
+            dx = cg.conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, xshape[1])
+        if not skip_w:
+            if ctx.needs_input_grad[7]:
+                dw = cg.conv_wgrad(gh, gl, xh, xl, geom, k, stride, pad).to(wdt)
+            if want_db:
+                db = db32.to(bdt)
+        return (None, None, None, None, None, None, None, dw, db, dx, None, None)
+
+
 class _StackedConvFirstFn(torch.autograd.Function):
     """The first convolution (1 -> 32 channels, kernel (5,1), stride (3,1), padding 2) + GELU of all n period discriminators
     in one launch on the folded signals xs[i] (B, p, H, 1) — csrc/convfirst.hip — instead of a 5-column im2col operand, a
@@ -1128,6 +1187,7 @@ class MultiPeriodDiscriminator(nn.Module):
                 xp = F.pad(xp, (0, p - T % p), "reflect")
             cur.append(xp.view(B, 1, -1, p).permute(0, 3, 2, 1).to(cdt))          # (B, p, T/p, 1)
         fmaps, stacks, valid, taps = [[] for _ in discs], [], [], []
+        next_pair = None
         for li in range(len(discs[0].layers) + 1):
             layers = [d.layers[li] if li < len(d.layers) else d.conv_post for d in discs]
             k, stride, pad = layers[0].kernel_size[0], layers[0].stride[0], layers[0].padding[0]
@@ -1158,6 +1218,7 @@ class MultiPeriodDiscriminator(nn.Module):
             # from the second layer on the inputs are the slots of the previous layer's stacked output: hand that tensor over
             # (slot i = B*p_i sequences of H_i positions) so that its gradient comes back stacked, in one launch
             sgeom, src = None, cur
+            pair, next_pair = next_pair, None     # the bf16 (hi, lo) pair of stacks[-1], if the previous layer's epilogue wrote it
             if stacks and stacks[-1].dtype == cdt and os.environ.get("VMASR_STACK_INPUT", "1") == "1":
                 sgeom, src = tuple((B * p, c.shape[2]) for c, p in zip(cur, P)), (stacks[-1],)
             if (not act and stacks and cdt == torch.float32 and k == 3 and stride == 1 and pad == 1 and W.shape[1] == 1
@@ -1169,6 +1230,17 @@ class MultiPeriodDiscriminator(nn.Module):
                   and all(c.shape[3] == 1 for c in cur) and os.environ.get("VMASR_CONV_FIRST", "1") == "1"):
                 # the 1 -> 32 channel input convolution + GELU straight from the folded signals (no 5-column operand / K = 5 GEMM)
                 y = _StackedConvFirstFn.apply(_round_up(max(Ms), 256), W, bstack, *cur)
+            elif (_split_mode(W.shape[2], W.shape[1], cdt) and act and sgeom is not None and os.environ.get("VMASR_MPD_CONV", "mfma") == "mfma"
+                  and _lib.lib().vmasr_conv_mfma_supported(cur[0].shape[3], W.shape[1], k, stride)):
+                # the three compute-bound layers: one implicit-GEMM launch each way (csrc/convgemm.hip); the layer's epilogue
+                # leaves the bf16 pair of its activation for the next layer
+                wcache = None
+                if self._frozen is not None:
+                    wcache = self._frozen.setdefault(("mfma_ops", li), {})
+                out_pair = []
+                xh, xl = pair if pair is not None else (None, None)
+                y = _StackedConvMfmaFn.apply(k, stride, pad, _round_up(max(Ms), 256), sgeom, wcache, out_pair, W, bstack, src[0], xh, xl)
+                next_pair = out_pair[0]
             elif _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
                 y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, sgeom, W, bstack, *src)
             else:
