@@ -59,9 +59,6 @@ def main(args, config):
     from vm_asr_amd.trainer import (CosineWarmupScheduler, SyntheticVCTK, Trainer, _Logger, build_optimizer, default_metric_ftns,
                                     init_distributed)
     log = _Logger()
-    if config.MODEL.RESUME_PATH and not config.EVAL_MODE:
-        from vm_asr_amd.trainer import resume_config
-        config = resume_config(config, log)      # the reference restores the stored config before building anything
     if config.INFERENCE_MODE:
         raise SystemExit("--inference is not built (wav file I/O is out of scope, DESIGN.md §7); use --eval")
     if config.THROUGHPUT_MODE:

@@ -845,24 +845,29 @@ def test_checkpoint_optimizer_state_loads_into_a_plain_adamw(tmp_path):
     assert all(g["foreach"] is True and g["capturable"] is False for g in a.optimizer_G.param_groups)
 
 
-def test_resume_config_comes_from_the_generator_checkpoint(tmp_path):
-    """utils/utils.py:141-145: the stored config replaces the CLI config BEFORE anything is built (resume_config, called
-    first in main.py); the trainer itself no longer swaps its config after construction."""
+def test_resume_builds_from_the_cli_config_then_adopts_the_stored_one(tmp_path):
+    """base/base_trainer.py:24-56,181-192 + utils/utils.py:141-145: everything is BUILT from the CLI config (so
+    `--resume DIR --epochs N`, `--output`, `--batch-size` ... take effect: extending a finished run trains the extra epochs);
+    only `self.config` is replaced by the generator checkpoint's afterwards, with RESUME_PATH re-pointed."""
     from oracle.torch_backend import oracle_stft_patch
-    from vm_asr_amd.trainer import resume_config
     cfg = _tiny_config()
-    cfg.defrost(); cfg.OUTPUT = str(tmp_path); cfg.TRAIN.EPOCHS = 7; cfg.freeze()
+    cfg.defrost(); cfg.OUTPUT = str(tmp_path); cfg.TRAIN.EPOCHS = 7; cfg.PRINT_FREQ = 3; cfg.freeze()
     with oracle_stft_patch():
         a = _resumable(cfg, tmp_path, "cpu")
-        a._save_checkpoint(2, save_best=True)
+        a._save_checkpoint(7, save_best=True)          # a finished 7-epoch run
+    out2 = tmp_path / "continued"
     cli = _tiny_config()
-    cli.defrost(); cli.MODEL.RESUME_PATH = str(tmp_path); cli.TRAIN.EPOCHS = 99; cli.freeze()
-    got = resume_config(cli)
-    assert got.TRAIN.EPOCHS == 7 and got.MODEL.RESUME_PATH == str(tmp_path) and got.is_frozen()
-    b = _resumable(got, tmp_path, "cpu")
-    assert b.config is got and b.epochs == 7 and b.start_epoch == 3 and b.checkpoint_config.TRAIN.EPOCHS == 7
-    nothing = _tiny_config()
-    assert resume_config(nothing) is nothing
+    cli.defrost(); cli.MODEL.RESUME_PATH = str(tmp_path); cli.TRAIN.EPOCHS = 9; cli.OUTPUT = str(out2); cli.PRINT_FREQ = 11; cli.freeze()
+    b = _resumable(cli, tmp_path, "cpu")
+    assert b.epochs == 9 and b.start_epoch == 8                      # two more epochs to train, not zero
+    assert b.log_dir == str(out2)                                    # built from the CLI config
+    assert b.config is not cli and b.config.TRAIN.EPOCHS == 7 and b.config.PRINT_FREQ == 3 and b.config.is_frozen()
+    assert b.config.MODEL.RESUME_PATH == str(tmp_path) and b.checkpoint_config.TRAIN.EPOCHS == 7
+    # evaluation keeps the CLI config (utils/utils.py:154-176 never touches it)
+    ev = _tiny_config()
+    ev.defrost(); ev.MODEL.RESUME_PATH = str(tmp_path); ev.EVAL_MODE = True; ev.TRAIN.EPOCHS = 9; ev.freeze()
+    c = _resumable(ev, tmp_path, "cpu")
+    assert c.config is ev
 
 
 @pytest.mark.gpu

@@ -30,10 +30,10 @@ def supported(x, norm, in_proj):
         return False
     if not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
         return False
-    if not isinstance(in_proj, torch.nn.Linear) or in_proj.bias is not None:
+    if not isinstance(in_proj, torch.nn.Linear) or type(in_proj).__name__ == "Linear2d" or in_proj.bias is not None:
         return False
     d = x.shape[-1]
-    if isinstance(norm, torch.nn.LayerNorm):
+    if isinstance(norm, torch.nn.LayerNorm) and type(norm).__name__ != "LayerNorm2d":
         if tuple(norm.normalized_shape) != (d,) or norm.weight is None or norm.bias is None:
             return False
     elif not isinstance(norm, torch.nn.Identity):

@@ -48,7 +48,35 @@ def used_once(*params):
 
 
 def reset_uses():
+    """Start of a step (trainer) / of a test: forget the use counts AND whatever an aborted backward left queued.
+    autograd runs the end-of-pass callback only when a backward COMPLETES; after an exception (OOM, kernel error, a failed
+    graph capture that the trainer catches) the queue would stay non-empty for good, `defer_reduction` would never queue the
+    flush again and every later step would return uninitialised dgamma / dbeta.  Entries of an aborted pass are dropped:
+    their gradients belong to a step that did not happen."""
     _uses.clear()
+    _pending.clear()
+
+
+class deferred:
+    """`with layernorm.deferred(on):` — DEFER_REDUCE for the forward + backward of one step only (process-global state must not
+    leak into other backward passes of the process: a second trainer in ddp / accumulation mode, a tester, user code)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global DEFER_REDUCE
+        self.prev = DEFER_REDUCE
+        DEFER_REDUCE = self.on
+        reset_uses()
+        return self
+
+    def __exit__(self, *exc):
+        global DEFER_REDUCE
+        DEFER_REDUCE = self.prev
+        if exc[0] is not None:
+            reset_uses()
+        return False
 
 
 def _flush_pending():
@@ -82,7 +110,7 @@ def defer_reduction(ws, dg, db, rows, C, weight=None, bias=None, nblk=None):
     instead of adopting them as .grad).  nblk: rows of 2 C partials in ws (default: LayerNorm's own grid for `rows`)."""
     if not DEFER_REDUCE:
         return False
-    if not _pending:
+    if not _pending:     # (an aborted backward cannot leave entries behind: reset_uses() at the start of every step drops them)
         torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
     ref = lambda t: (None, 0) if t is None else (t.untyped_storage(), t.data_ptr())   # noqa: E731
     if nblk is None:

@@ -26,13 +26,15 @@ def _p(t):
 
 
 def supported(x, norm, mlp):
-    """GPU, bf16 autocast, fp32 channel-last stream, plain Mlp (GELU exact, no dropout) of a supported width."""
+    """GPU, bf16 autocast, fp32 channel-last stream, plain Mlp (GELU exact, no dropout) of a supported width.
+    (The channel-first subclasses Linear2d / LayerNorm2d act on axis 1: never the row kernel, whatever x.shape[-1] is.)"""
     if os.environ.get("VMASR_FUSED_MLP", "1") != "1" or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
         return False
     if not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
         return False
     fc1, fc2 = getattr(mlp, "fc1", None), getattr(mlp, "fc2", None)
-    if not (isinstance(fc1, torch.nn.Linear) and isinstance(fc2, torch.nn.Linear) and isinstance(norm, torch.nn.LayerNorm)):
+    if not (isinstance(fc1, torch.nn.Linear) and isinstance(fc2, torch.nn.Linear) and isinstance(norm, torch.nn.LayerNorm)
+            and all(type(m).__name__ not in ("Linear2d", "LayerNorm2d") for m in (fc1, fc2, norm))):
         return False
     if not isinstance(mlp.act, torch.nn.GELU) or getattr(mlp.act, "approximate", "none") != "none":
         return False

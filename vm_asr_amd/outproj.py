@@ -32,7 +32,7 @@ def supported(g, out_proj, x, dropout=None):
         return False
     if g.dtype != torch.bfloat16 or x.dtype not in (torch.float32, torch.bfloat16):
         return False
-    if not isinstance(out_proj, torch.nn.Linear) or out_proj.bias is not None:
+    if not isinstance(out_proj, torch.nn.Linear) or type(out_proj).__name__ == "Linear2d" or out_proj.bias is not None:
         return False
     if dropout is not None and not isinstance(dropout, torch.nn.Identity) and getattr(dropout, "p", 0.0) != 0.0 and dropout.training:
         return False

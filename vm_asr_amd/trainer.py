@@ -200,34 +200,6 @@ def load_optimizer_state(optimizer, state_dict, device):
     lr_to_device(optimizer, device)
 
 
-def resume_config(config, logger=None):
-    """The run's config as the reference resumes it: utils/utils.py:112-178 (`load_from_path`) replaces the CLI config
-    by the one stored in the GENERATOR's checkpoint BEFORE models, optimisers, schedulers or the trainer are built
-    (main.py calls this first).  Returns `config` unchanged when there is nothing to resume."""
-    from .config import from_yacs, yacs_pickle_compat
-    path = config.MODEL.RESUME_PATH
-    if not path:
-        return config
-    for kind in ("best", "latest"):
-        f = os.path.join(path, f"checkpoint-{kind}-G.pth")
-        if os.path.exists(f):
-            with yacs_pickle_compat():
-                ck = torch.load(f, map_location="cpu", weights_only=False)
-            if ck.get("config") is None:
-                return config
-            cfg = from_yacs(ck["config"]).clone()
-            cfg.defrost()
-            cfg.MODEL.RESUME_PATH = path
-            for k in ("EVAL_MODE", "INFERENCE_MODE", "THROUGHPUT_MODE"):      # what this invocation was asked to do
-                if hasattr(config, k):
-                    setattr(cfg, k, getattr(config, k))
-            cfg.freeze()
-            if logger is not None:
-                logger.info(f"Config restored from {f}")
-            return cfg
-    return config
-
-
 class _Logger:
     """stderr only: stdout belongs to callers that print machine-readable results (bench.py)."""
 
@@ -334,9 +306,10 @@ class BaseTrainer:
 
     def _resume_checkpoint(self):
         """Loads `checkpoint-best-*.pth` (falls back to latest) from MODEL.RESUME_PATH
-        (utils/utils.py:112-178): state_dict strict, optimizer state, epoch, monitor_best; the generator's
-        config restore of the reference (:141-145) happens before construction, in `resume_config()`.  Reads the reference's own
-        files too (their pickled yacs CfgNode resolves through config.yacs_pickle_compat)."""
+        (utils/utils.py:112-178): state_dict strict, optimizer state, epoch, monitor_best; then, as the reference does AFTER
+        everything has been constructed from the CLI config, `self.config` becomes the generator checkpoint's
+        (base/base_trainer.py:181-192).  Reads the reference's own files too (their pickled yacs CfgNode resolves through
+        config.yacs_pickle_compat)."""
         from .config import from_yacs, yacs_pickle_compat
         path = self.config.MODEL.RESUME_PATH
         for key, model in self.models.items():
@@ -356,11 +329,19 @@ class BaseTrainer:
                     if key == "generator":
                         self.start_epoch = ck["epoch"] + 1
                         self.mnt_best = ck.get("monitor_best", self.mnt_best)
-                        # The checkpoint's config is NOT swapped in here: everything this trainer derived (epochs, losses,
-                        # schedulers, log dir) came from the config it was constructed with.  The reference restores the
-                        # stored config BEFORE building anything (utils/utils.py:141-145) — that is `resume_config()`,
-                        # which main.py calls first; the stored one is kept for inspection.
+                        # base/base_trainer.py:181-192 + utils/utils.py:141-145: models, optimisers, schedulers, `self.epochs` and
+                        # the log directory were built from the CLI config BEFORE this point and stay as built (so
+                        # `--resume DIR --epochs N`, `--output`, `--batch-size`, moved data paths ... take effect); only
+                        # `self.config` — what the step reads from now on (losses, print / save frequencies) — becomes the
+                        # generator checkpoint's, with RESUME_PATH re-pointed.  Evaluation keeps the CLI config (:154-176).
                         self.checkpoint_config = from_yacs(ck["config"]) if ck.get("config") is not None else None
+                        if self.checkpoint_config is not None and not getattr(self.config, "EVAL_MODE", False) \
+                                and not getattr(self.config, "INFERENCE_MODE", False):
+                            cfg = self.checkpoint_config.clone()
+                            cfg.defrost()
+                            cfg.MODEL.RESUME_PATH = path
+                            cfg.freeze()
+                            self.config = cfg
                     self.logger.info(f"Resumed {name} from {f} (epoch {ck['epoch']})")
                     break
         if getattr(self, "_shadow_dst", None):
@@ -653,14 +634,21 @@ class Trainer(BaseTrainer):
 
     def _backward_g(self, st, zero=True):
         """Backward of the generator loss — through the (shared) discriminator pass for input gradients only."""
-        if zero:
-            self._zero_grads("generator", self.optimizer_G)
-        if st["shared"]:
-            from .discriminator import skip_weight_grads
-            with skip_weight_grads():
-                st["total_g"].backward(inputs=self._grad_targets("generator"))
-        else:   # the generator's pass saw the discriminator weights as constants (detach_weights)
-            st["total_g"].backward()
+        from . import layernorm
+        try:
+            if zero:
+                self._zero_grads("generator", self.optimizer_G)
+            if st["shared"]:
+                from .discriminator import skip_weight_grads
+                with skip_weight_grads():
+                    st["total_g"].backward(inputs=self._grad_targets("generator"))
+            else:   # the generator's pass saw the discriminator weights as constants (detach_weights)
+                st["total_g"].backward()
+        finally:
+            # the step's last backward is over (or failed): deferral is a property of THIS step's passes, not of the process —
+            # any other backward (another trainer, a tester, user code) must not inherit it; an aborted pass' queue is dropped
+            layernorm.DEFER_REDUCE = False
+            layernorm.reset_uses()
         self._gather_grads("generator")
 
     def _forward_backward(self, wave_input, wave_target, highcut, zero=True):

@@ -379,7 +379,10 @@ class SS2D(nn.Module):
                 and self.d_conv == 3 and self.out_norm_shape == "v0" and isinstance(self.out_norm, LayerNorm)
                 and getattr(self, "conv_act_fn", None) is None and isinstance(fc, partial)
                 and fc.keywords.get("SelectiveScan") is SelectiveScanCore and fc.keywords.get("CrossScan") is CrossScanHIP
-                and fc.keywords.get("CrossMerge") is CrossMergeHIP and fc.keywords.get("force_fp32", False))
+                and fc.keywords.get("CrossMerge") is CrossMergeHIP and fc.keywords.get("force_fp32", False)
+                # the fused cores are softplus / x_proj-as-einsum semantics only (forward_corev2's `hip_default` predicate): a
+                # forward_type that sets delta_softplus=False or no_einsum=True must take the operator chain
+                and fc.keywords.get("delta_softplus", True) and not fc.keywords.get("no_einsum", False))
 
     def _finish(self, y, residual):
         """out_proj (+ dropout) and — when the calling block handed over (stream, DropPath) — its stochastic-depth residual
