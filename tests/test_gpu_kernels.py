@@ -559,3 +559,44 @@ def test_layer_norm_deferred_reduction_matches_immediate():
         L.reset_uses()
     for a, b, c in zip(ref, got, got2):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * a.abs().max().item()) and torch.equal(b, c)
+
+
+def test_layer_norm_deferred_queue_survives_an_aborted_backward():
+    """autograd runs the end-of-pass callback only when a backward COMPLETES.  A backward that raises (OOM, kernel
+    error, failed graph capture) must not leave the queue non-empty for good: the next step (reset_uses(), as the trainer
+    calls it at the start of every step) has to produce correct dgamma / dbeta again."""
+    from vm_asr_amd import layernorm as L
+    torch.manual_seed(1)
+    ln = L.LayerNorm(16).to(DEV)
+    x = torch.randn(4096, 16, device=DEV, requires_grad=True)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    def grads():
+        ln.zero_grad(set_to_none=True)
+        ln(x).sin().sum().backward()
+        return [p.grad.clone() for p in ln.parameters()]
+    ref = grads()
+    try:
+        with pytest.raises(RuntimeError, match="boom"):
+            with L.deferred(True):
+                ln.zero_grad(set_to_none=True)
+                ln(Boom.apply(x)).sin().sum().backward()      # aborts AFTER LayerNorm's backward has queued its reduction
+        assert not L._pending and not L.DEFER_REDUCE              # scope left: nothing queued, deferral off again
+        L.DEFER_REDUCE = True                                      # the trainer's own protocol: flag + reset_uses() per step
+        L._pending.append(("stale",))                              # what an aborted pass used to leave behind
+        L.reset_uses()
+        got = grads()
+        assert not L._pending
+    finally:
+        L.DEFER_REDUCE = False
+        L.reset_uses()
+    for a, b in zip(ref, got):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * a.abs().max().item())
