@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r04_pmc_traffic.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 
@@ -45,6 +45,22 @@ def make_config(workload, batch):
         c.DATA.BATCH_SIZE = 4
     elif workload == "vm_asr_48k_16k_MPD_VSSM32":     # configs[4]: the yaml as written sets DIMS 32, batch 8
         c.MODEL.VSSM.DIMS = 32
+        c.TRAIN.ADVERSARIAL.ENABLE = True
+        c.TRAIN.ADVERSARIAL.DISCRIMINATORS = ["mpd"]
+        c.TRAIN.ADVERSARIAL.STFT_LOSS.EMPHASIZE_HIGH_FREQ = False
+        c.DATA.BATCH_SIZE = 8
+    elif workload == "vm_asr_48k_16k_nfft2048":       # configs/vm_asr_48k_16k_nfft2048.yaml:17-19 as written: n_fft 2048 (win stays 1024), batch 8
+        c.DATA.STFT.N_FFT = 2048
+        c.TRAIN.ADVERSARIAL.ENABLE = True
+        c.TRAIN.ADVERSARIAL.DISCRIMINATORS = ["mpd"]
+        c.TRAIN.ADVERSARIAL.STFT_LOSS.EMPHASIZE_HIGH_FREQ = False
+        c.DATA.BATCH_SIZE = 8
+    elif workload == "vm_asr_48k_16k_MPD_VSSM32_dstate32_nfft2048":
+        # configs[4] as BASELINE.json words it: the DIMS-32 yaml + `--opts MODEL.VSSM.SSM_D_STATE 32 DATA.STFT.N_FFT 2048`
+        # (main.py:39-44, config.py:100,55) — the long-sequence, general-N stress point
+        c.MODEL.VSSM.DIMS = 32
+        c.MODEL.VSSM.SSM_D_STATE = 32
+        c.DATA.STFT.N_FFT = 2048
         c.TRAIN.ADVERSARIAL.ENABLE = True
         c.TRAIN.ADVERSARIAL.DISCRIMINATORS = ["mpd"]
         c.TRAIN.ADVERSARIAL.STFT_LOSS.EMPHASIZE_HIGH_FREQ = False
@@ -107,7 +123,7 @@ def cpu_baseline(config, budget_s=60.0):
                       f"in {dt:.1f} s: torch-CPU modules + oracle C kernels (OpenMP)"}
 
 
-def run_point(config, args, device, rank, world, steps, warmup, timing):
+def run_point(config, args, device, rank, world, steps, warmup, timing, with_metrics=False):
     """Build the trainer for `config`, warm up, capture, time `steps` steps (barrier + synchronize on both sides, max over
     ranks) and — `timing` — run the same steps once more eagerly with the library's HIP-event timer on.
     -> (seconds for `steps` steps, graphed?, per-rank dict or None, {kernel: dict(launches, ms, alg_bytes)} or None)."""
@@ -126,15 +142,24 @@ def run_point(config, args, device, rank, world, steps, warmup, timing):
             print(json.dumps({"error": "HIP graph capture / replay self-test failed; rerun with --no-graphs to measure the eager step",
                               "detail": getattr(trainer, "graph_error", None), "rank": rank}), flush=True)
             sys.exit(3)
+    mets = []
+    if with_metrics:        # trainer/trainer.py:179-182: SNR / LSD / LSD-HF / LSD-LF of every step's output, read on the host
+        from vm_asr_amd.trainer import default_metric_ftns
+        mets = default_metric_ftns(config)
+
+    def one_step():
+        out, _ = trainer.train_step(*batch)
+        for m in mets:
+            float(m(out.float().squeeze(1), batch[1].squeeze(1), hf=batch[2]))
     for _ in range(warmup):
-        trainer.train_step(*batch)
+        one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     trainer.time_reduces = world > 1
     t0 = time.perf_counter()
     for _ in range(steps):
-        trainer.train_step(*batch)
+        one_step()
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0          # this rank's own time to finish its K steps
     if world > 1:
@@ -168,6 +193,8 @@ def run_point(config, args, device, rank, world, steps, warmup, timing):
         _lib.prof_enable(False)
         trainer._graphed = g_saved
         prof = _lib.prof_collect() if rank == 0 else {}
+        if rank == 0:
+            prof["__shapes__"] = {k: _lib.prof_collect_shapes(k) for k in prof if k in SCAN_KERNELS or k.startswith("sscan") or k.startswith("conv_mfma")}
     del trainer
     torch.cuda.empty_cache()
     return dt, graphed, per_rank, prof
@@ -186,7 +213,7 @@ def scan_summary(prof, steps):
     where a call still takes the unfused path; algorithmic bytes are counted once per op (the apply / single-pass kernels carry
     them)."""
     kern = {k: dict(v, avg_us=v["ms"] / v["launches"] * 1e3, gbs=v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)
-            for k, v in prof.items()}
+            for k, v in prof.items() if k != "__shapes__"}
     scan = {k: v for k, v in kern.items() if k.startswith("sscan") or k in SCAN_KERNELS}
     if not scan:
         return kern, None, None
@@ -198,25 +225,72 @@ def scan_summary(prof, steps):
     return kern, dom, op
 
 
-def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, steps=10):
+def shape_table(prof, name):
+    """Per call shape of kernel `name`: launches, average duration, contract-algorithmic GB/s.  A fused kernel can read > peak
+    here: the contract counts the reference operator's Delta / B / C / direction streams, which never exist in HBM (e.g. the
+    d_inner-2 call of ss2d_bwd_apply) — `frac_traffic` in the same block is the fraction on bytes actually moved."""
+    rows = []
+    for g in (prof.get("__shapes__") or {}).get(name, []):
+        us = g["ms"] / g["launches"] * 1e3
+        gbs = g["alg_bytes_per_launch"] / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        rows.append({"alg_bytes_per_launch": g["alg_bytes_per_launch"], "launches": g["launches"], "avg_us": round(us, 2),
+                     "GB/s": round(gbs, 1), "frac_contract": round(gbs / HBM_PEAK_GBS, 4),
+                     **({"note": "contract bytes exceed what any kernel could move: the streams counted never reach HBM (fusion)"}
+                        if gbs > HBM_PEAK_GBS else {})})
+    return rows
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: a PMC file measured on other sources must not be quoted as this build's traffic."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "vm_asr_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vm_asr_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, steps=10, with_metrics=False):
     """A second operating point measured in the same process after the headline (N = 1 only): compact record with its own
-    roofline block.  `mpd_gemm`: VMASR_MPD_GEMM for this point (read when the discriminator's layers are built into the graph)."""
+    roofline block.  `mpd_gemm`: VMASR_MPD_GEMM for this point (read when the discriminator's layers are built into the graph).
+    A point that does not fit at its yaml's batch is retried at half the batch (recorded)."""
     saved = os.environ.get("VMASR_MPD_GEMM")
     os.environ["VMASR_MPD_GEMM"] = mpd_gemm
+    tried = []
     try:
-        cfg = make_config(workload, batch)
-        dt, graphed, _, prof = run_point(cfg, args, device, rank, world, steps, 3, True)
+        while True:
+            cfg = make_config(workload, batch)
+            try:
+                dt, graphed, _, prof = run_point(cfg, args, device, rank, world, steps, 3, True, with_metrics=with_metrics)
+                break
+            except torch.OutOfMemoryError:
+                tried.append(cfg.DATA.BATCH_SIZE)
+                torch.cuda.empty_cache()
+                if cfg.DATA.BATCH_SIZE <= 1:
+                    raise
+                batch = cfg.DATA.BATCH_SIZE // 2
     finally:
         os.environ["VMASR_MPD_GEMM"] = saved if saved is not None else "bf16x3"
     B = cfg.DATA.BATCH_SIZE
-    rec = {"workload": f"{workload}.yaml, per-GPU batch {B}, DIMS {cfg.MODEL.VSSM.DIMS}, MPD GEMMs {mpd_gemm}", "value": B * steps / dt,
-           "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "execution": "HIP graph replay" if graphed else "eager"}
+    rec = {"workload": f"{workload}.yaml, per-GPU batch {B}, DIMS {cfg.MODEL.VSSM.DIMS}, d_state {cfg.MODEL.VSSM.SSM_D_STATE}, "
+                       f"n_fft {cfg.DATA.STFT.N_FFT}, MPD GEMMs {mpd_gemm}" + (", SNR/LSD/LSD-HF/LSD-LF evaluated and read every step" if with_metrics else ""),
+           "value": B * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "execution": "HIP graph replay" if graphed else "eager"}
+    if tried:
+        rec["out_of_memory_at_batch"] = tried
     kern, dom, op = scan_summary(prof, steps)
     if dom:
         d = kern[dom]
         rec["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": d["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d["avg_us"], "launches": d["launches"],
-                           "selective_scan_op": op}
+                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "traffic": None,
+                           "selective_scan_op": op, "shapes": shape_table(prof, dom)}
+        rec["scan_alg_bytes_per_clip"] = op["alg_bytes_per_step"] / B if op else None
+    top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:14]
+    rec["top_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "ms_per_step": round(v["ms"] / steps, 3)} for k, v in top}
+    rec["unfused_chain_kernels"] = sorted(k for k in kern if k in ("cross_scan", "cross_merge", "xproj_fwd", "xproj_bwd_a", "xproj_bwd_b")
+                                          or k.startswith("sscan_"))
     mf = {k: v for k, v in kern.items() if k.startswith("mlp_")}
     if mf:
         rec["mlp_mfma_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2)} for k, v in mf.items()}
@@ -228,7 +302,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="vm_asr_48k_MPD", choices=["vm_asr_48k_MPD", "vm_asr_48k", "vm_asr_48k_16k_MPD_VSSM32"])
+    ap.add_argument("--workload", default="vm_asr_48k_MPD", choices=["vm_asr_48k_MPD", "vm_asr_48k", "vm_asr_48k_16k_MPD_VSSM32", "vm_asr_48k_16k_nfft2048",
+                                                                  "vm_asr_48k_16k_MPD_VSSM32_dstate32_nfft2048"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the yaml's)")
     ap.add_argument("--no-amp", action="store_true")
     ap.add_argument("--amp-scope", default="generator", choices=["generator", "step"],
@@ -238,7 +313,10 @@ def main():
                     help="the fp32 discriminator's compute-bound GEMMs: 'bf16x3' = error-compensated triple bf16 MFMA products "
                          "(fp32 operands split into hi + lo bf16, fp32 accumulation; csrc/split.hip), 'fp32' = f32-input MFMA GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-points", action="store_true", help="skip the secondary operating points (fp32 MPD GEMMs; DIMS 32, batch 8)")
+    ap.add_argument("--no-extra-points", action="store_true",
+                    help="skip the secondary operating points (fp32 MPD GEMMs; per-step metrics; DIMS 32; n_fft 2048; d_state 32 + n_fft 2048)")
+    ap.add_argument("--with-metrics", action="store_true",
+                    help="evaluate SNR / LSD / LSD-HF / LSD-LF on the HIP STFT and read them on the host every step, as trainer/trainer.py:179-182 does")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     args = ap.parse_args()
@@ -256,7 +334,10 @@ def main():
     torch.cuda.set_device(device)
 
     config = make_config(args.workload, args.batch)
-    dt, graphed, per_rank, prof = run_point(config, args, device, rank, world, args.steps, args.warmup, not args.no_kernel_timing)
+    from vm_asr_amd.trainer import distributed_info
+    dinfo = distributed_info(device)
+    dt, graphed, per_rank, prof = run_point(config, args, device, rank, world, args.steps, args.warmup, not args.no_kernel_timing,
+                                            with_metrics=args.with_metrics)
     timing = prof is not None
 
     B = config.DATA.BATCH_SIZE
@@ -277,26 +358,35 @@ def main():
                    "execution": ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
                                  "optimiser graph)") if graphed else "eager"},
     }
+    out["distributed"] = dinfo     # what the process group actually was: world size, backend, RCCL version, every rank's device
+    out["config"]["per_step_metrics"] = bool(args.with_metrics)
     if per_rank is not None:
         out["per_rank"] = per_rank
     if rank == 0 and timing:
         kern, dom, op = scan_summary(prof, args.steps)
         if dom:
             d = kern[dom]
-            # HBM bytes per launch from the committed PMC passes of this same workload (rocprofv3 cannot
-            # run inside bench.py): profiles/<PMC_FILE>, made by tools/pmc_bench_report.py
-            traffic = None
-            pmc_file = PMC_FILE if os.path.exists(os.path.join(ROOT, "profiles", PMC_FILE)) else "r02_pmc_traffic.json"
+            # HBM bytes per launch from the PMC passes of this same workload (rocprofv3 cannot run inside bench.py): profiles/<PMC_FILE>,
+            # made by tools/evidence_r04.sh / tools/pmc_bench_report.py, which records the digest of the kernel sources it measured;
+            # a file measured on other sources is NOT quoted (traffic = null, traffic_note says why)
+            traffic, traffic_note, pmc_file = None, None, PMC_FILE
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
-                traffic = pmc[dom]["hbm_bytes_per_launch"] if B == 4 and args.workload == "vm_asr_48k_MPD" else None
-            except Exception:
-                pass
+                pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+                if pj.get("csrc_digest") != csrc_digest():
+                    traffic_note = f"profiles/{pmc_file} was measured on other kernel sources (digest {pj.get('csrc_digest')} != {csrc_digest()}): not quoted"
+                elif B == 4 and args.workload == "vm_asr_48k_MPD":
+                    traffic = pj["kernels"][dom]["hbm_bytes_per_launch"]
+            except Exception as e:
+                traffic_note = f"no PMC file for this build ({type(e).__name__})"
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": d["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_traffic": (traffic / (d["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                  "FETCH_SIZE x2 per the gfx950 correction)" if traffic else None,
+                                  "FETCH_SIZE x2 per the gfx950 correction; same kernel sources as this build)" if traffic else traffic_note,
+                "frac_definition": "frac = contract-algorithmic bytes / time / peak (what the reference's operator would move); "
+                                   "frac_traffic = PMC bytes actually moved / time / peak — the fused kernels are VALU-issue-bound, not HBM-bound",
+                "shapes": shape_table(prof, dom),
                 "bytes_definition": "SURVEY.md 8(d) algorithmic bytes of the selective-scan calls the launch performs (for the fused "
                                     "ss2d_* kernels: the reference contract's Delta/B/C/direction streams that never reach HBM here "
                                     "are part of it, so `traffic` << algorithmic bytes is the fusion, not over-fetch)",
@@ -311,12 +401,17 @@ def main():
         # driver-visible secondary operating points: the reference-precision discriminator GEMMs, and
         # configs[4]'s yaml (DIMS 32, batch 8) with its own roofline block.  Never part of `value`.
         pts = {}
-        for name, wl, bsz, gemm in (("mpd_gemm_fp32", "vm_asr_48k_MPD", 0, "fp32"),
-                                    ("vm_asr_48k_16k_MPD_VSSM32", "vm_asr_48k_16k_MPD_VSSM32", 0, args.mpd_gemm)):
+        for name, wl, bsz, gemm, met in (("mpd_gemm_fp32", "vm_asr_48k_MPD", 0, "fp32", False),
+                                         ("with_metrics", "vm_asr_48k_MPD", 0, args.mpd_gemm, True),
+                                         ("vm_asr_48k_16k_MPD_VSSM32", "vm_asr_48k_16k_MPD_VSSM32", 0, args.mpd_gemm, False),
+                                         ("vm_asr_48k_16k_nfft2048", "vm_asr_48k_16k_nfft2048", 0, args.mpd_gemm, False),
+                                         ("vm_asr_48k_16k_MPD_VSSM32_dstate32_nfft2048", "vm_asr_48k_16k_MPD_VSSM32_dstate32_nfft2048", 0,
+                                          args.mpd_gemm, False)):
             try:
-                pts[name] = extra_point(name, wl, bsz, gemm, args, device, rank, world)
+                pts[name] = extra_point(name, wl, bsz, gemm, args, device, rank, world, steps=(5 if "dstate32" in name else 10), with_metrics=met)
             except Exception as e:   # informative only
                 pts[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
         out["operating_points"] = pts
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

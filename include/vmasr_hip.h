@@ -620,6 +620,9 @@ void vmasr_prof_reset(void);
 const char *vmasr_prof_name(int kernel_id);
 /* returns 0, or a hipError_t; blocks the host until the recorded events have completed */
 int vmasr_prof_collect(int kernel_id, int64_t *launches, double *total_ms, double *alg_bytes);
+/* the same per CALL SHAPE: launches of `kernel_id` grouped by their algorithmic byte count (<= max_groups groups, in order of
+ * first appearance); returns the number of groups filled, negative on a HIP error */
+int vmasr_prof_collect_shapes(int kernel_id, int max_groups, double *group_bytes, int64_t *group_launches, double *group_ms);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,8 @@ def kid(name):
                  ("col2im_kernel", "col2im_kx1"), ("deep_bwd_kernel", "ss2d_deep_bwd"), ("deep_fwd_kernel", "ss2d_deep_fwd"),
                  ("deep_xproj_kernel", "ss2d_deep_xproj"), ("deep_xg_kernel", "ss2d_deep_xbwd"), ("deep_dx_kernel", "ss2d_deep_xbwd"),
                  ("mlp_fwd_kernel", "mlp_fwd"), ("mlp_bwd_kernel", "mlp_bwd"), ("inproj_kernel", "inproj"), ("outproj_kernel", "outproj"),
-                 ("ln_gate_pair", "ln_gate_pair"), ("ln_gate", "ln_gate")):
+                 ("ln_gate_pair", "ln_gate_pair"), ("ln_gate", "ln_gate"), ("conv_mfma_nt_kernel", "conv_mfma_nt"),
+                 ("conv_mfma_wgrad_kernel", "conv_mfma_wgrad")):
         if k in name:
             return v
     for k in ("sscan_carry_kernel<false>", "sscan_carry_kernel<true>", "sscan_bwd_reduce_kernel", "cross_scan_kernel",
@@ -47,7 +48,10 @@ for k in f:
     fb, wb = f[k][1] * 2 * 1024 / n, (w[k][1] * 1024 / w[k][0]) if k in w else 0.0
     res[k] = {"launches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
     print(f"{k:28s} n={n:5d} fetch {fb/1e6:9.2f} MB  write {wb/1e6:9.2f} MB  total {(fb+wb)/1e6:9.2f} MB per launch")
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest   # the digest bench.py compares against before quoting `traffic`
+json.dump({"csrc_digest": csrc_digest(), "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
                    "`python bench.py --steps 1 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-timing`; "
                    "KiB units, FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B)", "kernels": res},
           open(sys.argv[3], "w"), indent=1)

@@ -158,6 +158,8 @@ SYMBOLS = {
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
     "vmasr_prof_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "vmasr_prof_collect_shapes": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                                 ctypes.POINTER(ctypes.c_double)]),
     "vmasr_cross_scan": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_cross_merge": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_dwconv_silu_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -249,3 +251,16 @@ def prof_collect():
         if n.value:
             out[l.vmasr_prof_name(k).decode()] = dict(launches=n.value, ms=ms.value, alg_bytes=by.value)
     return out
+
+
+def prof_collect_shapes(name, max_groups=16):
+    """-> [dict(alg_bytes_per_launch, launches, ms)] of kernel `name`, one entry per distinct call shape (= algorithmic byte count)."""
+    l = lib()
+    for k in range(K_COUNT):
+        if l.vmasr_prof_name(k).decode() == name:
+            by, n, ms = (ctypes.c_double * max_groups)(), (ctypes.c_int64 * max_groups)(), (ctypes.c_double * max_groups)()
+            ng = l.vmasr_prof_collect_shapes(k, max_groups, by, n, ms)
+            if ng < 0:
+                raise RuntimeError(f"prof_collect_shapes failed ({ng})")
+            return [dict(alg_bytes_per_launch=by[i], launches=n[i], ms=ms[i]) for i in range(ng)]
+    raise KeyError(name)

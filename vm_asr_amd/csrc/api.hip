@@ -103,3 +103,28 @@ VMASR_EXPORT int vmasr_prof_collect(int kid, int64_t *launches, double *total_ms
     if (alg_bytes) *alg_bytes = by;
     return 0;
 }
+
+// Per call shape: the launches of kernel `kid` grouped by their algorithmic byte count (a kernel's call shapes differ in it),
+// up to `max_groups` groups in order of first appearance.  Returns the number of groups (negative: HIP error).
+VMASR_EXPORT int vmasr_prof_collect_shapes(int kid, int max_groups, double *group_bytes, int64_t *group_launches, double *group_ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int ng = 0;
+    for (Rec &r : g_recs) {
+        if (r.kid != kid) continue;
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e != hipSuccess) return -(int)e;
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, r.e0, r.e1);
+        if (e != hipSuccess) return -(int)e;
+        int g = 0;
+        while (g < ng && group_bytes[g] != r.bytes) ++g;
+        if (g == ng) {
+            if (ng == max_groups) continue;
+            group_bytes[ng] = r.bytes; group_launches[ng] = 0; group_ms[ng] = 0.0;
+            ++ng;
+        }
+        ++group_launches[g];
+        group_ms[g] += t;
+    }
+    return ng;
+}

@@ -49,10 +49,42 @@ def init_distributed():
         # "nccl" is RCCL on ROCm.  VMASR_DIST_BACKEND=gloo lets the multi-process path be exercised
         # on a machine with fewer GPUs than ranks (ranks then share devices; test use only).
         backend = os.environ.get("VMASR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "nccl":
+                # bind the communicator to THIS rank's device up front (eager RCCL init on the right GPU: no lazy init on the
+                # first collective, no "guessing device" warning, and graph capture never races a communicator bootstrap)
+                kw["device_id"] = torch.device("cuda", local % torch.cuda.device_count())
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("VMASR_DIST_TIMEOUT_S", "600")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
+
+
+def distributed_info(device):
+    """What the process group actually is, gathered from every rank (bench.py records it so that an N-GPU line proves N ranks on
+    N different devices): world size, backend, RCCL version, and per rank the device index / name / UUID / PCI bus id."""
+    info = {"world_size": 1, "backend": None, "rccl_version": None}
+    mine = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()}
+    if device.type == "cuda":
+        p = torch.cuda.get_device_properties(device)
+        mine.update(device_index=device.index, name=p.name, uuid=str(getattr(p, "uuid", "")),
+                    pci_bus_id=getattr(p, "pci_bus_id", None), pci_device_id=getattr(p, "pci_device_id", None))
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    if dist.is_available() and dist.is_initialized():
+        info["world_size"], info["backend"] = dist.get_world_size(), dist.get_backend()
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, mine)
+        info["ranks"] = ranks
+        info["distinct_devices"] = len({(r.get("uuid") or r.get("pci_bus_id"), r.get("device_index")) for r in ranks})
+    else:
+        info["ranks"] = [mine]
+        info["distinct_devices"] = 1
+    return info
 
 
 def unwrap(m):
@@ -852,6 +884,9 @@ class Trainer(BaseTrainer):
         schedule count only real training steps."""
         from .graph_step import GraphedTrainStep
         snap = self._snapshot_training_state() if preserve_state else None
+        multi = self.world > 1 and dist.is_initialized()
+        if multi:
+            dist.barrier()          # every rank has built its models / communicator before anybody starts capturing
         try:
             self._graphed = GraphedTrainStep(self, example_batch, warmup)
             ok = True
@@ -860,6 +895,15 @@ class Trainer(BaseTrainer):
             self.graph_error = f"{type(e).__name__}: {e}"
             self.logger.warning(f"HIP graph capture unavailable ({self.graph_error}); running eagerly")
             ok = False
+        if multi:
+            # all ranks replay graphs or none does: a rank that fell back to the eager step would issue its collectives in a
+            # different order relative to its kernels and run ~2x slower — the others would sit in the all-reduce
+            dev = torch.device("cpu") if dist.get_backend() == "gloo" else self.device
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if ok and flag.item() == 0.0:
+                self._graphed, ok = None, False
+                self.graph_error = "graph capture failed on another rank"
         if snap is not None:
             torch.cuda.synchronize(self.device)
             self._restore_training_state(snap)
