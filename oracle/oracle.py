@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libvmasr_oracle.so")
+_LIB_PATH = os.environ.get("VMASR_ORACLE_LIB") or os.path.join(_HERE, "libvmasr_oracle.so")   # VMASR_ORACLE_LIB: the ASan build (make asan)
 _LIB64_PATH = os.path.join(_HERE, "libvmasr_oracle64.so")
 _lib = None
 _lib64 = None
@@ -41,6 +41,8 @@ def build(force=False):
     """Compile the C restatement with gcc (no GPU, no reference needed)."""
     src = os.path.join(_HERE, "vmasr_oracle.c")
     for path in (_LIB_PATH, _LIB64_PATH):
+        if os.path.dirname(os.path.abspath(path)) != _HERE:
+            continue          # an explicitly given library outside the tree is used as it is
         if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(path)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
