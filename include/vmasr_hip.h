@@ -309,6 +309,13 @@ int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, in
 int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
                           int32_t splits, vmasr_stream_t stream);
 
+/* Finish of n split-K weight-gradient GEMMs in one launch (csrc/wgrad.hip): item i has partial products parts[i] (S_i, N_i, ld_i)
+ * fp32; dws[i] (N_i, K_i) = sum over the S_i slabs of columns [0, K_i); dbs[i] (may be NULL) (N_i) = the same sum of column K_i
+ * (the bias gradient when the GEMM's operand carried a ones column).  Host arrays of device pointers / sizes.
+ * e1s / e2s (arrays may be NULL, entries may be NULL): (N_i) = columns K_i + 1 / K_i + 2 (the deep SS2D core's dA_log, dD). */
+int vmasr_wgrad_finish_multi(const float *const *parts, float *const *dws, float *const *dbs, float *const *e1s, float *const *e2s,
+                             const int32_t *Ss, const int32_t *Ns, const int32_t *Ks, const int32_t *lds, int32_t n, vmasr_stream_t stream);
+
 /* AdamW step of many parameter tensors in one launch (torch.optim.AdamW semantics, utils/optimizer.py:16-50 of the
  * reference; non-amsgrad, decoupled weight decay, bias correction).  `items` is a DEVICE array, one entry per tensor;
  * `chunks` a DEVICE array of (item index, chunk index) int32 pairs, one per workgroup, chunk = vmasr_adamw_chunk() elements;
@@ -419,7 +426,7 @@ int vmasr_ss2d_bwd(const vmasr_ss2d_params *p, vmasr_stream_t stream);
  * H and W multiples of 4, H*W in {256,512,1024,2048,4096} (vmasr_ss2d_deep_supported): a workgroup owns whole (b, d) rows,
  * cross-scan / cross-merge are LDS index computations, x_proj runs as a small kernel in front (and its adjoint behind).
  * All buffers are caller-owned device memory; `dtype` (VMASR_F32 or VMASR_BF16) is the type of x, dx, tp, tb, tc, gpos:
- *   x (B,D,H,W);  WxT (4,D,R+2) = x_proj_weight with its last two axes swapped;  Wdt (4,D,R) = dt_projs_weight;  dtb (4,D);
+ *   x (B,D,H,W);  WxT (4,R+2,D) = x_proj_weight AS STORED (the field keeps its round-3 name; since round 4 no transposed copy is made);  Wdt (4,D,R) = dt_projs_weight;  dtb (4,D);
  *   Alog (4D);  Ds (4D)                                                                                  weights fp32
  *   xdbl (B,4,R+2,H*W) fp32: written by the forward, read by the backward (directions 1/3 in (w,h) order);
  *   y (B,D,H*W) fp32 = the merged output.
@@ -613,6 +620,7 @@ enum {
     VMASR_K_CONV_MFMA_FWD,      /* discriminator (k,1) convolution as an implicit bf16x3 MFMA GEMM + bias + GELU + split (csrc/convgemm.hip) */
     VMASR_K_CONV_MFMA_DGRAD,    /* its input gradient (residue classes of the stride, no col2im)                                               */
     VMASR_K_CONV_MFMA_WGRAD,    /* its weight gradient (transposed LDS reads)                                                                   */
+    VMASR_K_WGRAD_FINISH,       /* sum over split-K slabs + bias column split-off of many weight gradients, one launch (csrc/wgrad.hip) */
     VMASR_K_COUNT
 };
 void vmasr_prof_enable(int on);

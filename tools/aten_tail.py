@@ -11,10 +11,14 @@ import bench  # noqa: E402
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 cfg = bench.make_config(os.environ.get("WORKLOAD", "vm_asr_48k_MPD"), int(os.environ.get("BATCH", "0")))
 dev = torch.device("cuda", 0)
-tr = bench.build_trainer(cfg, dev, amp=True, capturable=False)
+bench_mode = os.environ.get("TAIL_BENCH_MODE", "1") == "1"   # the step exactly as bench.py runs it (flat buffers, HIP AdamW, bf16 shadows), executed eagerly
+tr = bench.build_trainer(cfg, dev, amp=True, capturable=bench_mode)
 for m in tr.models.values():
     m.train()
 batch = bench.synth_batch(cfg, dev, 0)
+if bench_mode:
+    assert tr.enable_graphs(batch, warmup=2), getattr(tr, "graph_error", None)
+    tr._graphed = None
 for _ in range(3):
     tr.train_step(*batch)
 torch.cuda.synchronize()

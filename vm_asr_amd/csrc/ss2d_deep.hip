@@ -50,7 +50,7 @@ __device__ __forceinline__ float tree_sum(const float *p, const int stride) {
 
 // ---- x_proj: x (B, D, L) -> x_dbl (B, 4, C, L) ----------------------------------------------------------------------------
 // grid (L / 64, B, 4 directions); NW waves split the rows, lane = position (row-major); the C sums of the direction are reduced
-// over the waves in LDS.  WxT (4, D, C): the direction's C weights of a row are one contiguous scalar load.
+// over the waves in LDS.  Wx (4, C, D) is x_proj_weight AS STORED (scalar loads at stride D: a transposed copy per call cost a launch).
 template <typename T, int R, int NW>
 __global__ __launch_bounds__(64 * NW) void deep_xproj_kernel(const T *__restrict__ x, const float *__restrict__ WxT,
                                                             float *__restrict__ xdbl, const DeepGeo g) {
@@ -63,12 +63,12 @@ __global__ __launch_bounds__(64 * NW) void deep_xproj_kernel(const T *__restrict
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
     const T *xp = x + ((size_t)b * g.D + d0) * g.L + p;
-    const float *wp = WxT + ((size_t)k * g.D + d0) * C;
+    const float *wp = WxT + (size_t)k * C * g.D + d0;
 #pragma unroll 4
     for (int r = 0; r < rows; ++r) {
         const float v = to_f32(xp[(size_t)r * g.L]);
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = fmaf(wp[r * C + c], v, acc[c]);
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(wp[(size_t)c * g.D + r], v, acc[c]);
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) s_red[(wave * C + c) * 64 + lane] = acc[c];
@@ -258,7 +258,7 @@ struct DeepBwdArgs {
     Weights w;
     float *du;                // (B, D, L) fp32: the scan's own gradient wrt x, merged over the directions
     void *tp, *tb, *tc;       // (B, 4, D, L) dtype T each
-    float *pg;                // (B, 4, D, WR, kPG)
+    float *pg;                // (B, WR, 4, D, kPG): slab-major, so that csrc/wgrad.hip sums the B * WR slabs of a (4 D, kPG) matrix
 };
 
 template <int R, int WR>
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64 * WR * RG) void deep_bwd_kernel(const DeepBwdArg
         const RowP<R> w = load_row<R>(a.w, k * D + d);
         float tp[4], tb[4], tc[4];
         bwd_dir<R, WR>(k, q, lane, u, dout, s, w, tot + k * WR, adj + k * WR, du, tp, tb, tc,
-                       a.pg + ((((size_t)b * 4 + k) * D + d) * WR + q) * kPG);
+                       a.pg + ((((size_t)b * WR + q) * 4 + k) * D + d) * kPG);
         const size_t trow = (((size_t)b * 4 + k) * D + d) * L;
         store4<T, true>(static_cast<T *>(a.tp) + trow, l0, L, tp);
         store4<T, true>(static_cast<T *>(a.tb) + trow, l0, L, tb);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * WR * RG) void deep_bwd_kernel(const DeepBwdArg
         const RowP<R> w = load_row<R>(a.w, k * D + d);
         float tp[4], tb[4], tc[4];
         bwd_dir<R, WR>(k, q, lane, uc, dc, s, w, tot + k * WR, adj + k * WR, duc, tp, tb, tc,
-                       a.pg + ((((size_t)b * 4 + k) * D + d) * WR + q) * kPG);
+                       a.pg + ((((size_t)b * WR + q) * 4 + k) * D + d) * kPG);
         const size_t trow = (((size_t)b * 4 + k) * D + d) * L;      // (column-major order, like the scan: deep_xg_kernel maps back)
         store4<T, true>(static_cast<T *>(a.tp) + trow, l0, L, tp);
         store4<T, true>(static_cast<T *>(a.tb) + trow, l0, L, tb);
@@ -487,10 +487,10 @@ __global__ __launch_bounds__(256) void deep_dx_kernel(const float *__restrict__ 
         float sk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float *wr = WxT + ((size_t)k * D + d) * C;
-            float s0 = wr[0] * gv[k * C], s1 = wr[1] * gv[k * C + 1];
+            const float *wr = WxT + (size_t)k * C * D + d;          // x_proj_weight as stored: (4, C, D)
+            float s0 = wr[0] * gv[k * C], s1 = wr[D] * gv[k * C + 1];
 #pragma unroll
-            for (int c = 2; c < C; c += 2) { s0 = fmaf(wr[c], gv[k * C + c], s0); s1 = fmaf(wr[c + 1], gv[k * C + c + 1], s1); }
+            for (int c = 2; c < C; c += 2) { s0 = fmaf(wr[(size_t)c * D], gv[k * C + c], s0); s1 = fmaf(wr[(size_t)(c + 1) * D], gv[k * C + c + 1], s1); }
             sk[k] = s0 + s1;
         }
         dx[o] = from_f32<T>(du[o] + ((sk[0] + sk[2]) + (sk[1] + sk[3])));

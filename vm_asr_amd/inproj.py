@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from . import layernorm as _ln
+from .wgrad import weight_grad_finished
 from .linear import LP_ATTR, weight_grad
 from .mlp import _bf16_t
 
@@ -72,6 +73,10 @@ class _InProjFn(torch.autograd.Function):
             _ln.note_use(gamma, beta)
         ctx.fresh = lambda: gamma is not None and gamma.grad is None and beta.grad is None and _ln.used_once(gamma, beta)
         ctx.params = (gamma, beta)
+        if ctx.needs_input_grad[3]:
+            _ln.note_use(weight)
+        ctx.wparam = weight
+        ctx.fresh_w = lambda: weight.grad is None and weight.dtype == torch.float32 and _ln.used_once(weight)
         return xT, sz
 
     @staticmethod
@@ -108,7 +113,8 @@ class _InProjFn(torch.autograd.Function):
                 dg, db = dg.to(gdt), db.to(bedt)
             else:
                 dx = dxn.to(x2.dtype)
-        dw = weight_grad(gpre, xn)                                    # (4d, d) fp32, split over the rows when few tiles
+        # (4d, d) fp32, split over the rows when few tiles; finished together with the pass' other weight gradients (wgrad.py)
+        dw, _ = weight_grad_finished(gpre, xn, d, ctx.wparam, None, ctx.fresh_w())
         return dx.view(shape), dg, db, dw.to(wdt), None
 
 

@@ -47,6 +47,24 @@ def used_once(*params):
     return all(_uses.get(id(t), 0) == 1 for t in params if t is not None)
 
 
+_cb_queued = [False]   # the end-of-pass callback of the running backward has been queued
+_flush_hooks = []      # other modules' end-of-pass work (vm_asr_amd/wgrad.py): objects with .flush() and .reset()
+
+
+def ensure_callback():
+    """Queue ONE end-of-pass callback per backward pass (autograd runs it when the pass completes)."""
+    if not _cb_queued[0]:
+        _cb_queued[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_all)
+
+
+def _flush_all():
+    _cb_queued[0] = False
+    _flush_pending()
+    for h in _flush_hooks:
+        h.flush()
+
+
 def reset_uses():
     """Start of a step (trainer) / of a test: forget the use counts AND whatever an aborted backward left queued.
     autograd runs the end-of-pass callback only when a backward COMPLETES; after an exception (OOM, kernel error, a failed
@@ -55,6 +73,9 @@ def reset_uses():
     their gradients belong to a step that did not happen."""
     _uses.clear()
     _pending.clear()
+    _cb_queued[0] = False
+    for h in _flush_hooks:
+        h.reset()
 
 
 class deferred:
@@ -110,8 +131,7 @@ def defer_reduction(ws, dg, db, rows, C, weight=None, bias=None, nblk=None):
     instead of adopting them as .grad).  nblk: rows of 2 C partials in ws (default: LayerNorm's own grid for `rows`)."""
     if not DEFER_REDUCE:
         return False
-    if not _pending:     # (an aborted backward cannot leave entries behind: reset_uses() at the start of every step drops them)
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+    ensure_callback()    # (an aborted backward cannot leave entries behind: reset_uses() at the start of every step drops them)
     ref = lambda t: (None, 0) if t is None else (t.untyped_storage(), t.data_ptr())   # noqa: E731
     if nblk is None:
         nblk = int(_lib.lib().vmasr_layer_norm_bwd_blocks(rows, C))

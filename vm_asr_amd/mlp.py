@@ -16,6 +16,7 @@ import torch
 
 from . import _lib
 from . import layernorm as _ln
+from .wgrad import weight_grad_finished
 from .linear import LP_ATTR, LPT_ATTR, weight_grad
 
 __all__ = ["fused_mlp_residual", "supported"]
@@ -86,6 +87,10 @@ class _FusedMlpFn(torch.autograd.Function):
             _ln.note_use(gamma, beta)
         ctx.fresh = lambda: gamma.grad is None and beta.grad is None and _ln.used_once(gamma, beta)
         ctx.params = (gamma, beta)
+        if any(ctx.needs_input_grad[3:7]):
+            _ln.note_use(w1, b1, w2, b2)
+        ctx.wparams = (w1, b1, w2, b2)
+        ctx.fresh_w = lambda: (all(p.grad is None and p.dtype == torch.float32 for p in (w1, b1, w2, b2)) and _ln.used_once(w1, b1, w2, b2))
         return y.view(x.shape)
 
     @staticmethod
@@ -121,11 +126,12 @@ class _FusedMlpFn(torch.autograd.Function):
             _lib.check(lib.vmasr_layer_norm_bwd_res(_p(x2), _p(dxn), _p(g32), _p(stats[0]), _p(stats[1]), _p(gy2), _p(dx),
                                                     None if later else _p(dg_), None if later else _p(db_), _p(ws), rows, d, _lib.torch_dtype_code(x2.dtype), _lib.BF16, _lib.current_stream(dev)),
                        "layer_norm_bwd_res")
-        # [dW1 | db1 | 0] = gpre^T xn_aug,  [dW2 | db2 | 0] = gys^T act_aug  (fp32 accumulation, split over the rows when few tiles)
-        g1 = weight_grad(gpre, xn_aug)
-        g2 = weight_grad(gys, act_aug)
-        return (dx.view(shape), dg_.to(gdt), db_.to(bedt), g1[:, :d].to(w1dt), g1[:, d].to(b1dt), g2[:, :hd].to(w2dt),
-                g2[:, hd].to(b2dt), None, None)
+        # [dW1 | db1 | 0] = gpre^T xn_aug,  [dW2 | db2 | 0] = gys^T act_aug  (fp32 accumulation, split over the rows when few tiles);
+        # the sum over the slabs and the split into contiguous dW / db: one launch for ALL queued GEMMs of the pass (wgrad.py)
+        fresh_w = ctx.fresh_w()
+        dw1, db1 = weight_grad_finished(gpre, xn_aug, d, ctx.wparams[0], ctx.wparams[1], fresh_w)
+        dw2, db2 = weight_grad_finished(gys, act_aug, hd, ctx.wparams[2], ctx.wparams[3], fresh_w)
+        return (dx.view(shape), dg_.to(gdt), db_.to(bedt), dw1.to(w1dt), db1.to(b1dt), dw2.to(w2dt), db2.to(b2dt), None, None)
 
 
 def fused_mlp_residual(x, norm, mlp, scale=None):

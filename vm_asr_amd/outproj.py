@@ -14,6 +14,8 @@ import os
 import torch
 
 from . import _lib
+from .wgrad import weight_grad_finished
+from . import layernorm as _ln
 from .linear import weight_grad
 from .mlp import _bf16, _bf16_t
 
@@ -62,6 +64,10 @@ class _OutProjFn(torch.autograd.Function):
         ctx.save_for_backward(g2, wb, sc)
         ctx.wt = _bf16_t(w, wb)
         ctx.meta = (g.shape, x.shape, x2.dtype, rps, w.dtype)
+        if ctx.needs_input_grad[1]:
+            _ln.note_use(w)
+        ctx.wparam = w
+        ctx.fresh_w = lambda: w.grad is None and w.dtype == torch.float32 and _ln.used_once(w)
         return y.view(x.shape)
 
     @staticmethod
@@ -82,7 +88,9 @@ class _OutProjFn(torch.autograd.Function):
             gys = torch.empty((rows, d), dtype=torch.bfloat16, device=dev)
             _lib.check(_lib.lib().vmasr_outproj_bwd(_p(gy2), _p(wt), _p(sc), rps, _p(dg), _p(gys), rows, d, _lib.torch_dtype_code(gy2.dtype),
                                                     _lib.current_stream(dev)), "outproj_bwd")
-        dw = weight_grad(gys, g2) if ctx.needs_input_grad[1] else None       # (d, 2d) fp32
+        dw = None
+        if ctx.needs_input_grad[1]:                                          # (d, 2d) fp32; finished with the pass' other weight gradients
+            dw, _ = weight_grad_finished(gys, g2, di, ctx.wparam, None, ctx.fresh_w())
         return dg.view(gshape), None if dw is None else dw.to(wdt), gy.to(xdt) if ctx.needs_input_grad[2] else None, None
 
 

@@ -12,7 +12,9 @@ import os
 import torch
 
 from . import _lib
+from . import layernorm as _ln
 from .linear import _mm_acc
+from .wgrad import finish_slabs
 
 __all__ = ["ss2d_deep", "supported"]
 
@@ -46,7 +48,7 @@ class _SS2DDeepFn(torch.autograd.Function):
         B, D, H, W = x.shape
         R, L = Wdt.shape[-1], H * W
         x = x.contiguous()
-        wx = Wx.detach().float().reshape(4, R + 2, D).transpose(1, 2).contiguous()       # (4, D, R + 2)
+        wx = _f32c(Wx, (4, R + 2, D))           # as stored (no copy for an fp32 parameter): the kernels index (k, c, d) directly
         wdt, b32 = _f32c(Wdt, (4, D, R)), _f32c(dtb, (4, D))
         al, ds = _f32c(A_logs, (4 * D,)), _f32c(Ds, (4 * D,))
         with torch.cuda.device(x.device):
@@ -57,6 +59,11 @@ class _SS2DDeepFn(torch.autograd.Function):
             _lib.check(_lib.lib().vmasr_ss2d_deep_fwd(ctypes.byref(p), _lib.current_stream(x.device)), "ss2d_deep_fwd")
         ctx.save_for_backward(x, xdbl, wx, wdt, b32, al, ds)
         ctx.meta = (Wx.dtype, Wx.shape, Wdt.dtype, Wdt.shape, dtb.dtype, dtb.shape, A_logs.dtype, A_logs.shape, Ds.dtype)
+        ps = (Wx, Wdt, dtb, A_logs, Ds)
+        if any(ctx.needs_input_grad[1:]):
+            _ln.note_use(*ps)
+        ctx.params = ps
+        ctx.fresh = lambda: all(p.grad is None and p.dtype == torch.float32 for p in ps[1:]) and _ln.used_once(*ps[1:])
         return y
 
     @staticmethod
@@ -73,7 +80,7 @@ class _SS2DDeepFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             du = torch.empty((B, D, L), dtype=torch.float32, device=x.device)
             terms = torch.empty((3, B, 4, D, L), dtype=x.dtype, device=x.device)
-            pg = torch.empty((B, 4, D, WR, 20), dtype=torch.float32, device=x.device)
+            pg = torch.empty((B * WR, 4 * D, 20), dtype=torch.float32, device=x.device)      # per-(b, wave) slabs of (4 D, kPG)
             dx = torch.empty_like(x)
             gpos = torch.empty((B, 4 * C, L), dtype=x.dtype, device=x.device)
             g32 = torch.empty((B, 4 * C, L), dtype=torch.float32, device=x.device)
@@ -82,10 +89,17 @@ class _SS2DDeepFn(torch.autograd.Function):
                                                                       _p(gpos), _p(g32))
             _lib.check(lib.vmasr_ss2d_deep_bwd(ctypes.byref(p), _lib.current_stream(x.device)), "ss2d_deep_bwd")
             # dW_x[kc][d] = sum_{b,p} gpos[b][kc][p] x[b][d][p]: (B, 4C, L) @ (B, L, D), fp32 accumulation, summed over the batch
-            dWx = _mm_acc(gpos, x.view(B, D, L).transpose(1, 2), torch.float32).sum(0)
-            s = pg[..., :R + 3].sum((0, 3))                                   # (4, D, R + 3)
-        return (dx, dWx.view(wxshape).to(wxdt), s[..., :R].reshape(wdtshape).to(wdtdt), s[..., R].reshape(dtbshape).to(dtbdt),
-                s[..., R + 1].reshape(alshape).to(aldt), s[..., R + 2].reshape(-1).to(dsdt))
+            px = _mm_acc(gpos, x.view(B, D, L).transpose(1, 2), torch.float32)          # (B, 4C, D): summed over the batch by the finish
+            dWx = torch.empty((4 * C, D), dtype=torch.float32, device=x.device)
+            Wx_ = ctx.params[0]
+            finish_slabs(px, D, (dWx,), (Wx_,), Wx_.grad is None and Wx_.dtype == torch.float32 and _ln.used_once(Wx_))
+            # the per-(b, wave) parameter sums -> dW_dt (4, D, R), d dt_bias (4, D), dA_log (4 D), dD (4 D): contiguous tensors,
+            # finished together with the pass' other parameter gradients in one launch (wgrad.py)
+            dWdt = torch.empty((4 * D, R), dtype=torch.float32, device=x.device)
+            ddtb, dal, dds = (torch.empty(4 * D, dtype=torch.float32, device=x.device) for _ in range(3))
+            finish_slabs(pg, R, (dWdt, ddtb, dal, dds), ctx.params[1:], ctx.fresh())
+        return (dx, dWx.view(wxshape).to(wxdt), dWdt.view(wdtshape).to(wdtdt), ddtb.view(dtbshape).to(dtbdt),
+                dal.view(alshape).to(aldt), dds.to(dsdt))
 
 
 def ss2d_deep(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
