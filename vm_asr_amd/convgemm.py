@@ -84,8 +84,10 @@ def conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, rows_in):
 
 
 def wgrad_splits(n, Cin, Cout, k, M):
-    """Split factor of the weight gradient's contraction (the M rows): enough 128 x 128 tiles x splits to fill 256 CUs twice."""
-    tiles = n * (Cout // 128) * (k * Cin // 128)
+    """Split factor of the weight gradient's contraction (the M rows): enough 128 x 128 output tiles x splits to fill the 256 CUs
+    (two workgroups each) a few times."""
+    T = 128
+    tiles = n * (Cout // T) * (k * Cin // T)
     s = 1
     while tiles * s < 768 and s < 16 and M // (2 * s) >= 1024:
         s *= 2

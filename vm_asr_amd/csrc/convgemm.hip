@@ -277,8 +277,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 constexpr int CW_BR = 32;                              // contraction rows per step
-constexpr int CW_TILE = CW_BR * 256;                   // 8 KB per operand tile
-constexpr int CW_STAGE = 4 * CW_TILE;                  // g_hi, g_lo, x_hi, x_lo
 
 struct CwProb {
     const bf16_t *gh, *gl, *xh, *xl;
@@ -291,21 +289,35 @@ struct CwParams {
     int nslots, splits, tiles_co, tiles_kc, Cin, Cout, k, stride, pad;
 };
 
-__device__ __forceinline__ int cw_off(const int row, const int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+// byte offset of 16-byte chunk `ch` of row `row` in an operand tile with ROWB-byte rows
+template <int ROWB>
+__device__ __forceinline__ int cw_off(const int row, const int ch) { return row * ROWB + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
 
+template <int ROWB>
 __device__ __forceinline__ bf16x8 cw_frag(const unsigned char *tile, const int ks, const int colbase, const int lane) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int ch = ((colbase + 16 * (g & 1)) >> 3) + (p >> 1);
     const int r0 = ks * 16 + 8 * (g >> 1) + q;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + cw_off(r0, ch) + 8 * (p & 1)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + cw_off(r0 + 4, ch) + 8 * (p & 1)));
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + cw_off<ROWB>(r0, ch) + 8 * (p & 1)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + cw_off<ROWB>(r0 + 4, ch) + 8 * (p & 1)));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void conv_mfma_wgrad_kernel(const CwParams P) {
+// BCO x BKC output tile (output channels x (tap, channel) columns of ONE tap), WM x WN waves of (BCO / WM) x (BKC / WN) each.
+// 128 x 128 / 4 waves: 64 KB LDS, two workgroups per CU; 256 x 256 / 8 waves: 128 KB, one per CU (half the staged bytes per MFMA).
+template <int BCO, int BKC, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const CwParams P) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int WTM = BCO / WM, WTN = BKC / WN, TI = WTM / 32, TJ = WTN / 32;
+    constexpr int RBG = BCO * 2, RBX = BKC * 2;                 // row bytes of the g / x tiles
+    constexpr int TILE_G = CW_BR * RBG, TILE_X = CW_BR * RBX;
+    constexpr int STAGE = 2 * TILE_G + 2 * TILE_X;              // g_hi, g_lo, x_hi, x_lo
+    constexpr int CG = BCO / 8, CX = BKC / 8;                   // 16-byte chunks per row
+    constexpr int PG = CW_BR * CG / NT, PX = CW_BR * CX / NT;   // staging passes (one chunk per thread and pass)
+    static_assert(PG >= 1 && PX >= 1 && (CW_BR * CG) % NT == 0 && (CW_BR * CX) % NT == 0, "staging geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
 
     const int per_slot = P.splits * P.tiles_co * P.tiles_kc;
     const int t = xcd_remap(blockIdx.x, P.nslots * per_slot);
@@ -316,66 +328,74 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wgrad_kernel(const CwParams 
     const int tco = rem / P.tiles_kc, tkc = rem - tco * P.tiles_kc;
     const CwProb &pr = P.prob[slot];
     const int Cin = P.Cin, Cout = P.Cout;
-    const int co0 = tco * 128, kc0 = tkc * 128;
+    const int co0 = tco * BCO, kc0 = tkc * BKC;
     const int tap = kc0 / Cin, c0 = kc0 - tap * Cin;
     const int mbeg = split * pr.mchunk, mend = min(pr.M, mbeg + pr.mchunk);
     const int nk = mend > mbeg ? (mend - mbeg + CW_BR - 1) / CW_BR : 0;
 
     // (register staging: an LDS-DMA version of this loop measured 20-25 % SLOWER, profiles/r04_convgemm_microbench_v1.log)
-    // staging: rows srow, srow + 16 of the step, 16-byte chunk `ch` of each
-    const int srow = tid >> 4, ch = tid & 15;
-    int m_cur[2], seq[2], q[2];
+    // pass p of the g tile: chunk (tid + p NT) -> row (tid + p NT) / CG, chunk % CG; likewise for x with CX
+    int g_row[PG], g_ch[PG], g_m[PG];
+    int x_row[PX], x_ch[PX], x_m[PX], x_seq[PX], x_q[PX];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        m_cur[i] = mbeg + srow + 16 * i;
-        seq[i] = m_cur[i] / pr.Q;
-        q[i] = m_cur[i] - seq[i] * pr.Q;
+    for (int i = 0; i < PG; ++i) {
+        const int idx = tid + i * NT;
+        g_row[i] = idx / CG; g_ch[i] = idx % CG;
+        g_m[i] = mbeg + g_row[i];
     }
-    u32x4 rg_h0, rg_h1, rg_l0, rg_l1, rx_h0, rx_h1, rx_l0, rx_l1;
-    bool g_ok0 = false, g_ok1 = false, x_ok0 = false, x_ok1 = false;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int idx = tid + i * NT;
+        x_row[i] = idx / CX; x_ch[i] = idx % CX;
+        x_m[i] = mbeg + x_row[i];
+        x_seq[i] = x_m[i] / pr.Q;
+        x_q[i] = x_m[i] - x_seq[i] * pr.Q;
+    }
+    u32x4 rg_h[PG], rg_l[PG], rx_h[PX], rx_l[PX];
+    bool g_ok[PG], x_ok[PX];
     const u32x4 z4 = {0u, 0u, 0u, 0u};
-#define CW_ADV(i)                                                     \
-    do {                                                              \
-        m_cur[i] += CW_BR; q[i] += CW_BR;                             \
-        while (q[i] >= pr.Q) { q[i] -= pr.Q; ++seq[i]; }              \
-    } while (0)
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
 #define CW_LOAD()                                                                                              \
     do {                                                                                                       \
-        const bool gk0_ = m_cur[0] < mend, gk1_ = m_cur[1] < mend;                                             \
-        const int p0_ = q[0] * P.stride + tap - P.pad, p1_ = q[1] * P.stride + tap - P.pad;                    \
-        const bool xk0_ = gk0_ && p0_ >= 0 && p0_ < pr.H, xk1_ = gk1_ && p1_ >= 0 && p1_ < pr.H;               \
-        const size_t go0_ = (size_t)(gk0_ ? m_cur[0] : 0) * Cout + co0 + ch * 8;                               \
-        const size_t go1_ = (size_t)(gk1_ ? m_cur[1] : 0) * Cout + co0 + ch * 8;                               \
-        const size_t xo0_ = (size_t)(xk0_ ? seq[0] * pr.H + p0_ : 0) * Cin + c0 + ch * 8;                      \
-        const size_t xo1_ = (size_t)(xk1_ ? seq[1] * pr.H + p1_ : 0) * Cin + c0 + ch * 8;                      \
-        rg_h0 = *reinterpret_cast<const u32x4 *>(pr.gh + go0_); rg_l0 = *reinterpret_cast<const u32x4 *>(pr.gl + go0_); \
-        rg_h1 = *reinterpret_cast<const u32x4 *>(pr.gh + go1_); rg_l1 = *reinterpret_cast<const u32x4 *>(pr.gl + go1_); \
-        rx_h0 = *reinterpret_cast<const u32x4 *>(pr.xh + xo0_); rx_l0 = *reinterpret_cast<const u32x4 *>(pr.xl + xo0_); \
-        rx_h1 = *reinterpret_cast<const u32x4 *>(pr.xh + xo1_); rx_l1 = *reinterpret_cast<const u32x4 *>(pr.xl + xo1_); \
-        g_ok0 = gk0_; g_ok1 = gk1_; x_ok0 = xk0_; x_ok1 = xk1_;                                                \
-        CW_ADV(0); CW_ADV(1);                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < PG; ++i) {                                                       \
+            g_ok[i] = g_m[i] < mend;                                                                           \
+            const size_t o_ = (size_t)(g_ok[i] ? g_m[i] : 0) * Cout + co0 + g_ch[i] * 8;                       \
+            rg_h[i] = *reinterpret_cast<const u32x4 *>(pr.gh + o_);                                            \
+            rg_l[i] = *reinterpret_cast<const u32x4 *>(pr.gl + o_);                                            \
+            g_m[i] += CW_BR;                                                                                   \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < PX; ++i) {                                                       \
+            const int p_ = x_q[i] * P.stride + tap - P.pad;                                                    \
+            x_ok[i] = x_m[i] < mend && p_ >= 0 && p_ < pr.H;                                                   \
+            const size_t o_ = (size_t)(x_ok[i] ? x_seq[i] * pr.H + p_ : 0) * Cin + c0 + x_ch[i] * 8;           \
+            rx_h[i] = *reinterpret_cast<const u32x4 *>(pr.xh + o_);                                            \
+            rx_l[i] = *reinterpret_cast<const u32x4 *>(pr.xl + o_);                                            \
+            x_m[i] += CW_BR; x_q[i] += CW_BR;                                                                  \
+            while (x_q[i] >= pr.Q) { x_q[i] -= pr.Q; ++x_seq[i]; }                                             \
+        }                                                                                                      \
     } while (0)
 #define CW_STORE(buf)                                                                                          \
     do {                                                                                                       \
-        unsigned char *s_ = smem + (buf) * CW_STAGE;                                                           \
-        const int o0_ = cw_off(srow, ch), o1_ = cw_off(srow + 16, ch);                                         \
-        *reinterpret_cast<u32x4 *>(s_ + o0_) = g_ok0 ? rg_h0 : z4;                                             \
-        *reinterpret_cast<u32x4 *>(s_ + o1_) = g_ok1 ? rg_h1 : z4;                                             \
-        *reinterpret_cast<u32x4 *>(s_ + CW_TILE + o0_) = g_ok0 ? rg_l0 : z4;                                   \
-        *reinterpret_cast<u32x4 *>(s_ + CW_TILE + o1_) = g_ok1 ? rg_l1 : z4;                                   \
-        *reinterpret_cast<u32x4 *>(s_ + 2 * CW_TILE + o0_) = x_ok0 ? rx_h0 : z4;                               \
-        *reinterpret_cast<u32x4 *>(s_ + 2 * CW_TILE + o1_) = x_ok1 ? rx_h1 : z4;                               \
-        *reinterpret_cast<u32x4 *>(s_ + 3 * CW_TILE + o0_) = x_ok0 ? rx_l0 : z4;                               \
-        *reinterpret_cast<u32x4 *>(s_ + 3 * CW_TILE + o1_) = x_ok1 ? rx_l1 : z4;                               \
+        unsigned char *s_ = smem + (buf) * STAGE;                                                              \
+        _Pragma("unroll") for (int i = 0; i < PG; ++i) {                                                       \
+            const int o_ = cw_off<RBG>(g_row[i], g_ch[i]);                                                     \
+            *reinterpret_cast<u32x4 *>(s_ + o_) = g_ok[i] ? rg_h[i] : z4;                                      \
+            *reinterpret_cast<u32x4 *>(s_ + TILE_G + o_) = g_ok[i] ? rg_l[i] : z4;                             \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < PX; ++i) {                                                       \
+            const int o_ = cw_off<RBX>(x_row[i], x_ch[i]);                                                     \
+            *reinterpret_cast<u32x4 *>(s_ + 2 * TILE_G + o_) = x_ok[i] ? rx_h[i] : z4;                         \
+            *reinterpret_cast<u32x4 *>(s_ + 2 * TILE_G + TILE_X + o_) = x_ok[i] ? rx_l[i] : z4;                \
+        }                                                                                                      \
     } while (0)
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (nk > 0) {
         CW_LOAD();
@@ -386,21 +406,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wgrad_kernel(const CwParams 
         const int buf = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) CW_LOAD();
-        const unsigned char *s = smem + buf * CW_STAGE;
+        const unsigned char *s = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            bf16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = cw_frag(s, ks, wm * 64 + i * 32, lane);
-                al[i] = cw_frag(s + CW_TILE, ks, wm * 64 + i * 32, lane);
-                bh[i] = cw_frag(s + 2 * CW_TILE, ks, wn * 64 + i * 32, lane);
-                bl[i] = cw_frag(s + 3 * CW_TILE, ks, wn * 64 + i * 32, lane);
+            for (int i = 0; i < TI; ++i) {
+                ah[i] = cw_frag<RBG>(s, ks, wm * WTM + i * 32, lane);
+                al[i] = cw_frag<RBG>(s + TILE_G, ks, wm * WTM + i * 32, lane);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TJ; ++j) {
+                bh[j] = cw_frag<RBX>(s + 2 * TILE_G, ks, wn * WTN + j * 32, lane);
+                bl[j] = cw_frag<RBX>(s + 2 * TILE_G + TILE_X, ks, wn * WTN + j * 32, lane);
+            }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
                     acc[i][j] = cg_mfma(al[i], bh[j], acc[i][j]);
                     acc[i][j] = cg_mfma(ah[i], bl[j], acc[i][j]);
                     acc[i][j] = cg_mfma(ah[i], bh[j], acc[i][j]);
@@ -409,20 +432,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wgrad_kernel(const CwParams 
         if (more) CW_STORE(buf ^ 1);
         __syncthreads();
     }
-#undef CW_ADV
 #undef CW_LOAD
 #undef CW_STORE
 
     const int KC = P.k * Cin;
     float *dw = pr.dw + (size_t)split * Cout * KC;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = kc0 + wn * 64 + j * 32 + lr;
+        for (int j = 0; j < TJ; ++j) {
+            const int col = kc0 + wn * WTN + j * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = co0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 dw[(size_t)row * KC + col] = acc[i][j][r];
             }
         }
@@ -556,7 +578,13 @@ VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, in
     VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride) && splits >= 1 && splits <= 64, VMASR_EINVAL,
                   "conv_mfma_wgrad: unsupported shape (Cin %d, Cout %d, k %d, stride %d, splits %d)", Cin, Cout, k, stride, splits);
     CwParams P = {};
-    P.nslots = n; P.splits = splits; P.tiles_co = Cout / 128; P.tiles_kc = k * Cin / 128;
+    static const int forced = [] { const char *e = getenv("VMASR_CONV_TILE"); return e ? atoi(e) : 0; }();
+    // 256 x 256 tiles measured NO faster than 128 x 128 for this kernel (1040 vs 1048 us on the 1024 -> 1024 layer, 558 vs 543 us
+    // on 512 -> 1024, profiles/r04_convgemm_microbench_v3.log: the transposed-read loop is not bound by the staged bytes) and need a
+    // split + sum pass to fill the chip: opt-in with VMASR_CONV_TILE=256
+    const bool big = Cout % 256 == 0 && Cin % 256 == 0 && forced == 256;
+    const int T = big ? 256 : 128;
+    P.nslots = n; P.splits = splits; P.tiles_co = Cout / T; P.tiles_kc = k * Cin / T;
     P.Cin = Cin; P.Cout = Cout; P.k = k; P.stride = stride; P.pad = pad;
     double bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -574,6 +602,16 @@ VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, in
     }
     const int tiles = n * splits * P.tiles_co * P.tiles_kc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, conv_mfma_wgrad_kernel, dim3(tiles), dim3(256), 2 * CW_STAGE, st, P);
+    if (big) {
+        constexpr size_t smem = 2 * 4 * CW_BR * 512;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_wgrad_kernel<256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr_done = true;
+        }
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<256, 256, 2, 4>), dim3(tiles), dim3(512), smem, st, P);
+    } else {
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 2 * 4 * CW_BR * 256, st, P);
+    }
     return check_launch("conv_mfma_wgrad");
 }

@@ -504,8 +504,14 @@ class PatchMerging2D(nn.Module):
         H, W, _ = x.shape[-3:]
         if (W % 2 != 0) or (H % 2 != 0):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
-        return torch.cat([x[..., 0::2, 0::2, :], x[..., 1::2, 0::2, :], x[..., 0::2, 1::2, :],
-                          x[..., 1::2, 1::2, :]], -1)
+        # cat([x[0::2, 0::2], x[1::2, 0::2], x[0::2, 1::2], x[1::2, 1::2]], -1) of the reference (model/vmamba.py:80-88) as ONE
+        # permuting copy: channel block j = 2 (w % 2) + (h % 2).  Same elements in the same order; forward 1 launch instead of 5,
+        # backward 1 instead of 4 zero fills + 4 strided copies + 3 adds (66 launches per generator step)
+        *lead, H, W, C = x.shape
+        y = x.reshape(*lead, H // 2, 2, W // 2, 2, C)
+        n = len(lead)
+        y = y.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4)       # (..., H/2, W/2, w%2, h%2, C)
+        return y.reshape(*lead, H // 2, W // 2, 4 * C)
 
     def forward(self, x):
         return self.reduction(self.norm(self._patch_merging_pad(x)))
