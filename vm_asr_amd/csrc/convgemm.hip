@@ -26,6 +26,7 @@
 // loads in flight during the current tile's MFMAs; one barrier per K step.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -34,6 +35,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void *cg_gptr;
 typedef __attribute__((address_space(3))) void *cg_lptr;
@@ -68,7 +70,11 @@ struct CgParams {
     int KB;                    // row length of B
 };
 
-__device__ __forceinline__ int cg_off(const int row, const int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// LDS byte offset of 16-byte chunk `chunk` of row `row` (64-byte rows).  The chunk index is XOR-ed with f(row >> 2), f(g) = (-g) & 3:
+// conflict-free for the ds_read_b128 lane groups of BOTH fragment shapes (32x32x16: 32 rows x one chunk per half wave; 16x16x32:
+// 16 rows x the four chunks, one per 16 lanes — the identity map f(g) = g is 2-way for the latter).
+__device__ __forceinline__ int cg_swz(const int row) { return (0 - (row >> 2)) & 3; }
+__device__ __forceinline__ int cg_off(const int row, const int chunk) { return row * 64 + ((chunk ^ cg_swz(row)) << 4); }
 
 __device__ __forceinline__ float cg_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
@@ -80,11 +86,12 @@ __device__ __forceinline__ f32x16 cg_mfma(const bf16x8 a, const bf16x8 b, const 
 // of 32 x 32.  128 x 128 / 4 waves: 64 KB of LDS, two workgroups per CU.  256 x 256 / 8 waves (128 x 64 per wave): 128 KB, one
 // workgroup per CU — half the global -> LDS bytes and 3/4 of the LDS fragment reads per MFMA, and a K step lasts twice as long
 // (48 MFMAs per wave), which is what covers the latency of the next tile's DMA; used whenever the output width allows.
-template <int BM, int BN, int WM, int WN, bool ACT>
+// MF: MFMA shape, 32 = v_mfma_f32_32x32x16_bf16 (two K sub-steps of 16 per stage), 16 = v_mfma_f32_16x16x32_bf16 (one of 32).
+template <int BM, int BN, int WM, int WN, bool ACT, int MF>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgParams P) {
     constexpr int NT = 64 * WM * WN;                   // threads
     constexpr int WTM = BM / WM, WTN = BN / WN;        // per-wave tile
-    constexpr int TI = WTM / 32, TJ = WTN / 32;
+    constexpr int TI = WTM / MF, TJ = WTN / MF;
     constexpr int TILE_A = BM * 64, TILE_B = BN * 64;  // bytes of one operand tile (rows of 32 bf16)
     constexpr int STAGE = 2 * TILE_A + 2 * TILE_B;     // A_hi, A_lo, B_hi, B_lo
     constexpr int RPP = NT / 4;                        // rows staged per pass (4 threads per 64-byte row)
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
     // that owns LDS unit (row, physical chunk c') fetches the row's LOGICAL chunk c' ^ ((row >> 2) & 3) — the swizzle lives on
     // the source address, the fragment reads apply the same XOR.  Per pass the workgroup fills RPP rows (wave w: rows 16w ..);
     // rows outside the data (padding taps, rows >= M) read a zero page instead (a DMA cannot be masked).
-    const int srow = tid >> 2, chunk = (tid & 3) ^ ((srow >> 2) & 3);
+    const int srow = tid >> 2, chunk = (tid & 3) ^ cg_swz(srow);
     int a_base[PA], a_hq[PA];
     bool a_ok[PA];
 #pragma unroll
@@ -167,13 +174,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
         }
     };
 
-    f32x16 acc[TI][TJ];
+    using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
+    constexpr int NR = MF == 32 ? 16 : 4;              // accumulator registers per tile
+    acc_t acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
 
     if (nk > 0) stage_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,29 +192,53 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
         const int buf = kt & 1;
         if (kt + 1 < nk) stage_tile(kt + 1, buf ^ 1);                  // lands during this tile's MFMAs (every wave left buf ^ 1 at the last barrier)
         const unsigned char *s = smem + buf * STAGE;
+        if constexpr (MF == 32) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int oa = cg_off(wm * WTM + i * 32 + lr, ks * 2 + lh);
-                ah[i] = *reinterpret_cast<const bf16x8 *>(s + oa);
-                al[i] = *reinterpret_cast<const bf16x8 *>(s + TILE_A + oa);
+                for (int i = 0; i < TI; ++i) {
+                    const int oa = cg_off(wm * WTM + i * 32 + lr, ks * 2 + lh);
+                    ah[i] = *reinterpret_cast<const bf16x8 *>(s + oa);
+                    al[i] = *reinterpret_cast<const bf16x8 *>(s + TILE_A + oa);
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int ob = cg_off(wn * WTN + j * 32 + lr, ks * 2 + lh);
+                    bh[j] = *reinterpret_cast<const bf16x8 *>(s + 2 * TILE_A + ob);
+                    bl[j] = *reinterpret_cast<const bf16x8 *>(s + 2 * TILE_A + TILE_B + ob);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        acc[i][j] = cg_mfma(al[i], bh[j], acc[i][j]);      // the two small products first, the large one last
+                        acc[i][j] = cg_mfma(ah[i], bl[j], acc[i][j]);
+                        acc[i][j] = cg_mfma(ah[i], bh[j], acc[i][j]);
+                    }
             }
+        } else {
+            // 16x16x32: lane l holds row (l & 15), k = 8 (l >> 4) .. + 7 of a 16-row operand tile: chunk l >> 4 of the row's 64 bytes
+            const int r16 = lane & 15, c16 = lane >> 4;
+            bf16x8 bh[TJ], bl[TJ];
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const int ob = cg_off(wn * WTN + j * 32 + lr, ks * 2 + lh);
+                const int ob = cg_off(wn * WTN + j * 16 + r16, c16);
                 bh[j] = *reinterpret_cast<const bf16x8 *>(s + 2 * TILE_A + ob);
                 bl[j] = *reinterpret_cast<const bf16x8 *>(s + 2 * TILE_A + TILE_B + ob);
             }
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+            for (int i = 0; i < TI; ++i) {
+                const int oa = cg_off(wm * WTM + i * 16 + r16, c16);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(s + oa);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(s + TILE_A + oa);
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
-                    acc[i][j] = cg_mfma(al[i], bh[j], acc[i][j]);      // the two small products first, the large one last
-                    acc[i][j] = cg_mfma(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = cg_mfma(ah[i], bh[j], acc[i][j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -231,8 +264,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        ct[((wm * WTM) % 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + lr] = acc[i][j][r];
+                    for (int r = 0; r < NR; ++r) {
+                        if constexpr (MF == 32)
+                            ct[((wm * WTM) % 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + lr] = acc[i][j][r];
+                        else      // 16 x 16 tile: element r of lane l is row 4 (l >> 4) + r, column l & 15
+                            ct[((wm * WTM) % 128 + i * 16 + 4 * (lane >> 4) + r) * BN + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r];
+                    }
         }
         __syncthreads();
 #pragma unroll 4
@@ -293,11 +330,13 @@ struct CwParams {
 template <int ROWB>
 __device__ __forceinline__ int cw_off(const int row, const int ch) { return row * ROWB + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
 
-template <int ROWB>
+// MF = 32: fragment of v_mfma_f32_32x32x16_bf16 for output index colbase + (lane & 31), contraction rows 16 ks + 8 (lane >> 5) ..;
+// MF = 16: fragment of v_mfma_f32_16x16x32_bf16 for output index colbase + (lane & 15), contraction rows 8 (lane >> 4) .. (all 32).
+template <int ROWB, int MF>
 __device__ __forceinline__ bf16x8 cw_frag(const unsigned char *tile, const int ks, const int colbase, const int lane) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int ch = ((colbase + 16 * (g & 1)) >> 3) + (p >> 1);
-    const int r0 = ks * 16 + 8 * (g >> 1) + q;
+    const int ch = (MF == 32 ? ((colbase + 16 * (g & 1)) >> 3) : (colbase >> 3)) + (p >> 1);
+    const int r0 = (MF == 32 ? ks * 16 + 8 * (g >> 1) : 8 * g) + q;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + cw_off<ROWB>(r0, ch) + 8 * (p & 1)));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + cw_off<ROWB>(r0 + 4, ch) + 8 * (p & 1)));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -305,10 +344,12 @@ __device__ __forceinline__ bf16x8 cw_frag(const unsigned char *tile, const int k
 
 // BCO x BKC output tile (output channels x (tap, channel) columns of ONE tap), WM x WN waves of (BCO / WM) x (BKC / WN) each.
 // 128 x 128 / 4 waves: 64 KB LDS, two workgroups per CU; 256 x 256 / 8 waves: 128 KB, one per CU (half the staged bytes per MFMA).
-template <int BCO, int BKC, int WM, int WN>
+template <int BCO, int BKC, int WM, int WN, int MF>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const CwParams P) {
     constexpr int NT = 64 * WM * WN;
-    constexpr int WTM = BCO / WM, WTN = BKC / WN, TI = WTM / 32, TJ = WTN / 32;
+    constexpr int WTM = BCO / WM, WTN = BKC / WN, TI = WTM / MF, TJ = WTN / MF;
+    using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
+    constexpr int NR = MF == 32 ? 16 : 4;
     constexpr int RBG = BCO * 2, RBX = BKC * 2;                 // row bytes of the g / x tiles
     constexpr int TILE_G = CW_BR * RBG, TILE_X = CW_BR * RBX;
     constexpr int STAGE = 2 * TILE_G + 2 * TILE_X;              // g_hi, g_lo, x_hi, x_lo
@@ -355,13 +396,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
     bool g_ok[PG], x_ok[PX];
     const u32x4 z4 = {0u, 0u, 0u, 0u};
 
-    f32x16 acc[TI][TJ];
+    acc_t acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
 
 #define CW_LOAD()                                                                                              \
     do {                                                                                                       \
@@ -407,27 +448,47 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
         const bool more = kt + 1 < nk;
         if (more) CW_LOAD();
         const unsigned char *s = smem + buf * STAGE;
+        if constexpr (MF == 32) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                ah[i] = cw_frag<RBG>(s, ks, wm * WTM + i * 32, lane);
-                al[i] = cw_frag<RBG>(s + TILE_G, ks, wm * WTM + i * 32, lane);
-            }
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                bh[j] = cw_frag<RBX>(s + 2 * TILE_G, ks, wn * WTN + j * 32, lane);
-                bl[j] = cw_frag<RBX>(s + 2 * TILE_G + TILE_X, ks, wn * WTN + j * 32, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i) {
+                    ah[i] = cw_frag<RBG, 32>(s, ks, wm * WTM + i * 32, lane);
+                    al[i] = cw_frag<RBG, 32>(s + TILE_G, ks, wm * WTM + i * 32, lane);
+                }
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
-                    acc[i][j] = cg_mfma(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = cg_mfma(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = cg_mfma(ah[i], bh[j], acc[i][j]);
+                    bh[j] = cw_frag<RBX, 32>(s + 2 * TILE_G, ks, wn * WTN + j * 32, lane);
+                    bl[j] = cw_frag<RBX, 32>(s + 2 * TILE_G + TILE_X, ks, wn * WTN + j * 32, lane);
                 }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        acc[i][j] = cg_mfma(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = cg_mfma(ah[i], bl[j], acc[i][j]);
+                        acc[i][j] = cg_mfma(ah[i], bh[j], acc[i][j]);
+                    }
+            }
+        } else {
+            bf16x8 bh[TJ], bl[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                bh[j] = cw_frag<RBX, 16>(s + 2 * TILE_G, 0, wn * WTN + j * 16, lane);
+                bl[j] = cw_frag<RBX, 16>(s + 2 * TILE_G + TILE_X, 0, wn * WTN + j * 16, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const bf16x8 ah = cw_frag<RBG, 16>(s, 0, wm * WTM + i * 16, lane);
+                const bf16x8 al = cw_frag<RBG, 16>(s + TILE_G, 0, wm * WTM + i * 16, lane);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
         }
         if (more) CW_STORE(buf ^ 1);
         __syncthreads();
@@ -441,10 +502,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            const int col = kc0 + wn * WTN + j * 32 + lr;
+            const int col = kc0 + wn * WTN + j * MF + (MF == 32 ? lr : (lane & 15));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = co0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int r = 0; r < NR; ++r) {
+                const int row = co0 + wm * WTM + i * MF + (MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : 4 * (lane >> 4) + r);
                 dw[(size_t)row * KC + col] = acc[i][j][r];
             }
         }
@@ -457,7 +518,7 @@ using namespace vmasr;
 
 namespace {
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MF>
 int cg_launch_cfg(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
     int tiles = 0;
     P.ntiles_n = P.NB / BN;
@@ -471,14 +532,14 @@ int cg_launch_cfg(CgParams &P, bool act, hipStream_t st, int kid, double bytes) 
     constexpr size_t smem = 2 * (2 * BM * 64 + 2 * BN * 64) + BM * sizeof(int);
     static bool attr_done = false;
     if (!attr_done && smem > 65536) {      // > 64 KB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, true, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, false, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     if (act) {
-        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, true>), dim3(tiles), dim3(64 * WM * WN), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, true, MF>), dim3(tiles), dim3(64 * WM * WN), smem, st, P);
     } else {
-        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, false>), dim3(tiles), dim3(64 * WM * WN), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, false, MF>), dim3(tiles), dim3(64 * WM * WN), smem, st, P);
     }
     return check_launch("conv_mfma");
 }
@@ -486,10 +547,14 @@ int cg_launch_cfg(CgParams &P, bool act, hipStream_t st, int kid, double bytes) 
 // 256 x 256 tiles when the output width allows and there are enough of them to fill the chip; VMASR_CONV_TILE=128 forces the small tile
 int cg_launch(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
     static const int forced = [] { const char *e = getenv("VMASR_CONV_TILE"); return e ? atoi(e) : 0; }();
+    // v_mfma_f32_16x16x32_bf16 by default: same cycles per FLOP as 32x32x16, but the chip holds a higher clock on it under load
+    // (MI355X_MICROARCH.md, DVFS give-back item 7): 5-9 % less time on the 512 -> 1024 and 1024 -> 1024 layers, forward and dgrad
+    // (profiles/r04_convgemm_microbench_v4.log); VMASR_CONV_MFMA=32 selects the 32x32x16 form
+    static const int mf = [] { const char *e = getenv("VMASR_CONV_MFMA"); return e ? atoi(e) : 16; }();
     bool big = P.NB % 256 == 0;
     if (forced == 128) big = false;
-    if (big) return cg_launch_cfg<256, 256, 2, 4>(P, act, st, kid, bytes);
-    return cg_launch_cfg<128, 128, 2, 2>(P, act, st, kid, bytes);
+    if (big) return mf == 16 ? cg_launch_cfg<256, 256, 2, 4, 16>(P, act, st, kid, bytes) : cg_launch_cfg<256, 256, 2, 4, 32>(P, act, st, kid, bytes);
+    return mf == 16 ? cg_launch_cfg<128, 128, 2, 2, 16>(P, act, st, kid, bytes) : cg_launch_cfg<128, 128, 2, 2, 32>(P, act, st, kid, bytes);
 }
 
 }  // namespace
@@ -579,6 +644,7 @@ VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, in
                   "conv_mfma_wgrad: unsupported shape (Cin %d, Cout %d, k %d, stride %d, splits %d)", Cin, Cout, k, stride, splits);
     CwParams P = {};
     static const int forced = [] { const char *e = getenv("VMASR_CONV_TILE"); return e ? atoi(e) : 0; }();
+    static const int mf = [] { const char *e = getenv("VMASR_CONV_MFMA"); return e ? atoi(e) : 16; }();
     // 256 x 256 tiles measured NO faster than 128 x 128 for this kernel (1040 vs 1048 us on the 1024 -> 1024 layer, 558 vs 543 us
     // on 512 -> 1024, profiles/r04_convgemm_microbench_v3.log: the transposed-read loop is not bound by the staged bytes) and need a
     // split + sum pass to fill the chip: opt-in with VMASR_CONV_TILE=256
@@ -606,12 +672,14 @@ VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, in
         constexpr size_t smem = 2 * 4 * CW_BR * 512;
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_wgrad_kernel<256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_wgrad_kernel<256, 256, 2, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             attr_done = true;
         }
-        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<256, 256, 2, 4>), dim3(tiles), dim3(512), smem, st, P);
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<256, 256, 2, 4, 16>), dim3(tiles), dim3(512), smem, st, P);
+    } else if (mf == 32) {
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2, 32>), dim3(tiles), dim3(256), 2 * 4 * CW_BR * 256, st, P);
     } else {
-        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 2 * 4 * CW_BR * 256, st, P);
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2, 16>), dim3(tiles), dim3(256), 2 * 4 * CW_BR * 256, st, P);
     }
     return check_launch("conv_mfma_wgrad");
 }
