@@ -316,6 +316,11 @@ int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, in
 int vmasr_wgrad_finish_multi(const float *const *parts, float *const *dws, float *const *dbs, float *const *e1s, float *const *e2s,
                              const int32_t *Ss, const int32_t *Ns, const int32_t *Ks, const int32_t *lds, int32_t n, vmasr_stream_t stream);
 
+/* y (rows, out) = x (rows, in) w^T (out, in) + bias, fp32 operands / result, the dot products accumulated in float64 and rounded once
+ * (csrc/linear.hip): the Linear layers of the fp32 parity path (nn.Linear of model/vmamba.py:855,881,498-500, model/model.py:57-116). */
+int vmasr_linear_f64acc(const float *x, const float *w, const float *bias, float *y, int64_t rows, int32_t out_features,
+                        int32_t in_features, vmasr_stream_t stream);
+
 /* AdamW step of many parameter tensors in one launch (torch.optim.AdamW semantics, utils/optimizer.py:16-50 of the
  * reference; non-amsgrad, decoupled weight decay, bias correction).  `items` is a DEVICE array, one entry per tensor;
  * `chunks` a DEVICE array of (item index, chunk index) int32 pairs, one per workgroup, chunk = vmasr_adamw_chunk() elements;

@@ -600,3 +600,31 @@ def test_layer_norm_deferred_queue_survives_an_aborted_backward():
         L.reset_uses()
     for a, b in zip(ref, got):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * a.abs().max().item())
+
+
+def test_linear_f64acc_is_correctly_rounded():
+    """csrc/linear.hip linear_f64acc: fp32 Linear of the parity path with float64 accumulation = the float64 result rounded once
+    (the family adds nothing to the forward's distance from the exact answer); backward through autograd against float64."""
+    from vm_asr_amd import linear as L
+    g = torch.Generator().manual_seed(2)
+    for rows, in_f, out_f in ((1000, 512, 300), (4096, 256, 128), (37, 16, 5), (64, 1024, 64)):
+        x = torch.randn(rows, in_f, generator=g).to(DEV).requires_grad_(True)
+        w = (torch.randn(out_f, in_f, generator=g) / in_f ** 0.5).to(DEV).requires_grad_(True)
+        b = torch.randn(out_f, generator=g).to(DEV).requires_grad_(True)
+        assert L._use_f64acc(x, w, b)
+        y = L.linear(x, w, b)
+        want64 = x.detach().double() @ w.detach().double().t() + b.detach().double()
+        want = want64.float()
+        ulp = torch.finfo(torch.float32).eps * want.abs().clamp(min=1e-30)
+        assert ((y.detach() - want).abs() <= ulp).all()
+        assert (y.detach() != want).float().mean().item() < 1e-3          # (double rounding can differ on near-ties only)
+        # torch's own fp32 GEMM for scale: noisier
+        e_hip = (y.detach().double() - want64).abs().max().item()
+        e_lt = (torch.nn.functional.linear(x.detach(), w.detach(), b.detach()).double() - want64).abs().max().item()
+        assert e_hip <= e_lt
+        gy = torch.randn(rows, out_f, generator=g).to(DEV)
+        y.backward(gy)
+        x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+        (x64 @ w64.t() + b64).backward(gy.double())
+        for got, ref in ((x.grad, x64.grad), (w.grad, w64.grad), (b.grad, b64.grad)):
+            assert (got.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()

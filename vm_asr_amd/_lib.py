@@ -136,6 +136,7 @@ SYMBOLS = {
     "vmasr_conv_mfma_dgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "vmasr_conv_mfma_wgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_wgrad_finish_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "vmasr_linear_f64acc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_ss2d_glue_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "vmasr_ss2d_pre_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_ss2d_pre_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -249,3 +249,79 @@ VMASR_EXPORT int vmasr_small_linear_bwd(const void *x, const float *w, const voi
     }
     return check_launch("small_linear_bwd");
 }
+
+// ---- fp32 Linear with float64 accumulation (the fp32 parity path) -----------------------------------------------------------
+// y[r][n] = sum_k x[r][k] W[n][k] + b[n], fp32 operands and result, the dot product accumulated in float64 and rounded ONCE.
+// Why: hipBLASLt's fp32 GEMMs accumulate K >= 256 in an order that leaves the result 1.4 - 1.7x further from the exact value than
+// torch's CPU fp32 evaluation of the same reference line (tools/linear_accuracy.py, profiles/r03_linear_accuracy.log), and the
+// Linear layers were the largest single-family term of the full-size forward's distance from float64.  With the
+// accumulation in float64 the family's error is the final rounding alone (<= 0.5 ulp), below any fp32 summation order — the
+// reference's included.  Used by vm_asr_amd/linear.py outside autocast only (model/vmamba.py:855,881,498-500, model/model.py:
+// 57-116); the bf16 benchmark path never reaches it.  64 x 64 output tile, K step 16, 4 x 4 outputs per thread.
+namespace vmasr {
+namespace {
+
+__global__ __launch_bounds__(256) void linear_f64acc_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ y, const long M, const int N,
+                                                            const int K) {
+    __shared__ float xs[16][68], ws[16][68];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const long m0 = (long)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;     // loader: row 0..63, 4 consecutive k
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + lk + e;
+            const long m = m0 + lr;
+            const int n = n0 + lr;
+            xs[lk + e][lr] = (m < M && k < K) ? x[m * K + k] : 0.f;
+            ws[lk + e][lr] = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = (double)xs[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = (double)ws[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n < N) y[m * N + n] = (float)(acc[i][j] + (bias ? (double)bias[n] : 0.0));
+        }
+    }
+}
+
+}  // namespace
+}  // namespace vmasr
+
+VMASR_EXPORT int vmasr_linear_f64acc(const float *x, const float *w, const float *bias, float *y, int64_t rows, int32_t out_features,
+                                     int32_t in_features, vmasr_stream_t stream) {
+    VMASR_REQUIRE(x && w && y, VMASR_EINVAL, "linear_f64acc: null tensor");
+    VMASR_REQUIRE(rows >= 0 && out_features > 0 && in_features > 0, VMASR_EINVAL, "linear_f64acc: bad sizes");
+    if (rows == 0) return 0;
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((out_features + 63) / 64));
+    VMASR_REQUIRE(grid.y <= 65535, VMASR_EINVAL, "linear_f64acc: out_features too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VMASR_LAUNCH(VMASR_K_SMALL_LINEAR_FWD, 4.0 * ((double)rows * (in_features + out_features) + (double)out_features * in_features),
+                 vmasr::linear_f64acc_kernel, grid, dim3(256), 0, st, x, w, bias, y, (long)rows, out_features, in_features);
+    return vmasr::check_launch("linear_f64acc");
+}

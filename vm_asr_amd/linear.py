@@ -10,6 +10,7 @@
 * everything else stays F.linear.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -169,6 +170,49 @@ class _LinearFn(torch.autograd.Function):
 _SplitKLinearFn = _LinearFn   # (tests)
 
 
+def _f64acc(x2, w, b):
+    """x2 (rows, in) @ w (out, in)^T + b with float64 accumulation (csrc/linear.hip), fp32 tensors."""
+    rows, out_f = x2.shape[0], w.shape[0]
+    with torch.cuda.device(x2.device):
+        y = torch.empty((rows, out_f), dtype=torch.float32, device=x2.device)
+        _lib.check(_lib.lib().vmasr_linear_f64acc(_p(x2), _p(w), _p(b), _p(y), rows, out_f, w.shape[1], _lib.current_stream(x2.device)),
+                   "linear_f64acc")
+    return y
+
+
+class _LinearF64AccFn(torch.autograd.Function):
+    """fp32 F.linear outside autocast (the parity path): forward and input gradient with float64 accumulation — the result is
+    the correctly rounded fp32 value, i.e. this family adds nothing to the distance from the exact answer (hipBLASLt's fp32
+    accumulation order at K >= 256 was 1.4-1.7x noisier than the reference's CPU evaluation: tools/linear_accuracy.py); the weight
+    gradient keeps the split-K fp32 GEMM (the gradient gates are met with it)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        out_f, in_f = weight.shape
+        x2 = x.reshape(-1, in_f).contiguous()
+        w = weight.detach().contiguous()
+        y = _f64acc(x2, w, None if bias is None else bias.detach().contiguous())
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (x.shape, bias is not None)
+        return y.view(*x.shape[:-1], out_f)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w = ctx.saved_tensors
+        shape, has_b = ctx.meta
+        gy2 = gy.reshape(x2.shape[0], w.shape[0]).float().contiguous()
+        dx = _f64acc(gy2, w.t().contiguous(), None).view(shape) if ctx.needs_input_grad[0] else None
+        dw = weight_grad(gy2, x2) if ctx.needs_input_grad[1] else None
+        db = gy2.sum(0) if has_b and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def _use_f64acc(x, weight, bias):
+    return (os.environ.get("VMASR_LINEAR_F64ACC", "1") == "1" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and (bias is None or bias.dtype == torch.float32) and not torch.is_autocast_enabled("cuda") and weight.dim() == 2
+            and weight.shape[1] >= 16)
+
+
 def linear(x, weight, bias=None, shadow_of=None, bias_shadow_of=None):
     """F.linear for this path.  Tiny in/out features over many GPU rows go to the HIP row-map kernel; under
     autocast, or for many rows with a small weight, the GEMM path goes through _LinearFn.  `shadow_of`:
@@ -179,6 +223,8 @@ def linear(x, weight, bias=None, shadow_of=None, bias_shadow_of=None):
         out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
         if out_dtype == x.dtype or x.dtype == torch.float32:
             return _SmallLinearFn.apply(x, weight, bias, out_dtype)
+    if _use_f64acc(x, weight, bias):
+        return _LinearF64AccFn.apply(x, weight, bias)
     if x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and x.is_floating_point():
         amp = torch.is_autocast_enabled("cuda")
         rows = x.numel() // max(1, in_f)
