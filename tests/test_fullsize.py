@@ -84,7 +84,7 @@ def test_fullsize_forward_hip(tag, hop):
     reference architecture (quirk: output_version v3 ends in a 1-channel VSS block), not of an implementation:
     two correct fp32 evaluations differ there by a few 1e-4 of the peak (each sits 1.5e-4 .. 2.6e-4 from the float64
     answer, test_fullsize_forward_hip_fp64_adjudicated).  Bounds after it: 2e-3 (max) and 1e-4 (RMS) of the output
-    peak, LSD within 1e-3."""
+    peak, LSD within 1e-4."""
     import oracle
     from oracle.torch_backend import oracle_stft_patch, use_oracle
     z = np.load(os.path.join(GOLDEN, "fullsize.npz"))
@@ -108,7 +108,8 @@ def test_fullsize_forward_hip(tag, hop):
         assert d.max() <= 2e-3 * scale, (tag, what, d.max(), scale)
         assert np.sqrt((d.astype(np.float64) ** 2).mean()) <= 1e-4 * scale, (tag, what)
     lsd = oracle.lsd(y_gpu.numpy()[:, 0], z[f"{tag}_target"][:, 0])
-    assert abs(lsd - float(z[f"{tag}_lsd"])) < 1e-3, (lsd, float(z[f"{tag}_lsd"]))
+    print(f"[{tag}] hip fp32 LSD {lsd:.6f} vs the reference's {float(z[f'{tag}_lsd']):.6f}: delta {abs(lsd - float(z[f'{tag}_lsd'])):.1e}")
+    assert abs(lsd - float(z[f"{tag}_lsd"])) < 1e-4, (lsd, float(z[f"{tag}_lsd"]))      # LSD parity 1e-4
 
 
 # ---- float64-adjudicated accuracy, dims-32 and n_fft-2048 configurations ---------------------------------------
@@ -154,7 +155,10 @@ def test_fullsize_forward_cpu_oracle_fp64_adjudicated(tag):
 # sequential fp32 evaluations and cover that spread; the claim "as accurate as the reference's fp32 arithmetic" is the
 # DISTRIBUTION test (test_fullsize_forward_hip_error_distribution: geometric mean of the ratio over 8 clips), and
 # per operator tests/test_ss2d_fused.py (x1.5 of the sequential recurrence's distance from float64, benchmark shapes).
-K_MAX, K_RMS = 3.0, 2.0
+K_MAX, K_RMS = 2.0, 1.5     # round 4: the fp32 Linear layers accumulate in float64 now (csrc/linear.hip) — measured on the golden
+                            # clips: HIP 0.33 .. 0.86x the noisier sequential-fp32 evaluation (worst sample), 0.38 .. 0.66x (RMS)
+LSD_TOL = 2e-5              # BASELINE.md §3 asks 1e-4; measured 1e-7 .. 5.5e-6 (the reference's own fp32 run sits 0 .. 3.7e-6 from the
+                            # float64 LSD): gated at 4x the worst measured value, five times tighter than the contract
 
 
 def _adjudicate(tag, who, y, y32, y64, target, lsd_ref, y_cpu=None):
@@ -176,7 +180,10 @@ def _adjudicate(tag, who, y, y32, y64, target, lsd_ref, y_cpu=None):
     assert e.max() <= K_MAX * ref_max, (tag, who, e.max(), ref_max)
     assert _rms(e) <= K_RMS * ref_rms, (tag, who, _rms(e), ref_rms)
     lsd = oracle.lsd(y[:, 0], target.numpy()[:, 0])
-    assert abs(lsd - lsd_ref) < 1e-3, (tag, who, lsd, lsd_ref)
+    lsd64 = oracle.lsd(y64.astype(np.float32)[:, 0], target.numpy()[:, 0])
+    print(f"[{tag}] {who}: LSD {lsd:.6f}  reference fp32 {lsd_ref:.6f} (delta {abs(lsd - lsd_ref):.1e})  float64 {lsd64:.6f} "
+          f"(delta {abs(lsd - lsd64):.1e}; reference fp32 vs float64 {abs(lsd_ref - lsd64):.1e})")
+    assert abs(lsd - lsd_ref) < LSD_TOL, (tag, who, lsd, lsd_ref)
 
 
 @pytest.mark.gpu
@@ -205,7 +212,9 @@ def test_f64ref_equals_float64_reference(tag):
     assert y.dtype == np.float64 and np.abs(y - y64).max() <= 1e-9 * np.abs(y64).max()
 
 
-N_CLIPS, GM_RMS, GM_MAX = int(os.environ.get("VMASR_TEST_CLIPS", "16")), 1.6, 1.9
+# round 4: measured 0.50 / 0.58 / 0.55 / 0.67 (RMS) and 0.47 / 0.53 / 0.56 / 0.68 (worst sample) over 16 clips (profiles/r04_gpu_parity.log):
+# the HIP fp32 forward is CLOSER to float64 than the sequential fp32 evaluation since its Linear layers accumulate in float64
+N_CLIPS, GM_RMS, GM_MAX = int(os.environ.get("VMASR_TEST_CLIPS", "16")), 1.0, 1.0
 
 
 @pytest.mark.gpu
@@ -342,11 +351,11 @@ def test_fullsize_backward_hip_fp64_adjudicated():
     worst = sorted(ratio, key=ratio.get)[-3:]
     print(f"full-size backward vs float64: whole-vector rel L2  hip {t_hip:.2e}  cpu-oracle fp32 {t_cpu:.2e}; worst per-tensor "
           f"ratios " + ", ".join(f"{n} {ratio[n]:.2f}" for n in worst))
-    assert t_hip <= 2.0 * t_cpu, (t_hip, t_cpu)
+    assert t_hip <= 1.0 * t_cpu, (t_hip, t_cpu)          # round 4: measured 0.51x (was 1.39x)
     p95 = float(np.percentile(list(ratio.values()), 95))
     print(f"per-tensor ratio: median {float(np.median(list(ratio.values()))):.2f}, 95th percentile {p95:.2f}, max {ratio[worst[-1]]:.2f}")
-    assert p95 <= 3.0, p95
-    assert ratio[worst[-1]] <= 10.0, (worst[-1], ratio[worst[-1]], e_hip[worst[-1]], e_cpu[worst[-1]])
+    assert p95 <= 1.5, p95                               # measured 0.75
+    assert ratio[worst[-1]] <= 3.0, (worst[-1], ratio[worst[-1]], e_hip[worst[-1]], e_cpu[worst[-1]])   # measured 1.24
 
 
 @pytest.mark.gpu
@@ -383,8 +392,8 @@ def test_fullsize_backward_dims32_hip_fp64_adjudicated():
     ratio = sorted(e_hip[n] / (e_cpu[n] + floor) for n in names)
     print(f"[d32] full-size backward vs float64: whole-vector rel L2  hip {t_hip:.2e}  cpu-oracle fp32 {t_cpu:.2e}; per-tensor ratio "
           f"median {ratio[len(ratio) // 2]:.2f}, 95th percentile {ratio[int(0.95 * len(ratio))]:.2f}, max {ratio[-1]:.2f}")
-    assert t_hip <= 2.0 * t_cpu, (t_hip, t_cpu)
-    assert ratio[int(0.95 * len(ratio))] <= 3.0 and ratio[-1] <= 10.0, (ratio[int(0.95 * len(ratio))], ratio[-1])
+    assert t_hip <= 1.0 * t_cpu, (t_hip, t_cpu)          # round 4: measured 0.57x
+    assert ratio[int(0.95 * len(ratio))] <= 1.5 and ratio[-1] <= 3.0, (ratio[int(0.95 * len(ratio))], ratio[-1])     # measured 0.67, 0.95
 
 
 @pytest.mark.gpu
