@@ -10,6 +10,7 @@ for r in rows:
 fam = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for (did, name), c in per.items():
     k = ("hipblaslt/tensile GEMM (Cijk_*)" if name.startswith("Cijk") else
+         "vmasr conv_mfma kernels (discriminator implicit GEMMs)" if ("vmasr" in name and "conv_mfma" in name) else
          "vmasr MFMA kernels (mlp_fwd / mlp_bwd)" if ("vmasr" in name and "mlp_" in name) else
          "vmasr library kernels (no MFMA)" if "vmasr" in name else "ATen / other")
     f = fam[k]
@@ -23,10 +24,10 @@ out = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over `p
                                     "gui_active_cycles_per_xcd": c.get("GRBM_GUI_ACTIVE", 0) / 8} for n, c in top]}
 own = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for (did, name), c in per.items():
-    if "vmasr" in name and "mlp_" in name:
+    if "vmasr" in name and ("mlp_" in name or "conv_mfma" in name):
         import re
         m = re.search(r"(mlp_(?:fwd|bwd)_kernel)<?(?:ILi)?(\d+)", name)
-        key = f"{m.group(1)} d={m.group(2)}" if m else name[:60]
+        key = f"{m.group(1)} d={m.group(2)}" if m else ("conv_mfma_wgrad" if "wgrad" in name else "conv_mfma_nt (fwd / dgrad)") if "conv_mfma" in name else name[:60]
         o = own[key]
         o[0] += 1; o[1] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0); o[2] += c.get("GRBM_GUI_ACTIVE", 0.0)
 out["vmasr_mfma_kernels"] = {k: {"dispatches": v[0], "mfma_util": (v[1] / (v[2] / 8 * 1024)) if v[2] else 0.0,
