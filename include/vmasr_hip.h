@@ -628,6 +628,10 @@ enum {
     VMASR_K_WGRAD_FINISH,       /* sum over split-K slabs + bias column split-off of many weight gradients, one launch (csrc/wgrad.hip) */
     VMASR_K_COUNT
 };
+/* Deterministic-reduction switch (debug aid, off by default; the Python side turns it on for VMASR_DETERMINISTIC=1): the kernels whose
+ * parameter-gradient sums end in fp32 atomics take those atomics in workgroup order (csrc/common.h) -> bit-reproducible results, slower. */
+void vmasr_set_deterministic(int on);
+int vmasr_get_deterministic(void);
 void vmasr_prof_enable(int on);
 void vmasr_prof_reset(void);
 const char *vmasr_prof_name(int kernel_id);

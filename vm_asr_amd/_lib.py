@@ -155,6 +155,8 @@ SYMBOLS = {
     "vmasr_ss2d_deep_waves_per_row": (c_i32, [c_i32, c_i32]),
     "vmasr_ss2d_deep_fwd": (ctypes.c_int, [ctypes.POINTER(SS2DDeepParams), c_vp]),
     "vmasr_ss2d_deep_bwd": (ctypes.c_int, [ctypes.POINTER(SS2DDeepParams), c_vp]),
+    "vmasr_set_deterministic": (None, [ctypes.c_int]),
+    "vmasr_get_deterministic": (ctypes.c_int, []),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -195,6 +197,8 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if l.vmasr_abi_version() != 1:
             raise RuntimeError("libvmasr_hip.so ABI version mismatch")
+        if os.environ.get("VMASR_DETERMINISTIC", "0") == "1":
+            l.vmasr_set_deterministic(1)
         _lib = l
     return _lib
 

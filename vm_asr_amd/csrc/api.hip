@@ -42,6 +42,20 @@ const char *kNames[VMASR_K_COUNT] = {
 }  // namespace
 
 bool g_prof_on = false;
+static bool g_det_on = false;
+static unsigned *g_det_buf = nullptr;
+
+unsigned *det_ticket(int kid) {
+    if (!g_det_on || kid < 0 || kid >= VMASR_K_COUNT) return nullptr;
+    if (g_det_buf == nullptr) {      // one zeroed word per kernel id, allocated on first use (deterministic mode only)
+        if (hipMalloc(reinterpret_cast<void **>(&g_det_buf), VMASR_K_COUNT * sizeof(unsigned)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_det_buf, 0, VMASR_K_COUNT * sizeof(unsigned));
+        (void)hipDeviceSynchronize();
+    }
+    return g_det_buf + kid;
+}
+void det_set(bool on) { g_det_on = on; }
+bool det_get() { return g_det_on; }
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -71,6 +85,9 @@ VMASR_EXPORT int vmasr_abi_version(void) { return VMASR_ABI_VERSION; }
 VMASR_EXPORT const char *vmasr_last_error(void) { return g_err; }
 
 VMASR_EXPORT void vmasr_prof_enable(int on) { g_prof_on = on != 0; }
+
+VMASR_EXPORT void vmasr_set_deterministic(int on) { vmasr::det_set(on != 0); }
+VMASR_EXPORT int vmasr_get_deterministic(void) { return vmasr::det_get() ? 1 : 0; }
 
 VMASR_EXPORT void vmasr_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -217,4 +217,48 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// ---- deterministic-reduction switch (SURVEY.md §5 debug aid; VMASR_DETERMINISTIC=1 / vmasr_set_deterministic) -----------------------
+// The parameter-gradient sums of several kernels end in fp32 atomics (as the reference's backward does: cus/selective_scan_bwd_kernel.cuh:
+// 218-219,262-271), so two runs differ at rounding level.  In deterministic mode the workgroups of such a launch take their closing
+// atomics IN WORKGROUP ORDER: a ticket word per kernel id (api.hip: det_ticket) counts the workgroups that are done; workgroup k
+// waits for ticket == k, performs its atomics (they execute at the memory side; `s_waitcnt vmcnt(0)` = performed), then passes the
+// turn on; the last one resets the ticket.  The float additions to every address then happen in a fixed order -> bit-reproducible
+// results.  Slow by design (the tails serialise, ~1 us per workgroup): a debug aid, off by default (ticket == nullptr: plain atomics).
+// Safe: workgroups are dispatched in linear order, so every workgroup waits only for ones dispatched before it; the wait is bounded.
+unsigned *det_ticket(int kernel_id);          // nullptr unless deterministic mode is on (host side, api.hip)
+void det_set(bool on);
+bool det_get();
+
+__device__ __forceinline__ unsigned det_me() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+// every thread of the workgroup calls both; between them the workgroup issues its global atomics
+__device__ __forceinline__ void det_enter(unsigned *ticket) {
+    if (ticket == nullptr) return;
+    if (threadIdx.x == 0) {
+        const unsigned me = det_me();
+        unsigned spins = 0;
+        while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != me && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void det_leave(unsigned *ticket) {
+    if (ticket == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned me = det_me(), total = gridDim.x * gridDim.y * gridDim.z;
+        __hip_atomic_store(ticket, me + 1 == total ? 0u : me + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// LDS float atomics of the waves of a workgroup in wave order (deterministic mode): `body` does the wave's ds_add's
+#define VMASR_DET_WAVE_ORDER(ticket, nwaves, ...)                                   \
+    do {                                                                            \
+        if ((ticket) == nullptr) { __VA_ARGS__; }                                   \
+        else {                                                                      \
+            for (int w_ = 0; w_ < (nwaves); ++w_) {                                 \
+                if ((int)(threadIdx.x >> 6) == w_) { __VA_ARGS__; }                 \
+                __syncthreads();                                                    \
+            }                                                                       \
+        }                                                                           \
+    } while (0)
+
 }  // namespace vmasr

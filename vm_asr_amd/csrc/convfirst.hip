@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const CfSlots t, co
 // grid (blocks, n).  dcols (n, rows, 5) / dw (n, 32, 5) / db (n, 32) may be NULL; dw, db are accumulated (zero-initialised).
 __global__ __launch_bounds__(256) void conv_first_bwd_kernel(const CfSlots t, const float *__restrict__ w, const float *__restrict__ pre,
                                                              const float *__restrict__ g, float *__restrict__ dcols, float *__restrict__ dw,
-                                                             float *__restrict__ db, const long rows) {
+                                                             float *__restrict__ db, const long rows, unsigned *det) {
     const int s = blockIdx.y, cg = threadIdx.x & 7, lane = threadIdx.x & 63;
     float wv[4][kCfK], aw[4][kCfK], ab[4];
 #pragma unroll
@@ -146,12 +146,14 @@ __global__ __launch_bounds__(256) void conv_first_bwd_kernel(const CfSlots t, co
             for (int e = 0; e < 24; ++e) fold[threadIdx.x >> 6][lane][e] = vals[e];
         }
         __syncthreads();
+        det_enter(det);
         if (threadIdx.x < 8 * 24) {
             const int g8 = threadIdx.x / 24, e = threadIdx.x % 24;
             const float v = (fold[0][g8][e] + fold[1][g8][e]) + (fold[2][g8][e] + fold[3][g8][e]);
             if (e < 20) { if (dw) atomicAdd(dw + ((size_t)s * kCfN + g8 * 4 + e / kCfK) * kCfK + e % kCfK, v); }
             else if (db) atomicAdd(db + s * kCfN + g8 * 4 + (e - 20), v);
         }
+        det_leave(det);
     }
 }
 
@@ -200,6 +202,6 @@ VMASR_EXPORT int vmasr_conv_first_bwd(const void *const *xs, const int64_t *Ns, 
 #endif
     const int blocks = (int)std::min<long>((rows + 31) / 32, VMASR_CF_BWD_BLOCKS);
     VMASR_LAUNCH(VMASR_K_CONV_POST, 8.0 * n * (double)rows * kCfN, conv_first_bwd_kernel, dim3(blocks, n), dim3(256), 0,
-                 static_cast<hipStream_t>(stream), t, w, pre, g, dcols, dw, db, (long)rows);
+                 static_cast<hipStream_t>(stream), t, w, pre, g, dcols, dw, db, (long)rows, det_ticket(VMASR_K_CONV_POST));
     return check_launch("conv_first_bwd");
 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_post_fwd_kernel(const float *__restr
 template <int VPL>
 __global__ __launch_bounds__(256) void conv_post_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ gy,
                                                             float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db,
-                                                            const CpSlots t, const long rows, const int run) {
+                                                            const CpSlots t, const long rows, const int run, unsigned *det) {
     constexpr int C = VPL * 256;
     const int s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long r0 = ((long)blockIdx.x * 4 + wave) * run;
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void conv_post_bwd_kernel(const float *__restr
         }
     }
     // fold the block's four waves in LDS, then one atomic per weight and workgroup
+    det_enter(det);                      // deterministic mode: the workgroups' atomics in workgroup order (common.h)
     if (dw) {
         __shared__ float4 fold[4][3 * VPL][64];
 #pragma unroll
@@ -150,7 +151,15 @@ __global__ __launch_bounds__(256) void conv_post_bwd_kernel(const float *__restr
             }
         }
     }
-    if (db && lane == 0 && bsum != 0.f) atomicAdd(db + s, bsum);   // gy is wave-uniform: every lane holds the run's sum
+    if (det == nullptr) {
+        if (db && lane == 0 && bsum != 0.f) atomicAdd(db + s, bsum);   // gy is wave-uniform: every lane holds the run's sum
+    } else if (db) {                     // deterministic mode: the four waves' sums in a fixed order, one atomic per workgroup
+        __shared__ float bs[4];
+        if (lane == 0) bs[wave] = bsum;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(db + s, (bs[0] + bs[1]) + (bs[2] + bs[3]));
+    }
+    det_leave(det);
 }
 
 int cp_check(const int64_t *Ms, const int32_t *Hs, int n, int64_t rows, int C, int k, CpSlots &t, const char *what) {
@@ -204,10 +213,10 @@ VMASR_EXPORT int vmasr_conv_post_bwd(const float *x, const float *w, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double bytes = (double)n * rows * ((dw ? C : 0) + (dx ? C : 0) + 1.0) * 4.0;
     switch (C / 256) {
-        case 1: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<1>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run); break;
-        case 2: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<2>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run); break;
-        case 3: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<3>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run); break;
-        default: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<4>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run); break;
+        case 1: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<1>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run, det_ticket(VMASR_K_CONV_POST)); break;
+        case 2: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<2>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run, det_ticket(VMASR_K_CONV_POST)); break;
+        case 3: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<3>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run, det_ticket(VMASR_K_CONV_POST)); break;
+        default: VMASR_LAUNCH(VMASR_K_CONV_POST, bytes, conv_post_bwd_kernel<4>, grid, dim3(256), 0, st, x, w, gy, dx, dw, db, t, (long)rows, run, det_ticket(VMASR_K_CONV_POST)); break;
     }
     return check_launch("conv_post_bwd");
 }

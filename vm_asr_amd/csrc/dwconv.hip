@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_a_kernel(const T *__restr
                                                                 const float *__restrict__ bias,
                                                                 const T *__restrict__ gy, float *__restrict__ gp,
                                                                 float *__restrict__ dw, float *__restrict__ db,
-                                                                const int C, const int H, const int W, const int chunk) {
+                                                                const int C, const int H, const int W, const int chunk, unsigned *det) {
     __shared__ float s_part[4][10];
     const int c = blockIdx.y, b = blockIdx.z;
     const int HW = H * W;
@@ -97,11 +97,13 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_a_kernel(const T *__restr
         if (lane == 0) s_part[wave][k] = s;
     }
     __syncthreads();
+    det_enter(det);                          // deterministic mode: the workgroups' atomics in workgroup order (common.h)
     if (threadIdx.x < 10) {
         const float s = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
         if (threadIdx.x < 9) atomicAdd(dw + c * 9 + threadIdx.x, s);
         else if (db) atomicAdd(db + c, s);
     }
+    det_leave(det);
 }
 
 template <typename T>
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_vec_kernel(const T *__restric
                                                               const float *__restrict__ bias, const T *__restrict__ gy,
                                                               T *__restrict__ y, float *__restrict__ gp,
                                                               float *__restrict__ dw, float *__restrict__ db,
-                                                              const int C, const int H, const int W, const int chunk) {
+                                                              const int C, const int H, const int W, const int chunk, unsigned *det) {
     __shared__ float s_part[4][10];
     const int c = blockIdx.y, b = blockIdx.z;
     const int HW = H * W;
@@ -206,11 +208,13 @@ __global__ __launch_bounds__(256) void dwconv_silu_vec_kernel(const T *__restric
             if (lane == 0) s_part[wave][k] = sres;
         }
         __syncthreads();
+        det_enter(det);
         if (threadIdx.x < 10) {
             const float sres = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
             if (threadIdx.x < 9) atomicAdd(dw + c * 9 + threadIdx.x, sres);
             else if (db) atomicAdd(db + c, sres);
         }
+        det_leave(det);
     }
 }
 
@@ -275,7 +279,7 @@ VMASR_EXPORT int vmasr_dwconv_silu_fwd(const void *x, const float *w, const floa
     do {                                                                                                             \
         if (vec) VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, (dwconv_silu_vec_kernel<TT, 0>), grid, dim3(256), 0, st,     \
                               (const TT *)x, w, bias, (const TT *)nullptr, (TT *)y, (float *)nullptr, (float *)nullptr, \
-                              (float *)nullptr, C, H, W, chunk);                                                     \
+                              (float *)nullptr, C, H, W, chunk, (unsigned *)nullptr);                                                     \
         else VMASR_LAUNCH(VMASR_K_DWCONV_FWD, bytes, dwconv_silu_fwd_kernel<TT>, grid, dim3(256), 0, st, (const TT *)x, w, \
                           bias, (TT *)y, C, H, W, chunk);                                                            \
     } while (0)
@@ -302,16 +306,17 @@ VMASR_EXPORT int vmasr_dwconv_silu_bwd(const void *x, const float *w, const floa
     const double bytes_a = n * (2 * es + 4), bytes_b = n * (4 + es);  // a: read x, gy, write gp;  b: read gp, write dx
     const size_t al = dtype == VMASR_F32 ? 16 : 8;
     const bool vec = W % 4 == 0 && aligned_to(x, al) && aligned_to(gy, al) && aligned_to(dx, al) && aligned_to(ws, 16);
+    unsigned *det = det_ticket(VMASR_K_DWCONV_BWD_A);
 #define VMASR_DW_BWD(TT)                                                                                              \
     do {                                                                                                              \
         if (vec) {                                                                                                    \
             VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, (dwconv_silu_vec_kernel<TT, 1>), grid_a, dim3(256), 0, st,      \
-                         (const TT *)x, w, bias, (const TT *)gy, (TT *)nullptr, ws, dw, db, C, H, W, chunk_a);          \
+                         (const TT *)x, w, bias, (const TT *)gy, (TT *)nullptr, ws, dw, db, C, H, W, chunk_a, det); \
             VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_vec_kernel<TT>, grid, dim3(256), 0, st, ws, w, \
                          (TT *)dx, C, H, W, chunk);                                                                   \
         } else {                                                                                                      \
             VMASR_LAUNCH(VMASR_K_DWCONV_BWD_A, bytes_a, dwconv_silu_bwd_a_kernel<TT>, grid_a, dim3(256), 0, st, (const TT *)x, \
-                         w, bias, (const TT *)gy, ws, dw, db, C, H, W, chunk_a);                                      \
+                         w, bias, (const TT *)gy, ws, dw, db, C, H, W, chunk_a, det);                                 \
             VMASR_LAUNCH(VMASR_K_DWCONV_BWD_B, bytes_b, dwconv_silu_bwd_b_kernel<TT>, grid, dim3(256), 0, st, ws, w,    \
                          (TT *)dx, C, H, W, chunk);                                                                   \
         }                                                                                                             \

@@ -58,6 +58,7 @@ struct MlpArgs {
     bf16_t *act_aug;                // (rows, 4D + 8): GELU(h) | 1 0 ...
     bf16_t *gpre;                   // (rows, 4D)
     float *mean, *rstd;             // (rows)
+    unsigned *det = nullptr;        // deterministic mode (common.h): the hidden-split waves add their partial tiles to LDS in wave order
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(HS > 4 ? 64 * HS : 256) void mlp_fwd_kernel(const M
         }
         const float sc = a.scale ? a.scale[ok ? row / a.rows_per_sample : 0] : 1.f;
         if constexpr (HS > 1) {
-            lds_accumulate<OT>(s_out, out, r, h);
+            VMASR_DET_WAVE_ORDER(a.det, HS, lds_accumulate<OT>(s_out, out, r, h));
             __syncthreads();
         }
 #pragma unroll
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(HS > 4 ? 64 * HS : 256) void mlp_bwd_kernel(const M
             }
         }
         if constexpr (HS > 1) {
-            lds_accumulate<OT>(s_out, dx, r, h);
+            VMASR_DET_WAVE_ORDER(a.det, HS, lds_accumulate<OT>(s_out, dx, r, h));
             __syncthreads();
         }
 #pragma unroll
@@ -561,6 +562,7 @@ VMASR_EXPORT int vmasr_mlp_fwd(const void *x, const float *gamma, const float *b
     VMASR_REQUIRE(aligned_to(x, 16) && aligned_to(y, 16) && aligned_to(w1, 16) && aligned_to(w2, 16) && aligned_to(b1, 16) &&
                       aligned_to(b2, 16), VMASR_EINVAL, "mlp_fwd: tensors must be 16-byte aligned");
     MlpArgs a{};
+    a.det = det_ticket(VMASR_K_MLP_FWD);
     a.x = x; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.w1 = static_cast<const bf16_t *>(w1); a.b1 = b1; a.w2 = static_cast<const bf16_t *>(w2); a.b2 = b2;
     a.scale = scale; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.y = y; a.rows = rows;
@@ -581,6 +583,7 @@ VMASR_EXPORT int vmasr_mlp_bwd(const void *x, const void *gy, const float *gamma
                       aligned_to(b1, 16) && aligned_to(dxn, 16) && aligned_to(xn_aug, 16) && aligned_to(gys, 16) &&
                       aligned_to(act_aug, 16) && aligned_to(gpre, 16), VMASR_EINVAL, "mlp_bwd: tensors must be 16-byte aligned");
     MlpArgs a{};
+    a.det = det_ticket(VMASR_K_MLP_BWD);
     a.x = x; a.gy = gy; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.w1 = static_cast<const bf16_t *>(w1); a.w1t = static_cast<const bf16_t *>(w1t); a.b1 = b1;
     a.w2t = static_cast<const bf16_t *>(w2t);

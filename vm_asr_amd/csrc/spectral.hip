@@ -37,12 +37,14 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float *__restrict_
 constexpr int kRowChunk = 32;
 
 __global__ __launch_bounds__(256) void gemv_cols_kernel(const float *__restrict__ W, const float *__restrict__ u,
-                                                        float *__restrict__ s, const int R, const int C) {
+                                                        float *__restrict__ s, const int R, const int C, unsigned *det) {
     const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int r0 = blockIdx.y * kRowChunk, r1 = min(R, r0 + kRowChunk);
-    if (c0 >= C) return;
+    const int r0 = blockIdx.y * kRowChunk;
+    int r1 = min(R, r0 + kRowChunk);
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if ((C & 3) == 0) {
+    if (c0 >= C) {
+        r1 = r0;                                          // (no early return: every thread reaches the ordered tail below)
+    } else if ((C & 3) == 0) {
         for (int r = r0; r < r1; ++r) {
             const float4 w = *reinterpret_cast<const float4 *>(W + (size_t)r * C + c0);
             const float ur = u[r];
@@ -56,9 +58,11 @@ __global__ __launch_bounds__(256) void gemv_cols_kernel(const float *__restrict_
                 if (c0 + i < C) a[i] = fmaf(W[(size_t)r * C + c0 + i], ur, a[i]);
         }
     }
+    det_enter(det);                                       // deterministic mode: workgroup order (common.h)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (c0 + i < C) atomicAdd(s + c0 + i, a[i]);
+    det_leave(det);
 }
 
 // y = x / max(||x||_2, eps); also zeroes `clear` (n_clear floats) for the next gemv_cols accumulation
@@ -111,18 +115,20 @@ __global__ __launch_bounds__(256) void gemv_rows_multi_kernel(const vmasr_spectr
     if (lane == 0) it.t[r] = acc;
 }
 
-__global__ __launch_bounds__(256) void gemv_cols_multi_kernel(const vmasr_spectral_item *__restrict__ items, const int n) {
+__global__ __launch_bounds__(256) void gemv_cols_multi_kernel(const vmasr_spectral_item *__restrict__ items, const int n, unsigned *det) {
     const int m = find_item(items, n, blockIdx.x, true);
     const vmasr_spectral_item it = items[m];
     const int local = blockIdx.x - it.col_tile_start;
     const int ctiles = (it.C + 1023) / 1024;
     const int c0 = ((local % ctiles) * 256 + threadIdx.x) * 4;
-    const int r0 = (local / ctiles) * kRowChunk, r1 = min(it.R, r0 + kRowChunk);
-    if (c0 >= it.C) return;
+    const int r0 = (local / ctiles) * kRowChunk;
+    int r1 = min(it.R, r0 + kRowChunk);
     const float *W = it.W, *u = it.u;
     const int C = it.C;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if ((C & 3) == 0) {
+    if (c0 >= C) {
+        r1 = r0;                                          // (no early return: every thread reaches the ordered tail below)
+    } else if ((C & 3) == 0) {
         for (int r = r0; r < r1; ++r) {
             const float4 w = *reinterpret_cast<const float4 *>(W + (size_t)r * C + c0);
             const float ur = u[r];
@@ -136,9 +142,11 @@ __global__ __launch_bounds__(256) void gemv_cols_multi_kernel(const vmasr_spectr
                 if (c0 + i < C) a[i] = fmaf(W[(size_t)r * C + c0 + i], ur, a[i]);
         }
     }
+    det_enter(det);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (c0 + i < C) atomicAdd(it.s + c0 + i, a[i]);
+    det_leave(det);
 }
 
 // one workgroup per matrix: COLS ? (v = normalize(s), s = 0) : (u = normalize(t))
@@ -193,7 +201,7 @@ VMASR_EXPORT int vmasr_spectral_power_iter_batched(const vmasr_spectral_item *it
     for (int it = 0; it < n_iter; ++it) {
         VMASR_LAUNCH(VMASR_K_SPECTRAL, (double)weight_bytes, gemv_rows_multi_kernel, dim3(total_row_blocks), dim3(256), 0, st, items, n);
         VMASR_LAUNCH(VMASR_K_SPECTRAL, 0.0, (l2_normalize_multi_kernel<false>), dim3(n), dim3(1024), 0, st, items, eps);
-        VMASR_LAUNCH(VMASR_K_SPECTRAL, (double)weight_bytes, gemv_cols_multi_kernel, dim3(total_col_tiles), dim3(256), 0, st, items, n);
+        VMASR_LAUNCH(VMASR_K_SPECTRAL, (double)weight_bytes, gemv_cols_multi_kernel, dim3(total_col_tiles), dim3(256), 0, st, items, n, det_ticket(VMASR_K_SPECTRAL));
         VMASR_LAUNCH(VMASR_K_SPECTRAL, 0.0, (l2_normalize_multi_kernel<true>), dim3(n), dim3(1024), 0, st, items, eps);
     }
     if (sigma) {  // sigma_m = u^T W v with the final u, v (what spectral_norm divides the weight by)
@@ -218,7 +226,7 @@ VMASR_EXPORT int vmasr_spectral_power_iter(const float *W, float *u, float *v, f
         VMASR_LAUNCH(VMASR_K_SPECTRAL, wb, gemv_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, st, W, v, t, R, C);
         VMASR_LAUNCH(VMASR_K_SPECTRAL, R * 8.0, l2_normalize_kernel, dim3(1), dim3(1024), 0, st, t, u, R, eps, (float *)nullptr, 0);
         VMASR_LAUNCH(VMASR_K_SPECTRAL, wb, gemv_cols_kernel, dim3((C + 1023) / 1024, (R + kRowChunk - 1) / kRowChunk), dim3(256), 0,
-                     st, W, u, s, R, C);
+                     st, W, u, s, R, C, det_ticket(VMASR_K_SPECTRAL));
         // normalise into v and clear the accumulator for the next round
         VMASR_LAUNCH(VMASR_K_SPECTRAL, C * 8.0, l2_normalize_kernel, dim3(1), dim3(1024), 0, st, s, v, C, eps, s, C);
     }

@@ -127,7 +127,8 @@ constexpr int kGbLanes = 64;   // float4 lanes (256 columns) per workgroup: a (2
 __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__restrict__ pre, const float *__restrict__ g,
                                                              bf16_t *__restrict__ hi, bf16_t *__restrict__ lo,
                                                              bf16_t *__restrict__ cat3, float *__restrict__ gx,
-                                                             float *__restrict__ db, const long M, const int N, const int has_act) {
+                                                             float *__restrict__ db, const long M, const int N, const int has_act,
+                                                             unsigned *det) {
     const int slot = blockIdx.z;
     const int nv = N / 4;
     const int lanes = nv < kGbLanes ? nv : kGbLanes;          // float4 columns of this workgroup's chunk
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
         __shared__ float red[256][4];
         red[threadIdx.x][0] = (float)s[0]; red[threadIdx.x][1] = (float)s[1]; red[threadIdx.x][2] = (float)s[2]; red[threadIdx.x][3] = (float)s[3];
         __syncthreads();
+        det_enter(det);                      // deterministic mode: the workgroups' atomics in workgroup order (common.h)
         if (rr == 0 && c < nv) {
             float t[4] = {0.f, 0.f, 0.f, 0.f};
             for (int q = 0; q < rows_per_pass; ++q) {
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_split_kernel(const float *__rest
             float *d = db + (size_t)slot * N + c * 4;
             atomicAdd(d + 0, t[0]); atomicAdd(d + 1, t[1]); atomicAdd(d + 2, t[2]); atomicAdd(d + 3, t[3]);
         }
+        det_leave(det);
     }
 }
 
@@ -255,7 +258,7 @@ VMASR_EXPORT int vmasr_gelu_bwd_split(const float *pre, const float *g, void *hi
     const double per_elem = (pre ? 8.0 : 4.0) + (hi ? 4.0 : 0.0) + (cat3 ? 6.0 : 0.0);
     VMASR_LAUNCH(VMASR_K_BIAS_GELU, per_elem * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, chunks, slots), dim3(256), 0,
                  st, pre, g, static_cast<bf16_t *>(hi), static_cast<bf16_t *>(lo), static_cast<bf16_t *>(cat3), static_cast<float *>(nullptr), db, (long)M, N,
-                 pre ? 1 : 0);
+                 pre ? 1 : 0, det_ticket(VMASR_K_BIAS_GELU));
     return check_launch("gelu_bwd_split");
 }
 
@@ -270,6 +273,6 @@ VMASR_EXPORT int vmasr_gelu_bwd(const float *pre, const float *g, float *gx, flo
     const int chunks = (N / 4 + kGbLanes - 1) / kGbLanes;
     hipStream_t st = static_cast<hipStream_t>(stream);
     VMASR_LAUNCH(VMASR_K_BIAS_GELU, 12.0 * slots * (double)M * N, gelu_bwd_split_kernel, dim3(blocks, chunks, slots), dim3(256), 0, st, pre, g,
-                 static_cast<bf16_t *>(nullptr), static_cast<bf16_t *>(nullptr), static_cast<bf16_t *>(nullptr), gx, db, (long)M, N, 1);
+                 static_cast<bf16_t *>(nullptr), static_cast<bf16_t *>(nullptr), static_cast<bf16_t *>(nullptr), gx, db, (long)M, N, 1, det_ticket(VMASR_K_BIAS_GELU));
     return check_launch("gelu_bwd");
 }

@@ -23,6 +23,7 @@ namespace {
 struct GlueGeom {
     int B, D, L, P, nch;   // P positions per workgroup, nch = D / CH channel chunks per position
     float eps;
+    unsigned *det = nullptr;   // deterministic mode: the ticket word of this kernel id (common.h), else null
 };
 
 // accurate exp and a true division: these kernels are memory-bound, and the generator ends in a LayerNorm over two
@@ -230,11 +231,16 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float *__restric
             dg[e] += __shfl_xor(dg[e], off);
             db[e] += __shfl_xor(db[e], off);
         }
-        if ((threadIdx.x & 63) < g.nch) {
-            atomicAdd(&acc[c * CH + e], dg[e]);
-            atomicAdd(&acc[g.D + c * CH + e], db[e]);
-        }
     }
+    // (deterministic mode: the waves' LDS adds in wave order, the workgroups' global atomics in workgroup order — common.h)
+    VMASR_DET_WAVE_ORDER(g.det, 4, {
+        if ((threadIdx.x & 63) < g.nch) {
+            _Pragma("unroll") for (int e = 0; e < CH; ++e) {
+                atomicAdd(&acc[c * CH + e], dg[e]);
+                atomicAdd(&acc[g.D + c * CH + e], db[e]);
+            }
+        }
+    });
     __syncthreads();
     tile_to_rows<float>(tile, dy, g, b, l0);
     if (part) {
@@ -243,10 +249,12 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float *__restric
         float *dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * g.D;
         for (int d = threadIdx.x; d < 2 * g.D; d += blockDim.x) dst[d] = acc[d];
     } else {
+        det_enter(g.det);
         for (int d = threadIdx.x; d < g.D; d += blockDim.x) {
             atomicAdd(dgamma + d, acc[d]);
             atomicAdd(dbeta + d, acc[g.D + d]);
         }
+        det_leave(g.det);
     }
 }
 
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_direct(const float *__restric
                                                           const float *__restrict__ beta, const float *__restrict__ mean,
                                                           const float *__restrict__ rstd, float *__restrict__ dy,
                                                           T *__restrict__ dsz, float *__restrict__ dgamma,
-                                                          float *__restrict__ dbeta, const int L, const int iters) {
+                                                          float *__restrict__ dbeta, const int L, const int iters, unsigned *det) {
     __shared__ float acc[2 * D];
     const int b = blockIdx.y;
     if (threadIdx.x < 2 * D) acc[threadIdx.x] = 0.f;
@@ -387,14 +395,18 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_direct(const float *__restric
         for (int d = 0; d < D; ++d) dy[((size_t)b * D + d) * L + l] = r * (go[d] - s1 - xh[d] * s2);
     }
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float a = wave_sum(dg[d]), c = wave_sum(db[d]);
-        if (lane == 0) { atomicAdd(&acc[d], a); atomicAdd(&acc[D + d], c); }
-    }
+    // (deterministic mode: the four waves' LDS adds in wave order, the workgroups' global atomics in workgroup order — common.h)
+    VMASR_DET_WAVE_ORDER(det, 4, {
+        _Pragma("unroll") for (int d = 0; d < D; ++d) {
+            const float a = wave_sum(dg[d]), c = wave_sum(db[d]);
+            if (lane == 0) { atomicAdd(&acc[d], a); atomicAdd(&acc[D + d], c); }
+        }
+    });
     __syncthreads();
+    det_enter(det);
     if (threadIdx.x < D) atomicAdd(dgamma + threadIdx.x, acc[threadIdx.x]);
     else if (threadIdx.x < 2 * D) atomicAdd(dbeta + threadIdx.x - D, acc[threadIdx.x]);
+    det_leave(det);
 }
 
 // ---- pair variants: y = y02 + transpose(y13) formed on the fly (the last step of CrossMerge never becomes a tensor) ------
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(256) void ln_gate_pair_bwd_kernel(const float *__re
                                                                const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                float *__restrict__ dy02, float *__restrict__ dy13,
                                                                T *__restrict__ dsz, float *__restrict__ dgamma,
-                                                               float *__restrict__ dbeta, const PairGeom g, const int iters) {
+                                                               float *__restrict__ dbeta, const PairGeom g, const int iters, unsigned *det) {
     __shared__ float acc[2 * D];
     const int b = blockIdx.y, L = g.H * g.W;
     if (threadIdx.x < 2 * D) acc[threadIdx.x] = 0.f;
@@ -488,14 +500,18 @@ __global__ __launch_bounds__(256) void ln_gate_pair_bwd_kernel(const float *__re
         }
     }
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float a = wave_sum(dg[d]), c = wave_sum(db[d]);
-        if (lane == 0) { atomicAdd(&acc[d], a); atomicAdd(&acc[D + d], c); }
-    }
+    // (deterministic mode: the four waves' LDS adds in wave order, the workgroups' global atomics in workgroup order — common.h)
+    VMASR_DET_WAVE_ORDER(det, 4, {
+        _Pragma("unroll") for (int d = 0; d < D; ++d) {
+            const float a = wave_sum(dg[d]), c = wave_sum(db[d]);
+            if (lane == 0) { atomicAdd(&acc[d], a); atomicAdd(&acc[D + d], c); }
+        }
+    });
     __syncthreads();
+    det_enter(det);
     if (threadIdx.x < D) atomicAdd(dgamma + threadIdx.x, acc[threadIdx.x]);
     else if (threadIdx.x < 2 * D) atomicAdd(dbeta + threadIdx.x - D, acc[threadIdx.x]);
+    det_leave(det);
 }
 
 #define GLUE_DIRECT_D(KERNEL, T, KID, BYTES, GRIDX, ...)                                                              \
@@ -681,9 +697,10 @@ static int ln_gate_bwd_impl(const float *y, const void *sz, const void *dout, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t sm = ((size_t)D * (g.P + 1) + 2 * D) * sizeof(float);
     const double bytes = (double)B * L * D * (8 + 3 * esz);
+    g.det = det_ticket(VMASR_K_LN_GATE);
     if (direct_ok(D)) {
         const int chunks = (L + 255) / 256, nblk = std::min(chunks, kGlueMaxBlocks), iters = (chunks + nblk - 1) / nblk;
-#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta, L, iters
+#define GLUE_ARGS(TT) y, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy, static_cast<TT *>(dsz), dgamma, dbeta, L, iters, det_ticket(VMASR_K_LN_GATE)
         GLUE_DIRECT(ln_gate_bwd_direct, VMASR_K_LN_GATE, bytes, nblk);
 #undef GLUE_ARGS
         return check_launch("ln_gate_bwd");
@@ -729,7 +746,7 @@ VMASR_EXPORT int vmasr_ln_gate_pair_bwd(const float *y02, const float *y13, cons
     const PairGeom g{H, W, W / 16, (H / 16) * (W / 16)};
     const int nblk = std::min(g.ntiles, kGlueMaxBlocks), iters = (g.ntiles + nblk - 1) / nblk;
     const double bytes = (double)B * L * D * (16 + 3 * esz);
-#define GLUE_ARGS(TT) y02, y13, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy02, dy13, static_cast<TT *>(dsz), dgamma, dbeta, g, iters
+#define GLUE_ARGS(TT) y02, y13, static_cast<const TT *>(sz), static_cast<const TT *>(dout), gamma, beta, mean, rstd, dy02, dy13, static_cast<TT *>(dsz), dgamma, dbeta, g, iters, det_ticket(VMASR_K_LN_GATE)
     GLUE_DIRECT(ln_gate_pair_bwd_kernel, VMASR_K_LN_GATE, bytes, nblk);
 #undef GLUE_ARGS
     return check_launch("ln_gate_pair_bwd");

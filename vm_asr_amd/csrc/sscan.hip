@@ -297,6 +297,8 @@ struct BwdGeom {
     int tiles_per_task, nseg, W, wg_per_group;  // wg_per_group = (rows_per_group / R) / W
     float *part;                                // MODE 1, d_state 1: (batch*dim, nseg, 3) partial sums or null
     int fused_carry;                            // MODE 1, d_state 1: fold the reverse aggregates in the prologue
+    unsigned *det = nullptr;                    // deterministic mode (common.h): the workgroups of the launch run ONE AFTER THE OTHER in
+                                                // workgroup order (this kernel's fp32 atomics sit inside its tile loop), else null
 };
 
 template <typename T, int R, bool DYN, bool VEC, int MODE>
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
     __shared__ float s_an[DYN ? 4 * kMaxDState : 1];  // a of the first step of the tile to the right
     extern __shared__ __attribute__((aligned(16))) float s_red[];  // dB / dC partials: 2 x W x 256 floats (W > 1 only)
 
+    det_enter(geo.det);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row pointers live in SGPRs
     const int W = geo.W;
@@ -566,6 +569,7 @@ __global__ __launch_bounds__(1024) void sscan_bwd_kernel(const vmasr_sscan_bwd_p
             }
         }
     }
+    det_leave(geo.det);
 }
 
 // one wave per row d: sum the (batch, segment) partials of dA / dD / ddelta_bias
@@ -714,6 +718,7 @@ int launch_bwd(const vmasr_sscan_bwd_params &q, const Plan &pl, hipStream_t st) 
     const double full = (5 * KD * es + 2 * KN * es + 2 * KN * 4) * BL, agg = (2 * KD + KN) * BL * es;
     const double xb = (double)p.batch * p.dim * ntiles * p.dstate * 2 * 4 * 2;
     if (pl.split != 1) {
+        geo.det = det_ticket(VMASR_K_SSCAN_BWD);
         VMASR_LAUNCH(VMASR_K_SSCAN_BWD, full, (sscan_bwd_kernel<T, R, DYN, VEC, 0>), dim3((int)nblocks), dim3(64 * W), smem, st, q, geo);
         return check_launch("sscan_bwd");
     }
@@ -729,6 +734,7 @@ int launch_bwd(const vmasr_sscan_bwd_params &q, const Plan &pl, hipStream_t st) 
     }
     geo.fused_carry = fuse;
     if (partials) geo.part = static_cast<float *>(q.ws_ptr) + (size_t)p.batch * p.dim * ntiles * 2;
+    geo.det = det_ticket(VMASR_K_SSCAN_BWD_APPLY);
     VMASR_LAUNCH(VMASR_K_SSCAN_BWD_APPLY, full, (sscan_bwd_kernel<T, R, DYN, VEC, 1>), dim3((int)nblocks), dim3(64 * W), smem, st, q, geo);
     if (partials)
         VMASR_LAUNCH(VMASR_K_SSCAN_BWD_CARRY, (double)p.batch * p.dim * pl.nseg * 12, sscan_bwd_reduce_kernel,

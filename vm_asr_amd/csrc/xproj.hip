@@ -455,16 +455,18 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void xproj_bwd_b_kernel(const T *__restrict__ xs, const float *__restrict__ ddts,
                                                           const float *__restrict__ dxdbl, const float *__restrict__ dtr,
                                                           float *__restrict__ dWx, float *__restrict__ dWdt,
-                                                          const XpGeom g, const int chunk) {
+                                                          const XpGeom g, const int chunk, unsigned *det) {
     constexpr int RW = 4;  // rows per wave
     const int C = g.R + 2 * g.N;
     const int lane = threadIdx.x & 63;
     const int nrb = (g.D + RW - 1) / RW;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);  // (k, row-block)
-    if (wid >= g.K * nrb) return;
+    const int wid_raw = blockIdx.x * 4 + (threadIdx.x >> 6);  // (k, row-block)
+    const bool active = wid_raw < g.K * nrb;
+    if (!active && det == nullptr) return;                // (deterministic mode: every wave reaches the ordered tail)
+    const int wid = active ? wid_raw : 0;
     const int k = wid / nrb, d0 = (wid % nrb) * RW;
     const int b = blockIdx.z;
-    const int l_begin = blockIdx.y * chunk, l_end = min(g.L, l_begin + chunk);
+    const int l_begin = blockIdx.y * chunk, l_end = active ? min(g.L, l_begin + chunk) : l_begin;
     float ax[RW][kMaxC], at[RW][kMaxR];
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
@@ -505,22 +507,29 @@ __global__ __launch_bounds__(256) void xproj_bwd_b_kernel(const T *__restrict__ 
                     at[j][r] += (q[0] * gv[j][0] + q[1] * gv[j][1]) + (q[2] * gv[j][2] + q[3] * gv[j][3]);
             }
     }
+    auto tail = [&]() {
+        if (!active) return;
 #pragma unroll
-    for (int j = 0; j < RW; ++j) {
-        if (d0 + j >= g.D) break;
+        for (int j = 0; j < RW; ++j) {
+            if (d0 + j >= g.D) break;
 #pragma unroll
-        for (int c = 0; c < kMaxC; ++c)
-            if (c < C) {
-                const float s = wave_sum(ax[j][c]);
-                if (lane == 0) atomicAdd(dWx + ((size_t)k * C + c) * g.D + d0 + j, s);
-            }
+            for (int c = 0; c < kMaxC; ++c)
+                if (c < C) {
+                    const float s = wave_sum(ax[j][c]);
+                    if (lane == 0) atomicAdd(dWx + ((size_t)k * C + c) * g.D + d0 + j, s);
+                }
 #pragma unroll
-        for (int r = 0; r < kMaxR; ++r)
-            if (r < g.R) {
-                const float s = wave_sum(at[j][r]);
-                if (lane == 0) atomicAdd(dWdt + ((size_t)k * g.D + d0 + j) * g.R + r, s);
-            }
-    }
+            for (int r = 0; r < kMaxR; ++r)
+                if (r < g.R) {
+                    const float s = wave_sum(at[j][r]);
+                    if (lane == 0) atomicAdd(dWdt + ((size_t)k * g.D + d0 + j) * g.R + r, s);
+                }
+        }
+    };
+    // deterministic mode (common.h): workgroups in workgroup order, their four waves in wave order
+    det_enter(det);
+    VMASR_DET_WAVE_ORDER(det, 4, tail());
+    det_leave(det);
 }
 
 // the MFMA kernels: d_state 1, whole 32-row / 32-position tiles, even dt_rank (the contraction runs two at a time)
@@ -624,7 +633,7 @@ VMASR_EXPORT int vmasr_xproj_bwd(const void *xs, const float *Wx, const float *W
                           Wx, Wdt, (TT *)dxs, ws, g);                                                                    \
         VMASR_LAUNCH(VMASR_K_XPROJ_BWD_B, bytes_b, (xproj_bwd_b_kernel<TT, V>),                                           \
                      dim3((nwaves + 3) / 4, (L + chunk - 1) / chunk, B), dim3(256), 0, st,                                \
-                     (const TT *)xs, ddts, ws, dtr, dWx, dWdt, g, chunk);                                                \
+                     (const TT *)xs, ddts, ws, dtr, dWx, dWdt, g, chunk, det_ticket(VMASR_K_XPROJ_BWD_B));               \
     } while (0)
     if (dtype == VMASR_F32) { if (vec) VMASR_XPB(float, true); else VMASR_XPB(float, false); }
     else if (dtype == VMASR_F16) { if (vec) VMASR_XPB(f16_t, true); else VMASR_XPB(f16_t, false); }
