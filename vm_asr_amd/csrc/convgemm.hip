@@ -645,10 +645,9 @@ VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, in
     CwParams P = {};
     static const int forced = [] { const char *e = getenv("VMASR_CONV_TILE"); return e ? atoi(e) : 0; }();
     static const int mf = [] { const char *e = getenv("VMASR_CONV_MFMA"); return e ? atoi(e) : 16; }();
-    // 256 x 256 tiles measured NO faster than 128 x 128 for this kernel (1040 vs 1048 us on the 1024 -> 1024 layer, 558 vs 543 us
-    // on 512 -> 1024, profiles/r04_convgemm_microbench_v3.log: the transposed-read loop is not bound by the staged bytes) and need a
-    // split + sum pass to fill the chip: opt-in with VMASR_CONV_TILE=256
-    const bool big = Cout % 256 == 0 && Cin % 256 == 0 && forced == 256;
+    // 256 x 256 / 8 waves when both channel counts allow (with the 16x16x32 MFMA form: 597 -> 504-518 us on the 512 -> 1024 layer, 1 012 -> 945-960 us
+    // on 1024 -> 1024, profiles/r04_convgemm_microbench_v5.log; with the 32x32x16 form it had measured no gain); VMASR_CONV_TILE=128 forces the small tile
+    const bool big = Cout % 256 == 0 && Cin % 256 == 0 && forced != 128;
     const int T = big ? 256 : 128;
     P.nslots = n; P.splits = splits; P.tiles_co = Cout / T; P.tiles_kc = k * Cin / T;
     P.Cin = Cin; P.Cout = Cout; P.k = k; P.stride = stride; P.pad = pad;
