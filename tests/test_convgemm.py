@@ -38,6 +38,9 @@ CASES = [
     (256, 128, 5, 1, 2, [(2, 64), (3, 41)]),
     (128, 128, 3, 2, 1, [(5, 33)]),
     (128, 128, 5, 3, 2, [(7, 3)]),               # sequences shorter than the kernel
+    (32, 128, 5, 3, 2, [(5, 61), (3, 100)]),     # the 32 -> 128 layer: 256 x 128 forward, 256 x 32 dgrad, 128 x 32 wgrad tiles
+    (128, 256, 5, 3, 2, [(9, 200)]),             # several 256-row tiles
+    (256, 256, 5, 1, 2, [(6, 90), (4, 131)]),    # 256 x 256 tiles everywhere
 ]
 
 

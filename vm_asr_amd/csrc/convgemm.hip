@@ -95,8 +95,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
     constexpr int TILE_A = BM * 64, TILE_B = BN * 64;  // bytes of one operand tile (rows of 32 bf16)
     constexpr int STAGE = 2 * TILE_A + 2 * TILE_B;     // A_hi, A_lo, B_hi, B_lo
     constexpr int RPP = NT / 4;                        // rows staged per pass (4 threads per 64-byte row)
-    constexpr int PA = BM / RPP, PB = BN / RPP;
-    static_assert(BM % RPP == 0 && BN % RPP == 0 && BM % 128 == 0, "tile / thread geometry");
+    constexpr int PA = BM / RPP, PB = (BN + RPP - 1) / RPP;
+    constexpr bool B_PART = BN < RPP;                  // narrow B tile (BN = 32): only the waves that own its rows stage it
+    static_assert(BM % RPP == 0 && (BN % RPP == 0 || (B_PART && BN % 16 == 0)) && BM % 128 == 0, "tile / thread geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *crow_tab = reinterpret_cast<int *>(smem + 2 * STAGE);         // C row of each of the tile's BM rows (-1: none)
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
     const bf16_t *bsrc_h[PB], *bsrc_l[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const size_t o = (size_t)(n0 + srow + RPP * i) * KB + chunk * 8;
+        const size_t o = (size_t)(n0 + ((B_PART && srow >= BN) ? 0 : srow + RPP * i)) * KB + chunk * 8;
         bsrc_h[i] = pr.bh + o;
         bsrc_l[i] = pr.bl + o;
     }
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
+            if (B_PART && srow >= BN) break;           // (wave-uniform: a wave stages 16 whole rows)
             CG_DMA(bsrc_h[i] + koff, d + 2 * TILE_A + i * RPP * 64);
             CG_DMA(bsrc_l[i] + koff, d + 2 * TILE_A + TILE_B + i * RPP * 64);
         }
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
                     }
         }
         __syncthreads();
+        static_assert(128 % RPI == 0, "epilogue geometry");
 #pragma unroll 4
         for (int it = 0; it < 128 / RPI; ++it) {
             const int row = it * RPI + tid / C4;
@@ -328,7 +331,10 @@ struct CwParams {
 
 // byte offset of 16-byte chunk `ch` of row `row` in an operand tile with ROWB-byte rows
 template <int ROWB>
-__device__ __forceinline__ int cw_off(const int row, const int ch) { return row * ROWB + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+__device__ __forceinline__ int cw_off(const int row, const int ch) {
+    if constexpr (ROWB == 64) return row * 64 + (ch << 4);     // 4 rows = one 256-B bank row: a transposed-read block is conflict-free as it lies
+    else return row * ROWB + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
 
 // MF = 32: fragment of v_mfma_f32_32x32x16_bf16 for output index colbase + (lane & 31), contraction rows 16 ks + 8 (lane >> 5) ..;
 // MF = 16: fragment of v_mfma_f32_16x16x32_bf16 for output index colbase + (lane & 15), contraction rows 8 (lane >> 4) .. (all 32).
@@ -354,8 +360,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
     constexpr int TILE_G = CW_BR * RBG, TILE_X = CW_BR * RBX;
     constexpr int STAGE = 2 * TILE_G + 2 * TILE_X;              // g_hi, g_lo, x_hi, x_lo
     constexpr int CG = BCO / 8, CX = BKC / 8;                   // 16-byte chunks per row
-    constexpr int PG = CW_BR * CG / NT, PX = CW_BR * CX / NT;   // staging passes (one chunk per thread and pass)
-    static_assert(PG >= 1 && PX >= 1 && (CW_BR * CG) % NT == 0 && (CW_BR * CX) % NT == 0, "staging geometry");
+    constexpr int PG = CW_BR * CG / NT, PX = (CW_BR * CX + NT - 1) / NT;   // staging passes (one chunk per thread and pass)
+    constexpr bool X_PART = CW_BR * CX < NT;                    // narrow x tile (32 channels): only the first CW_BR * CX threads stage it
+    static_assert(PG >= 1 && (CW_BR * CG) % NT == 0 && (X_PART || (CW_BR * CX) % NT == 0), "staging geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
         const int idx = tid + i * NT;
-        x_row[i] = idx / CX; x_ch[i] = idx % CX;
+        x_row[i] = (idx / CX) % CW_BR; x_ch[i] = idx % CX;
         x_m[i] = mbeg + x_row[i];
         x_seq[i] = x_m[i] / pr.Q;
         x_q[i] = x_m[i] - x_seq[i] * pr.Q;
@@ -414,6 +421,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
             g_m[i] += CW_BR;                                                                                   \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < PX; ++i) {                                                       \
+            if (X_PART && tid >= CW_BR * CX) break;                                                            \
             const int p_ = x_q[i] * P.stride + tap - P.pad;                                                    \
             x_ok[i] = x_m[i] < mend && p_ >= 0 && p_ < pr.H;                                                   \
             const size_t o_ = (size_t)(x_ok[i] ? x_seq[i] * pr.H + p_ : 0) * Cin + c0 + x_ch[i] * 8;           \
@@ -432,6 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
             *reinterpret_cast<u32x4 *>(s_ + TILE_G + o_) = g_ok[i] ? rg_l[i] : z4;                             \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < PX; ++i) {                                                       \
+            if (X_PART && tid >= CW_BR * CX) break;                                                            \
             const int o_ = cw_off<RBX>(x_row[i], x_ch[i]);                                                     \
             *reinterpret_cast<u32x4 *>(s_ + 2 * TILE_G + o_) = x_ok[i] ? rx_h[i] : z4;                         \
             *reinterpret_cast<u32x4 *>(s_ + 2 * TILE_G + TILE_X + o_) = x_ok[i] ? rx_l[i] : z4;                \
@@ -551,17 +560,19 @@ int cg_launch(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
     // (MI355X_MICROARCH.md, DVFS give-back item 7): 5-9 % less time on the 512 -> 1024 and 1024 -> 1024 layers, forward and dgrad
     // (profiles/r04_convgemm_microbench_v4.log); VMASR_CONV_MFMA=32 selects the 32x32x16 form
     static const int mf = [] { const char *e = getenv("VMASR_CONV_MFMA"); return e ? atoi(e) : 16; }();
-    bool big = P.NB % 256 == 0;
-    if (forced == 128) big = false;
-    if (big) return mf == 16 ? cg_launch_cfg<256, 256, 2, 4, 16>(P, act, st, kid, bytes) : cg_launch_cfg<256, 256, 2, 4, 32>(P, act, st, kid, bytes);
+    if (P.NB % 256 == 0 && forced != 128)
+        return mf == 16 ? cg_launch_cfg<256, 256, 2, 4, 16>(P, act, st, kid, bytes) : cg_launch_cfg<256, 256, 2, 4, 32>(P, act, st, kid, bytes);
+    if (P.NB % 128 == 0 && forced != 128) return cg_launch_cfg<256, 128, 4, 2, 16>(P, act, st, kid, bytes);     // per wave 64 x 64
+    if (P.NB == 32) return cg_launch_cfg<256, 32, 8, 1, 16>(P, act, st, kid, bytes);                            // per wave 32 x 32 (the 32-channel side)
     return mf == 16 ? cg_launch_cfg<128, 128, 2, 2, 16>(P, act, st, kid, bytes) : cg_launch_cfg<128, 128, 2, 2, 32>(P, act, st, kid, bytes);
 }
 
 }  // namespace
 
 VMASR_EXPORT int vmasr_conv_mfma_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride) {
-    return Cin % CG_BK == 0 && Cout % CG_BK == 0 && Cin % CG_BN == 0 && Cout % CG_BN == 0 && k >= 1 && k <= 8 && stride >= 1 &&
-           stride <= 3;
+    // channel counts: multiples of 128, or exactly 32 on the input side (the 32 -> 128 layer: 256 x 32 / 128 x 32 tile configurations)
+    const bool in_ok = Cin > 0 && (Cin % 128 == 0 || Cin == 32), out_ok = Cout > 0 && Cout % 128 == 0;
+    return in_ok && out_ok && k >= 1 && k <= 8 && stride >= 1 && stride <= 3;
 }
 
 VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
@@ -648,8 +659,9 @@ VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, in
     // 256 x 256 / 8 waves when both channel counts allow (with the 16x16x32 MFMA form: 597 -> 504-518 us on the 512 -> 1024 layer, 1 012 -> 945-960 us
     // on 1024 -> 1024, profiles/r04_convgemm_microbench_v5.log; with the 32x32x16 form it had measured no gain); VMASR_CONV_TILE=128 forces the small tile
     const bool big = Cout % 256 == 0 && Cin % 256 == 0 && forced != 128;
-    const int T = big ? 256 : 128;
-    P.nslots = n; P.splits = splits; P.tiles_co = Cout / T; P.tiles_kc = k * Cin / T;
+    const bool narrow = Cin == 32;                       // the 32 -> 128 layer: 128 x 32 tiles (one tap's 32 channels)
+    const int T = big ? 256 : 128, TK = narrow ? 32 : T;
+    P.nslots = n; P.splits = splits; P.tiles_co = Cout / T; P.tiles_kc = k * Cin / TK;
     P.Cin = Cin; P.Cout = Cout; P.k = k; P.stride = stride; P.pad = pad;
     double bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -675,6 +687,8 @@ VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, in
             attr_done = true;
         }
         VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<256, 256, 2, 4, 16>), dim3(tiles), dim3(512), smem, st, P);
+    } else if (narrow) {
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 32, 4, 1, 16>), dim3(tiles), dim3(256), 2 * (2 * CW_BR * 256 + 2 * CW_BR * 64), st, P);
     } else if (mf == 32) {
         VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2, 32>), dim3(tiles), dim3(256), 2 * 4 * CW_BR * 256, st, P);
     } else {

@@ -826,15 +826,34 @@ class _StackedConvMfmaFn(torch.autograd.Function):
         lib = _lib.lib()
         skip_w = _PHASE["skip_weight_grads"]
         want_db = ctx.needs_input_grad[8] and not skip_w
+        # The input gradient of the 32 -> 128 layer stays an fp32 GEMM + col2im: it is the last GEMM in front of d(loss)/d(wave), a sum
+        # with heavy cancellation, where the pair's 16-17 bits per product showed (2.5e-3 of the gradient's scale from float64 against
+        # 4e-4 for fp32 — tests/test_mpd.py holds 5e-4); its forward and weight gradient take the MFMA kernels like the other layers
+        fp32_dgrad = C < 128 and ctx.needs_input_grad[9]
+        need_pair = (not fp32_dgrad and ctx.needs_input_grad[9]) or (ctx.needs_input_grad[7] and not skip_w)
+        gh = gl = gx = None
         with torch.cuda.device(gy.device):
-            gh = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
-            gl = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
             db32 = torch.zeros((n, N), dtype=torch.float32, device=gy.device) if want_db else None
-            _lib.check(lib.vmasr_gelu_bwd_split(pre.data_ptr(), gy.data_ptr(), gh.data_ptr(), gl.data_ptr(), None,
-                                                db32.data_ptr() if want_db else None, n, M, N, _lib.current_stream(gy.device)),
-                       "gelu_bwd_split")
+            if need_pair:
+                gh = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
+                gl = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
+                _lib.check(lib.vmasr_gelu_bwd_split(pre.data_ptr(), gy.data_ptr(), gh.data_ptr(), gl.data_ptr(), None,
+                                                    db32.data_ptr() if want_db else None, n, M, N, _lib.current_stream(gy.device)),
+                           "gelu_bwd_split")
+            if fp32_dgrad:
+                gx = torch.empty_like(gy)
+                _lib.check(lib.vmasr_gelu_bwd(pre.data_ptr(), gy.data_ptr(), gx.data_ptr(),
+                                              db32.data_ptr() if (want_db and not need_pair) else None, n, M, N,
+                                              _lib.current_stream(gy.device)), "gelu_bwd")
         dx = dw = db = None
-        if ctx.needs_input_grad[9]:
+        if fp32_dgrad:
+            dcols = torch.bmm(gx, w)                                      # (n, M, k*C) fp32
+            with torch.cuda.device(gy.device):
+                dx = torch.empty(xshape, dtype=torch.float32, device=gy.device)
+                _, Ns, Hs = _slot_arrays([0] * n, [ns for ns, _ in geom], [h for _, h in geom])
+                _lib.check(lib.vmasr_col2im_kx1_stacked(dcols.data_ptr(), dx.data_ptr(), Ns, Hs, n, C, k, stride, pad, M, xshape[1], _lib.F32,
+                                                        _lib.current_stream(gy.device)), "col2im_kx1_stacked")
+        elif ctx.needs_input_grad[9]:
             if "wt" not in ops:      # (n, Cout, k, C) -> (n, C, k*Cout): the dgrad GEMM's B operand, (tap, output channel) order
                 ops["wt"] = split_bf16(w.view(n, N, k, C).permute(0, 3, 2, 1).reshape(n, C, k * N).contiguous())
             wth, wtl = ops["wt"]
@@ -1230,10 +1249,16 @@ class MultiPeriodDiscriminator(nn.Module):
                   and all(c.shape[3] == 1 for c in cur) and os.environ.get("VMASR_CONV_FIRST", "1") == "1"):
                 # the 1 -> 32 channel input convolution + GELU straight from the folded signals (no 5-column operand / K = 5 GEMM)
                 y = _StackedConvFirstFn.apply(_round_up(max(Ms), 256), W, bstack, *cur)
-            elif (_split_mode(W.shape[2], W.shape[1], cdt) and act and sgeom is not None and os.environ.get("VMASR_MPD_CONV", "mfma") == "mfma"
+            elif (cdt == torch.float32 and os.environ.get("VMASR_MPD_GEMM", "bf16x3") == "bf16x3" and act and sgeom is not None
+                  and os.environ.get("VMASR_MPD_CONV", "mfma") == "mfma"
+                  and (cur[0].shape[3] >= 128 or os.environ.get("VMASR_MPD_CONV_L1", "0") == "1")
                   and _lib.lib().vmasr_conv_mfma_supported(cur[0].shape[3], W.shape[1], k, stride)):
-                # the three compute-bound layers: one implicit-GEMM launch each way (csrc/convgemm.hip); the layer's epilogue
-                # leaves the bf16 pair of its activation for the next layer
+                # the three compute-bound layers (128 -> 512 -> 1024 -> 1024): one implicit-GEMM launch each way (csrc/convgemm.hip); the
+                # layer's epilogue leaves the bf16 pair of its activation for the next layer.  The 32 -> 128 layer CAN take the same
+                # kernels (256 x 128 / 256 x 32 / 128 x 32 tile configurations, VMASR_MPD_CONV_L1=1: 28.7 -> 28.0 ms per step) but stays on
+                # fp32 GEMMs by default: it is the first GEMM behind the signal, and with its forward at the pair's 16-17 bits the input
+                # gradient d(loss)/d(wave) of an |f|-type loss moved to 2.5e-3 of its scale from float64 (fp32: 4e-4; gate 5e-4,
+                # tests/test_mpd.py) — near-zero GELU outputs change sign
                 wcache = None
                 if self._frozen is not None:
                     wcache = self._frozen.setdefault(("mfma_ops", li), {})
