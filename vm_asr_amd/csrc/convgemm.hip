@@ -562,7 +562,9 @@ int cg_launch(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
     static const int mf = [] { const char *e = getenv("VMASR_CONV_MFMA"); return e ? atoi(e) : 16; }();
     if (P.NB % 256 == 0 && forced != 128)
         return mf == 16 ? cg_launch_cfg<256, 256, 2, 4, 16>(P, act, st, kid, bytes) : cg_launch_cfg<256, 256, 2, 4, 32>(P, act, st, kid, bytes);
-    if (P.NB % 128 == 0 && forced != 128) return cg_launch_cfg<256, 128, 4, 2, 16>(P, act, st, kid, bytes);     // per wave 64 x 64
+    // 256 x 128 (per wave 64 x 64): only for the 32-channel input side (K = 160: five K steps) — on the 128 -> 512 layer's dgrad it measured
+    // SLOWER than 128 x 128 with two workgroups per CU (317 vs 279 us, profiles/r04_convgemm_microbench_v6_b4.log)
+    if (P.NB % 128 == 0 && P.CA == 32 && forced != 128) return cg_launch_cfg<256, 128, 4, 2, 16>(P, act, st, kid, bytes);
     if (P.NB == 32) return cg_launch_cfg<256, 32, 8, 1, 16>(P, act, st, kid, bytes);                            // per wave 32 x 32 (the 32-channel side)
     return mf == 16 ? cg_launch_cfg<128, 128, 2, 2, 16>(P, act, st, kid, bytes) : cg_launch_cfg<128, 128, 2, 2, 32>(P, act, st, kid, bytes);
 }
