@@ -302,6 +302,11 @@ typedef struct vmasr_cg_slot {
     int32_t reserved;
 } vmasr_cg_slot;
 int vmasr_conv_mfma_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride);
+/* CUs the conv_mfma kernels may occupy from now on (process-wide; 0 = all, the default): launched with fewer workgroups than
+ * tiles they loop over the tiles.  Used by the two-stream train step while other kernels run beside them; results do
+ * not depend on it. */
+void vmasr_conv_set_cu_limit(int32_t cus);
+int32_t vmasr_conv_get_cu_limit(void);
 int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
                         int64_t rows_out, int32_t act, vmasr_stream_t stream);
 int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,

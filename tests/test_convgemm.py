@@ -129,3 +129,42 @@ def test_conv_mfma_full_size_layer_matches_float64_on_sampled_rows():
     got = pre[0, rows_chk].double()
     assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
     assert (y[0, rows_chk].double() - F.gelu(want)).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+@gpu
+def test_conv_mfma_cu_limit_changes_nothing_but_the_grid():
+    """vmasr_conv_set_cu_limit: fewer workgroups than tiles, each looping over several — bit-identical outputs."""
+    from vm_asr_amd import convgemm as cg
+    from vm_asr_amd.discriminator import split_bf16
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    Cin, Cout, k, stride, pad = 256, 256, 5, 3, 2
+    geom = [(6, 700), (4, 1001), (9, 333)]
+    n = len(geom)
+    H1 = [cg.out_positions(H, k, stride, pad) for _, H in geom]
+    Ms = [ns * h1 for (ns, _), h1 in zip(geom, H1)]
+    rows_in = -(-max(ns * H for ns, H in geom) // 256) * 256
+    rows_out = -(-max(Ms) // 256) * 256
+    x = _stack([torch.randn(ns * H, Cin, generator=g).to(dev) for ns, H in geom], rows_in)
+    W = (torch.randn(n, Cout, k * Cin, generator=g) / (k * Cin) ** 0.5).to(dev)
+    bias = torch.randn(n, Cout, generator=g).to(dev)
+    gy = _stack([torch.randn(M, Cout, generator=g).to(dev) for M in Ms], rows_out)
+    xh, xl = split_bf16(x)
+    wh, wl = split_bf16(W)
+    gh, gl = split_bf16(gy)
+    wth, wtl = split_bf16(W.view(n, Cout, k, Cin).permute(0, 3, 2, 1).reshape(n, Cin, k * Cout).contiguous())
+
+    def run():
+        f = cg.conv_fwd(xh, xl, wh, wl, bias, geom, k, stride, pad, rows_out, act=True)
+        d = cg.conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, rows_in)
+        w = cg.conv_wgrad(gh, gl, xh, xl, geom, k, stride, pad, splits=2)
+        torch.cuda.synchronize()
+        return list(f) + [d, w]
+
+    ref = run()
+    for cus in (8, 24, 200):
+        with cg.cu_limit(cus):
+            got = run()
+        assert int(cg._lib.lib().vmasr_conv_get_cu_limit()) == 0
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), cus

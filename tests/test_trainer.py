@@ -259,6 +259,55 @@ def test_shared_fake_pass_gives_the_same_gradients(monkeypatch):
         assert (ga[k] - gb[k]).abs().max().item() <= 2e-3 * scale + 1e-7, (k, (ga[k] - gb[k]).abs().max().item(), scale)
 
 
+@pytest.mark.gpu
+def test_two_stream_step_gives_the_same_gradients(monkeypatch):
+    """The step on two streams (discriminator on a side stream beside the generator: trainer._two_streams) == the same step on
+    one stream: same losses, same gradients of every parameter — eagerly and as one captured graph with a fork / join
+    (replayed three times on changing inputs: a missing dependency between the branches would show as stale values)."""
+    cfg = _tiny_config()
+    batches = [[t.cuda() for t in _batch(cfg, 2, seed=s)] for s in (0, 1, 2)]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VMASR_TWO_STREAM", flag)
+        tr = _gpu_trainer(cfg, amp=False)
+        for m in tr.models.values():
+            m.train()
+        assert tr._two_streams() == (flag == "1")
+        res = []
+        for b in batches:
+            _, logs = tr._forward_backward(*b)
+            torch.cuda.synchronize()
+            grads = {f"{k}.{n}": p.grad.detach().clone() for k in ("generator", "mpd")
+                     for n, p in tr.models[k].named_parameters() if p.grad is not None}
+            res.append(({k: float(v) for k, v in logs.items()}, grads))
+        out[flag] = res
+    for (la, ga), (lb, gb) in zip(out["1"], out["0"]):
+        for k in lb:
+            assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-7, (k, la[k], lb[k])
+        assert ga.keys() == gb.keys()
+        for k in gb:
+            scale = max(gb[k].abs().max().item(), 1e-8)
+            assert (ga[k] - gb[k]).abs().max().item() <= 1e-4 * scale + 1e-7, (k, (ga[k] - gb[k]).abs().max().item(), scale)
+    # captured: loss trajectories of the graphed two-stream step against the graphed one-stream step
+    hist = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VMASR_TWO_STREAM", flag)
+        tr = _gpu_trainer(cfg, amp=False, capturable=True)
+        for m in tr.models.values():
+            m.train()
+        assert tr.enable_graphs(batches[0], warmup=3)
+        assert (tr._graphed.graph_g is None) == (flag == "1")
+        h = []
+        for i in range(4):
+            _, logs = tr.train_step(*batches[i % 3])
+            h.append({k: float(v) for k, v in logs.items()})
+        torch.cuda.synchronize()
+        hist[flag] = h
+    for a, b in zip(hist["1"], hist["0"]):
+        for k, v in a.items():
+            assert abs(v - b[k]) <= 0.02 * abs(v) + 1e-4, (k, v, b[k])
+
+
 # ---- round 2: batch contract, checkpoints, schedule, accumulation, multi-process decisions -------------------
 def test_synthetic_vctk_batch_contract():
     """H0: `(wave_in (1,T), wave_tgt (1,T), highcut int64, name, pad)` with T = int(SEGMENT * TARGET_SR) and

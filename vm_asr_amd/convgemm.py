@@ -16,6 +16,23 @@ def supported(Cin, Cout, k, stride):
     return bool(_lib.lib().vmasr_conv_mfma_supported(int(Cin), int(Cout), int(k), int(stride)))
 
 
+class cu_limit:
+    """with cu_limit(n): the conv_mfma kernels launched inside occupy at most n CUs (persistent tile loops); 0 / None = all.
+    Host-side launch geometry only — the results do not depend on it."""
+
+    def __init__(self, cus):
+        self.cus = int(cus or 0)
+
+    def __enter__(self):
+        self.prev = int(_lib.lib().vmasr_conv_get_cu_limit())
+        _lib.lib().vmasr_conv_set_cu_limit(self.cus)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().vmasr_conv_set_cu_limit(self.prev)
+        return False
+
+
 def _slots(n):
     return (_lib.CgSlot * n)()
 

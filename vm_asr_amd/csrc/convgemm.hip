@@ -104,8 +104,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
 
-    // ---- which tile ------------------------------------------------------------------------------------------------
-    const int t = xcd_remap(blockIdx.x, P.total_tiles);
+    // ---- which tile: one per workgroup, or — launched with fewer workgroups than tiles (vmasr_conv_set_cu_limit: the two-stream
+    // train step leaves CUs to the generator's kernels) — tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x % 8 == 0 keeps a
+    // workgroup's tiles on its XCD's run of the remap)
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
+    const int t = xcd_remap(tile, P.total_tiles);
     int pi = 0;
 #pragma unroll 1
     for (int i = 1; i < P.nprob; ++i) pi = (t >= P.prob[i].tile_start) ? i : pi;
@@ -304,6 +308,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
             }
         }
     }
+    __syncthreads();                                   // the next tile's row table and first stage overwrite this tile's LDS
+    }
 }
 
 // ---- weight gradient: dW[co, t Cin + c] = sum_m g[m, co] x[xrow(m, t), c] ---------------------------------------------------
@@ -368,7 +374,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
     const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
 
     const int per_slot = P.splits * P.tiles_co * P.tiles_kc;
-    const int t = xcd_remap(blockIdx.x, P.nslots * per_slot);
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < P.nslots * per_slot; tile += gridDim.x) {      // (persistent when launched with fewer workgroups than tiles)
+    const int t = xcd_remap(tile, P.nslots * per_slot);
     const int slot = t / per_slot;
     int rem = t - slot * per_slot;
     const int split = rem / (P.tiles_co * P.tiles_kc);
@@ -518,6 +526,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
                 dw[(size_t)row * KC + col] = acc[i][j][r];
             }
         }
+    __syncthreads();                                   // (every wave is out of the last stage before the next tile's first store)
+    }
 }
 
 }  // namespace
@@ -526,6 +536,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
 using namespace vmasr;
 
 namespace {
+
+// CUs the convolution kernels may occupy (0: all).  The two-stream train step (trainer._backward_two) sets it while the generator's
+// small kernels run beside them: a 256 x 256 tile holds a CU's LDS for ~300 us, and the dispatcher hands freed CUs to the running grid's
+// next workgroup first, so without spare CUs the other stream's kernels start late.
+int g_cg_cu_limit = 0;
+
+int cg_grid(int tiles, size_t smem) {
+    if (g_cg_cu_limit <= 0) return tiles;
+    const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(smem, 1)));
+    return std::min(tiles, g_cg_cu_limit * per_cu / 8 * 8);
+}
 
 template <int BM, int BN, int WM, int WN, int MF>
 int cg_launch_cfg(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
@@ -546,9 +567,9 @@ int cg_launch_cfg(CgParams &P, bool act, hipStream_t st, int kid, double bytes) 
         attr_done = true;
     }
     if (act) {
-        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, true, MF>), dim3(tiles), dim3(64 * WM * WN), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, true, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
     } else {
-        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, false, MF>), dim3(tiles), dim3(64 * WM * WN), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, false, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
     }
     return check_launch("conv_mfma");
 }
@@ -570,6 +591,9 @@ int cg_launch(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
 }
 
 }  // namespace
+
+VMASR_EXPORT void vmasr_conv_set_cu_limit(int32_t cus) { g_cg_cu_limit = cus < 0 ? 0 : cus; }
+VMASR_EXPORT int32_t vmasr_conv_get_cu_limit(void) { return g_cg_cu_limit; }
 
 VMASR_EXPORT int vmasr_conv_mfma_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride) {
     // channel counts: multiples of 128, or exactly 32 on the input side (the 32 -> 128 layer: 256 x 32 / 128 x 32 tile configurations)
@@ -688,13 +712,13 @@ VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, in
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_wgrad_kernel<256, 256, 2, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             attr_done = true;
         }
-        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<256, 256, 2, 4, 16>), dim3(tiles), dim3(512), smem, st, P);
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<256, 256, 2, 4, 16>), dim3(cg_grid(tiles, smem)), dim3(512), smem, st, P);
     } else if (narrow) {
-        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 32, 4, 1, 16>), dim3(tiles), dim3(256), 2 * (2 * CW_BR * 256 + 2 * CW_BR * 64), st, P);
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 32, 4, 1, 16>), dim3(cg_grid(tiles, 2 * (2 * CW_BR * 256 + 2 * CW_BR * 64))), dim3(256), 2 * (2 * CW_BR * 256 + 2 * CW_BR * 64), st, P);
     } else if (mf == 32) {
-        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2, 32>), dim3(tiles), dim3(256), 2 * 4 * CW_BR * 256, st, P);
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2, 32>), dim3(cg_grid(tiles, 2 * 4 * CW_BR * 256)), dim3(256), 2 * 4 * CW_BR * 256, st, P);
     } else {
-        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2, 16>), dim3(tiles), dim3(256), 2 * 4 * CW_BR * 256, st, P);
+        VMASR_LAUNCH(VMASR_K_CONV_MFMA_WGRAD, bytes, (conv_mfma_wgrad_kernel<128, 128, 2, 2, 16>), dim3(cg_grid(tiles, 2 * 4 * CW_BR * 256)), dim3(256), 2 * 4 * CW_BR * 256, st, P);
     }
     return check_launch("conv_mfma_wgrad");
 }

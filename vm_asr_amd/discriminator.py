@@ -514,7 +514,7 @@ class _BatchedLinearFn(torch.autograd.Function):
             want_db = ctx.needs_input_grad[2] and not skip_w
             with torch.cuda.device(gy.device):
                 gx = torch.empty_like(gy)
-                db32 = torch.zeros((n, N), dtype=torch.float32, device=gy.device) if want_db else None
+                db32, = _lib.zeros_f32(gy.device, (n, N) if want_db else None)
                 _lib.check(_lib.lib().vmasr_gelu_bwd(rest[0].data_ptr(), gy.data_ptr(), gx.data_ptr(), db32.data_ptr() if want_db else None,
                                                      n, M, N, _lib.current_stream(gy.device)), "gelu_bwd")
             gy = gx
@@ -742,7 +742,7 @@ class _StackedConvSplitFn(torch.autograd.Function):
         if N % 4 == 0 and N <= 1024:
             # one pass: (GELU' *) gradient -> bf16 split (+ bias gradient); the fp32 gradient is never written
             with torch.cuda.device(gy.device):
-                db32 = torch.zeros((n, N), dtype=torch.float32, device=gy.device) if want_db else None
+                db32, = _lib.zeros_f32(gy.device, (n, N) if want_db else None)
                 if want_dx:    # [gh | gl | gh]: the weight-gradient GEMMs read gh, gl as column blocks of it (lda = 3N)
                     gcat = torch.empty((n, M, 3 * N), dtype=torch.bfloat16, device=gy.device)
                     gh, gl = gcat[:, :, :N], gcat[:, :, N:2 * N]
@@ -833,7 +833,7 @@ class _StackedConvMfmaFn(torch.autograd.Function):
         need_pair = (not fp32_dgrad and ctx.needs_input_grad[9]) or (ctx.needs_input_grad[7] and not skip_w)
         gh = gl = gx = None
         with torch.cuda.device(gy.device):
-            db32 = torch.zeros((n, N), dtype=torch.float32, device=gy.device) if want_db else None
+            db32, = _lib.zeros_f32(gy.device, (n, N) if want_db else None)
             if need_pair:
                 gh = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
                 gl = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
@@ -901,8 +901,7 @@ class _StackedConvFirstFn(torch.autograd.Function):
         dxs = [None] * n
         with torch.cuda.device(dev):
             dcols = torch.empty((n, rows, 5), dtype=torch.float32, device=dev) if want_dx else None
-            dw = torch.zeros((n, 32, 5), dtype=torch.float32, device=dev) if want_dw else None
-            db = torch.zeros((n, 32), dtype=torch.float32, device=dev) if want_db else None
+            dw, db = _lib.zeros_f32(dev, (n, 32, 5) if want_dw else None, (n, 32) if want_db else None)
             _lib.check(lib.vmasr_conv_first_bwd(ptrs, Ns, Hs, n, w32.data_ptr(), pre.data_ptr(), gy.data_ptr(),
                                                 dcols.data_ptr() if want_dx else None, dw.data_ptr() if want_dw else None,
                                                 db.data_ptr() if want_db else None, rows, _lib.current_stream(dev)), "conv_first_bwd")
@@ -950,8 +949,7 @@ class _StackedConvPostFn(torch.autograd.Function):
         ms, hs = (ctypes.c_int64 * n)(*Ms), (ctypes.c_int32 * n)(*Hs)
         with torch.cuda.device(dev):
             dx = torch.empty_like(xc) if want_dx else None
-            dw = torch.zeros((n, 1, 3 * C), dtype=torch.float32, device=dev) if want_dw else None
-            db = torch.zeros(n, dtype=torch.float32, device=dev) if want_db else None
+            dw, db = _lib.zeros_f32(dev, (n, 1, 3 * C) if want_dw else None, (n,) if want_db else None)
             _lib.check(lib.vmasr_conv_post_bwd(xc.data_ptr(), w32.data_ptr(), gy.data_ptr(), dx.data_ptr() if want_dx else None,
                                                dw.data_ptr() if want_dw else None, db.data_ptr() if want_db else None, ms, hs, n, rows, C, 3,
                                                _lib.current_stream(dev)), "conv_post_bwd")

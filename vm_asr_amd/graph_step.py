@@ -105,10 +105,15 @@ class GraphedTrainStep:
         # (hipEventQuery) at any time, which in the default global mode would invalidate a capture in progress
         with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
             st = tr._forward_losses(*self.static_in)
-            tr._backward_d(st)
-        self.graph_g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_g, pool=self.graph_fb.pool(), capture_error_mode="thread_local"):
-            tr._backward_g(st)
+            if st.get("two"):      # two-stream step: ONE graph with a fork / join (the branches run concurrently on replay)
+                tr._backward_both(st)
+            else:
+                tr._backward_d(st)
+        self.graph_g = None
+        if not st.get("two"):
+            self.graph_g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_g, pool=self.graph_fb.pool(), capture_error_mode="thread_local"):
+                tr._backward_g(st)
         self.static_out, self.static_logs = st["wave_out"].detach(), st["logs"]
         del st
         self.graph_opt = torch.cuda.CUDAGraph()
@@ -121,8 +126,9 @@ class GraphedTrainStep:
                 dst.copy_(src, non_blocking=True)
         self.graph_fb.replay()
         if self.tr.gan:
-            self.tr._reduce_grads("mpd", async_op=True)       # overlaps graph A2
-        self.graph_g.replay()
+            self.tr._reduce_grads("mpd", async_op=True)       # overlaps graph A2 (one-stream layout)
+        if self.graph_g is not None:
+            self.graph_g.replay()
         self.tr._reduce_grads("generator", async_op=True)
         self.tr._wait_reduces()
         self.graph_opt.replay()

@@ -101,7 +101,7 @@ class _LNGateFn(torch.autograd.Function):
                                                     None if later else _p(dg), None if later else _p(db), _p(ws), B, D, L, code,
                                                     _lib.current_stream(sz.device)), "ln_gate_bwd_ws")
                 return dy, dsz, dg.to(ctx.meta[0]), db.to(ctx.meta[1]), None
-            dgb = torch.zeros((2, D), dtype=torch.float32, device=sz.device)
+            dgb, = _lib.zeros_f32(sz.device, (2, D))
             _lib.check(lib.vmasr_ln_gate_bwd(_p(y), _p(sz), _p(dout), _p(g32), _p(b32), _p(stats[0]), _p(stats[1]), _p(dy), _p(dsz),
                                              _p(dgb[0]), _p(dgb[1]), B, D, L, code, _lib.current_stream(sz.device)), "ln_gate_bwd")
         return dy, dsz, dgb[0].to(ctx.meta[0]), dgb[1].to(ctx.meta[1]), None
@@ -134,7 +134,7 @@ class _LNGatePairsFn(torch.autograd.Function):
         with torch.cuda.device(sz.device):
             dys = torch.empty((2,) + tuple(y02.shape), dtype=torch.float32, device=sz.device)
             dsz = torch.empty_like(sz)
-            dgb = torch.zeros((2, D), dtype=torch.float32, device=sz.device)
+            dgb, = _lib.zeros_f32(sz.device, (2, D))
             _lib.check(_lib.lib().vmasr_ln_gate_pair_bwd(_p(y02), _p(y13), _p(sz), _p(dout), _p(g32), _p(b32), _p(stats[0]), _p(stats[1]),
                                                          _p(dys[0]), _p(dys[1]), _p(dsz), _p(dgb[0]), _p(dgb[1]), B, D, H, W,
                                                          _lib.torch_dtype_code(sz.dtype), _lib.current_stream(sz.device)), "ln_gate_pair_bwd")

@@ -469,16 +469,19 @@ class Trainer(BaseTrainer):
         sc, mag = self.multi_resolution_stft(wave_out.squeeze(1), wave_target.squeeze(1))
         return sc + mag
 
-    def _generator_losses(self, wave_out, wave_target, fmap_real=None, fake_pass=None):
+    def _generator_losses(self, wave_out, wave_target, fmap_real=None, fake_pass=None, parts=("signal", "mpd")):
+        """parts: "signal" = the losses on the waveform itself, "mpd" = the ones through the period discriminator (the two-stream
+        step evaluates them on different streams; the dict keeps the reference's order either way)."""
         cfg, out = self.config.TRAIN, {}
         wave_out = wave_out.float()
-        if "l1" in cfg.LOSSES.GEN:
-            out["l1"] = mae_loss(wave_out, wave_target)
-        if "l2" in cfg.LOSSES.GEN:
-            out["l2"] = mse_loss(wave_out, wave_target)
-        if "multi_resolution_stft" in cfg.LOSSES.GEN:
-            out["multi_resolution_stft"] = self._get_stft_loss(wave_out, wave_target)
-        if self.gan and "mpd" in cfg.ADVERSARIAL.DISCRIMINATORS:
+        if "signal" in parts:
+            if "l1" in cfg.LOSSES.GEN:
+                out["l1"] = mae_loss(wave_out, wave_target)
+            if "l2" in cfg.LOSSES.GEN:
+                out["l2"] = mse_loss(wave_out, wave_target)
+            if "multi_resolution_stft" in cfg.LOSSES.GEN:
+                out["multi_resolution_stft"] = self._get_stft_loss(wave_out, wave_target)
+        if "mpd" in parts and self.gan and "mpd" in cfg.ADVERSARIAL.DISCRIMINATORS:
             mpd = unwrap(self.models["mpd"])  # weights used as constants: no MPD gradients, no DDP hooks
             if fake_pass is not None:      # shared fake pass (see _forward_backward): scores / features already there
                 y_gen, fmap_gen = fake_pass
@@ -615,41 +618,99 @@ class Trainer(BaseTrainer):
                                   and os.environ.get("VMASR_LN_DEFER", "1") == "1")
         layernorm.reset_uses()
 
+    def _two_streams(self):
+        """The step on two HIP streams: the period discriminator's chip-filling MFMA kernels on a side stream,
+        the generator's ~1400 small launches on the main one.  Needs the shared fake pass (GPU, flat gradient buffers);
+        off in deterministic mode (the ordered-accumulation tickets are per kernel, not per stream)."""
+        if os.environ.get("VMASR_TWO_STREAM", "1") != "1" or os.environ.get("VMASR_DETERMINISTIC", "0") == "1":
+            return False
+        return self._share_fake_pass()
+
+    def _side_cus(self):
+        """-> context: CUs the discriminator's convolution kernels may take while the generator's kernels run beside them
+        (VMASR_SIDE_CUS, default 208 of 256; 0 = all)."""
+        from . import convgemm
+        return convgemm.cu_limit(int(os.environ.get("VMASR_SIDE_CUS", "208")))
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
+
     def _forward_losses(self, wave_input, wave_target, highcut):
         """generator forward -> discriminator + generator losses (one autograd graph; the D graph is built on the
         same D weights the G pass sees, so both backwards can run before either optimiser step).
         Returns the state the two backward phases consume."""
         acc = self._acc
         self._set_deferred_reductions()
-        with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
-            wave_out = self.models["generator"](wave_input, highcut)
         shared = self._share_fake_pass()
+        two = shared and self._two_streams()
+        dev_t = self.device.type
+        step_amp = lambda: torch.autocast(device_type=dev_t, dtype=torch.bfloat16, enabled=self.amp and self.amp_scope == "step")  # noqa: E731
         d_losses = {}
-        with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp and self.amp_scope == "step"):
-            # D loss first, with the same D weights the G pass sees (reference order, trainer/trainer.py:369-399)
-            with self._mpd_weights_once():
-                if shared:
-                    # The reference runs D(fake) twice per step on identical values (detached for the D loss, attached
-                    # for the G loss: trainer/trainer.py:376-384).  Here ONE pass over the fake signal carries both:
-                    # the G loss is back-propagated through it for input gradients only, the D loss for weight
-                    # gradients only (`backward(inputs=...)` + skip_weight_grads) — 1/8 fewer discriminator FLOPs.
-                    mpd = unwrap(self.models["mpd"])
+        if two:
+            # main stream: generator forward, losses on the waveform.   side stream: D(real) meanwhile, then D(fake) and
+            # the losses on its outputs.  autograd runs every backward node on its forward's stream, so the backward
+            # passes split the same way (see _backward_both).
+            import contextlib
+            main, side = torch.cuda.current_stream(self.device), self._side_stream()
+            mpd = unwrap(self.models["mpd"])
+            with contextlib.ExitStack() as weights:
+                side.wait_stream(main)                       # fork: last step's optimiser, this step's inputs
+                with torch.cuda.stream(side), step_amp(), self._side_cus():       # (beside the generator's forward)
+                    weights.enter_context(self._mpd_weights_once())
                     y_real, f_real = mpd.forward_single(wave_target)
-                    y_fake, f_fake = mpd.forward_single(wave_out.float())
+                with torch.autocast(device_type=dev_t, dtype=torch.bfloat16, enabled=self.amp):
+                    wave_out = self.models["generator"](wave_input, highcut)
+                wave_f = wave_out.float()
+                # the autograd graph is CUT here: the discriminator sees a leaf, whose gradient _backward_two() hands to the
+                # generator's backward — so the order in which the three backward pieces are issued is ours, not the engine's
+                wave_d = wave_f.detach().requires_grad_(True)
+                side.wait_stream(main)
+                wave_d.record_stream(side)
+                with torch.cuda.stream(side), step_amp():
+                    y_fake, f_fake = mpd.forward_single(wave_d)
                     d_losses = {"mpd": self.higi_gan_loss.discriminator_loss(y_real, y_fake)}
                     f_real = f_real.detach() if hasattr(f_real, "stacks") else [[f.detach() for f in fs] for fs in f_real]
-                    g_losses = self._generator_losses(wave_out, wave_target, f_real, fake_pass=(y_fake, f_fake))
-                else:
-                    d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
-                    g_losses = self._generator_losses(wave_out, wave_target, fmap_real)
-        total_g = sum(g_losses.values()) / acc
+                    g_side = self._generator_losses(wave_d, wave_target, f_real, fake_pass=(y_fake, f_fake), parts=("mpd",))
+                    total_d = sum(d_losses.values()) / acc
+                    g_mpd = sum(g_side.values()) / acc if g_side else None
+                with step_amp():
+                    g_losses = self._generator_losses(wave_f, wave_target, parts=("signal",))
+                    g_sig = sum(g_losses.values()) / acc if g_losses else None
+            main.wait_stream(side)                           # (the side stream's scalar losses are summed for the log on the main one)
+            for v in list(g_side.values()) + [total_d]:
+                v.record_stream(main)
+            g_losses.update(g_side)
+            two = {"wave_f": wave_f, "wave_d": wave_d, "g_sig": g_sig, "g_mpd": g_mpd}
+        else:
+            with torch.autocast(device_type=dev_t, dtype=torch.bfloat16, enabled=self.amp):
+                wave_out = self.models["generator"](wave_input, highcut)
+            with step_amp():
+                # D loss first, with the same D weights the G pass sees (reference order, trainer/trainer.py:369-399)
+                with self._mpd_weights_once():
+                    if shared:
+                        # The reference runs D(fake) twice per step on identical values (detached for the D loss, attached
+                        # for the G loss: trainer/trainer.py:376-384).  Here ONE pass over the fake signal carries both:
+                        # the G loss is back-propagated through it for input gradients only, the D loss for weight
+                        # gradients only (`backward(inputs=...)` + skip_weight_grads) — 1/8 fewer discriminator FLOPs.
+                        mpd = unwrap(self.models["mpd"])
+                        y_real, f_real = mpd.forward_single(wave_target)
+                        y_fake, f_fake = mpd.forward_single(wave_out.float())
+                        d_losses = {"mpd": self.higi_gan_loss.discriminator_loss(y_real, y_fake)}
+                        f_real = f_real.detach() if hasattr(f_real, "stacks") else [[f.detach() for f in fs] for fs in f_real]
+                        g_losses = self._generator_losses(wave_out, wave_target, f_real, fake_pass=(y_fake, f_fake))
+                    else:
+                        d_losses, fmap_real = self._discriminator_losses(wave_out, wave_target)
+                        g_losses = self._generator_losses(wave_out, wave_target, fmap_real)
+            total_d = sum(d_losses.values()) / acc if self.gan else None
+        with torch.set_grad_enabled(not two):      # (two streams: the pieces above carry the backward, this sum is the log's)
+            total_g = sum(g_losses.values()) / acc
         logs = {"total_loss": total_g.detach()}
         logs.update({f"generator/{k}": v.detach() for k, v in g_losses.items()})
-        total_d = None
         if self.gan:
-            total_d = sum(d_losses.values()) / acc
             logs["total_disc_loss"] = total_d.detach()
-        return {"wave_out": wave_out, "total_g": total_g, "total_d": total_d, "shared": shared, "logs": logs}
+        return {"wave_out": wave_out, "total_g": total_g, "total_d": total_d, "shared": shared, "two": two, "logs": logs}
 
     def _backward_d(self, st, zero=True):
         """Backward of the discriminator loss (weight gradients of the MPD) + packing into its flat buffer.
@@ -683,11 +744,65 @@ class Trainer(BaseTrainer):
             layernorm.reset_uses()
         self._gather_grads("generator")
 
-    def _forward_backward(self, wave_input, wave_target, highcut, zero=True):
-        """forward -> losses -> backward of the D loss -> backward of the G loss (no collectives, no optimiser)."""
-        st = self._forward_losses(wave_input, wave_target, highcut)
+    def _backward_two(self, st, zero=True):
+        """The backward passes of the two-stream step, issued in the order that lets them overlap (capture order is replay
+        enqueue order):  side: G losses -> through the discriminator -> d/d(wave)  [input gradients only]
+                         side: D loss -> discriminator weight gradients, packed            } beside each other
+                         main: d/d(wave) + the waveform losses -> generator, packed        }
+        then the main stream joins the side stream."""
+        from . import layernorm
+        from .discriminator import skip_weight_grads
+        tw = st["two"]
+        main, side = torch.cuda.current_stream(self.device), self._side_stream()
+        try:
+            with torch.cuda.stream(side):
+                if tw["g_mpd"] is not None:
+                    with skip_weight_grads():
+                        tw["g_mpd"].backward(inputs=[tw["wave_d"]], retain_graph=True)
+                handed = torch.cuda.Event()
+                handed.record(side)
+                if zero:
+                    self._zero_grads("mpd", self.optimizer_D)
+                with self._side_cus():                                            # (beside the generator's backward)
+                    st["total_d"].backward(inputs=self._grad_targets("mpd"))
+                self._gather_grads("mpd")
+            main.wait_event(handed)
+            if zero:
+                self._zero_grads("generator", self.optimizer_G)
+            roots, seeds = [], []
+            if tw["g_sig"] is not None:
+                roots.append(tw["g_sig"])
+                seeds.append(None)
+            gw = tw["wave_d"].grad
+            if gw is not None:
+                gw.record_stream(main)
+                roots.append(tw["wave_f"])
+                seeds.append(gw)
+            torch.autograd.backward(roots, seeds, inputs=self._grad_targets("generator"))
+        finally:
+            layernorm.DEFER_REDUCE = False
+            layernorm.reset_uses()
+        self._gather_grads("generator")
+        main.wait_stream(side)
+
+    def _backward_both(self, st, zero=True, after_d=None):
+        """Both backward passes in the order the step's stream layout wants.
+        One stream : D loss, [after_d(): the MPD all-reduce starts], G loss.
+        Two streams: _backward_two(), then after_d()."""
+        if st.get("two"):
+            self._backward_two(st, zero)
+            if after_d is not None:
+                after_d()
+            return
         self._backward_d(st, zero)
+        if after_d is not None:
+            after_d()
         self._backward_g(st, zero)
+
+    def _forward_backward(self, wave_input, wave_target, highcut, zero=True):
+        """forward -> losses -> both backward passes (no collectives, no optimiser)."""
+        st = self._forward_losses(wave_input, wave_target, highcut)
+        self._backward_both(st, zero)
         return st["wave_out"].detach(), st["logs"]
 
     def _share_fake_pass(self):
@@ -831,10 +946,7 @@ class Trainer(BaseTrainer):
         first, last = self._micro % self._acc == 0, (self._micro + 1) % self._acc == 0
         self._micro += 1
         st = self._forward_losses(wave_input, wave_target, highcut)
-        self._backward_d(st, zero=first)
-        if last and self.gan:
-            self._reduce_grads("mpd", async_op=True)        # overlaps the generator's backward
-        self._backward_g(st, zero=first)
+        self._backward_both(st, zero=first, after_d=(lambda: self._reduce_grads("mpd", async_op=True)) if last and self.gan else None)
         if last:
             self._reduce_grads("generator", async_op=True)
             self._wait_reduces()
