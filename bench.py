@@ -191,10 +191,30 @@ def run_point(config, args, device, rank, world, steps, warmup, timing, with_met
             trainer.train_step(*batch)
         torch.cuda.synchronize()
         _lib.prof_enable(False)
-        trainer._graphed = g_saved
         prof = _lib.prof_collect() if rank == 0 else {}
         if rank == 0:
             prof["__shapes__"] = {k: _lib.prof_collect_shapes(k) for k in prof if k in SCAN_KERNELS or k.startswith("sscan") or k.startswith("conv_mfma")}
+        if getattr(trainer, "_two_streams", lambda: False)():
+            # the step runs the discriminator's kernels BESIDE the generator's (two streams): the durations above are those of
+            # kernels sharing the chip.  Third pass, one stream: every kernel alone on the chip — its own roofline figure.
+            prev = os.environ.get("VMASR_TWO_STREAM")
+            os.environ["VMASR_TWO_STREAM"] = "0"
+            try:
+                _lib.prof_reset()
+                _lib.prof_enable(True)
+                for _ in range(steps):
+                    trainer.train_step(*batch)
+                torch.cuda.synchronize()
+                _lib.prof_enable(False)
+                if rank == 0:
+                    alone = _lib.prof_collect()
+                    alone["__shapes__"] = {k: _lib.prof_collect_shapes(k) for k in alone if k in SCAN_KERNELS or k.startswith("sscan")}
+                    prof["__unshared__"] = alone
+            finally:
+                if prev is None:
+                    del os.environ["VMASR_TWO_STREAM"]
+                else:
+                    os.environ["VMASR_TWO_STREAM"] = prev
     del trainer
     torch.cuda.empty_cache()
     return dt, graphed, per_rank, prof
@@ -213,7 +233,7 @@ def scan_summary(prof, steps):
     where a call still takes the unfused path; algorithmic bytes are counted once per op (the apply / single-pass kernels carry
     them)."""
     kern = {k: dict(v, avg_us=v["ms"] / v["launches"] * 1e3, gbs=v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)
-            for k, v in prof.items() if k != "__shapes__"}
+            for k, v in prof.items() if not k.startswith("__")}
     scan = {k: v for k, v in kern.items() if k.startswith("sscan") or k in SCAN_KERNELS}
     if not scan:
         return kern, None, None
@@ -286,6 +306,11 @@ def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, step
                            "frac": d["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d["avg_us"], "launches": d["launches"],
                            "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "traffic": None,
                            "selective_scan_op": op, "shapes": shape_table(prof, dom)}
+        if "__unshared__" in prof:          # (two-stream step: see main()'s roofline.shared_chip)
+            kern1, _, op1 = scan_summary(prof["__unshared__"], steps)
+            d1 = kern1[dom]
+            rec["roofline"]["unshared"] = {"kernel": dom, "achieved": d1["gbs"], "frac": d1["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d1["avg_us"],
+                                           "selective_scan_op": op1, "shapes": shape_table(prof["__unshared__"], dom)}
         rec["scan_alg_bytes_per_clip"] = op["alg_bytes_per_step"] / B if op else None
     top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:14]
     rec["top_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "ms_per_step": round(v["ms"] / steps, 3)} for k, v in top}
@@ -341,6 +366,8 @@ def main():
     timing = prof is not None
 
     B = config.DATA.BATCH_SIZE
+    two_stream = (config.TRAIN.ADVERSARIAL.ENABLE and os.environ.get("VMASR_TWO_STREAM", "1") == "1"
+                  and os.environ.get("VMASR_DETERMINISTIC", "0") != "1" and os.environ.get("VMASR_SHARE_FAKE_PASS", "1") == "1")
     out = {
         "metric": "audio clips/sec (train step) 48kHz n_fft=1024", "value": world * B * args.steps / dt,
         "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -355,8 +382,12 @@ def main():
                                f"AdamW); DIMS {config.MODEL.VSSM.DIMS}, d_state {config.MODEL.VSSM.SSM_D_STATE}, clip 122640 @48 kHz, n_fft 1024 hop 240",
                    "per_gpu_batch": B, "global_batch": B * world,
                    "parallelism": f"dp{world} (clip-sharded; one RCCL all-reduce per flat gradient buffer)",
-                   "execution": ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
-                                 "optimiser graph)") if graphed else "eager"},
+                   "execution": (("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): one forward + backward graph with a fork / "
+                                  "join — the period discriminator on a side stream beside the generator (trainer._two_streams), its convolution "
+                                  f"kernels on at most {os.environ.get('VMASR_SIDE_CUS', '192')} CUs while they overlap — and an optimiser graph")
+                                 if two_stream else
+                                 ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
+                                  "optimiser graph)")) if graphed else ("eager, two streams" if two_stream else "eager")},
     }
     out["distributed"] = dinfo     # what the process group actually was: world size, backend, RCCL version, every rank's device
     out["config"]["per_step_metrics"] = bool(args.with_metrics)
@@ -397,6 +428,19 @@ def main():
                 "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbs"], 1),
                                 "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in sorted(kern.items())},
             }
+            if "__unshared__" in prof:
+                kern1, dom1, op1 = scan_summary(prof["__unshared__"], args.steps)
+                d1 = kern1[dom]
+                out["roofline"]["shared_chip"] = (
+                    "the figures above are measured in the step as it runs: two streams, the period discriminator's MFMA kernels beside the "
+                    "generator's (rocprofv3 of this command sees the same durations); `unshared` = the same kernels in a one-stream pass of "
+                    "the same K steps (VMASR_TWO_STREAM=0), each alone on the chip — the kernel's own roofline fraction")
+                out["roofline"]["unshared"] = {
+                    "kernel": dom, "achieved": d1["gbs"], "frac": d1["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d1["avg_us"],
+                    "frac_traffic": (traffic / (d1["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "selective_scan_op": op1, "shapes": shape_table(prof["__unshared__"], dom),
+                    "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbs"], 1),
+                                    "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in sorted(kern1.items())}}
     if rank == 0 and world == 1 and not args.no_extra_points and args.workload == "vm_asr_48k_MPD" and not args.batch and not args.no_graphs:
         # driver-visible secondary operating points: the reference-precision discriminator GEMMs, and
         # configs[4]'s yaml (DIMS 32, batch 8) with its own roofline block.  Never part of `value`.

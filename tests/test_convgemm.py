@@ -165,6 +165,6 @@ def test_conv_mfma_cu_limit_changes_nothing_but_the_grid():
     for cus in (8, 24, 200):
         with cg.cu_limit(cus):
             got = run()
-        assert int(cg._lib.lib().vmasr_conv_get_cu_limit()) == 0
+        assert int(cg._lib.lib().vmasr_conv_get_cu_limit()) == 0 and cg._LIMIT["cus"] == 0
         for a, b in zip(ref, got):
             assert torch.equal(a, b), cus

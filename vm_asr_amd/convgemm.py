@@ -16,21 +16,31 @@ def supported(Cin, Cout, k, stride):
     return bool(_lib.lib().vmasr_conv_mfma_supported(int(Cin), int(Cout), int(k), int(stride)))
 
 
+_LIMIT = {"cus": 0, "min_channels": 0}
+
+
 class cu_limit:
-    """with cu_limit(n): the conv_mfma kernels launched inside occupy at most n CUs (persistent tile loops); 0 / None = all.
+    """with cu_limit(n[, min_channels]): the conv_mfma kernels launched inside occupy at most n CUs (persistent tile loops) — those of
+    layers with max(Cin, Cout) >= min_channels, the others keep the whole chip; 0 / None = no limit.
     Host-side launch geometry only — the results do not depend on it."""
 
-    def __init__(self, cus):
-        self.cus = int(cus or 0)
+    def __init__(self, cus, min_channels=0):
+        self.new = {"cus": int(cus or 0), "min_channels": int(min_channels or 0)}
 
     def __enter__(self):
-        self.prev = int(_lib.lib().vmasr_conv_get_cu_limit())
-        _lib.lib().vmasr_conv_set_cu_limit(self.cus)
+        self.prev = dict(_LIMIT)
+        _LIMIT.update(self.new)
         return self
 
     def __exit__(self, *exc):
-        _lib.lib().vmasr_conv_set_cu_limit(self.prev)
+        _LIMIT.update(self.prev)
+        _lib.lib().vmasr_conv_set_cu_limit(0)
         return False
+
+
+def _apply_limit(Cin, Cout):
+    lim = _LIMIT["cus"] if max(Cin, Cout) >= _LIMIT["min_channels"] else 0
+    _lib.lib().vmasr_conv_set_cu_limit(lim)
 
 
 def _slots(n):
@@ -73,6 +83,7 @@ def conv_fwd(xh, xl, wh, wl, bias, geom, k, stride, pad, rows_out, act=True, wan
             s.ch, s.cl = _ptr(yh, i, rows_out * Cout * 2), _ptr(yl, i, rows_out * Cout * 2)
             s.bias = _ptr(bias, i, Cout * 4)
             s.nseq, s.H = int(nseq), int(H)
+        _apply_limit(Cin, Cout)
         _lib.check(_lib.lib().vmasr_conv_mfma_fwd(sl, n, Cin, Cout, k, stride, pad, rows_out, int(bool(act)),
                                                   _lib.current_stream(dev)), "conv_mfma_fwd")
     return pre, y, yh, yl
@@ -95,6 +106,7 @@ def conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, rows_in):
             s.bh, s.bl = _ptr(wth, i, Cin * k * Cout * 2), _ptr(wtl, i, Cin * k * Cout * 2)
             s.c0 = _ptr(dx, i, rows_in * Cin * 4)
             s.nseq, s.H = int(nseq), int(H)
+        _apply_limit(Cin, Cout)
         _lib.check(_lib.lib().vmasr_conv_mfma_dgrad(sl, n, Cin, Cout, k, stride, pad, rows_in, _lib.current_stream(dev)),
                    "conv_mfma_dgrad")
     return dx
@@ -132,6 +144,7 @@ def conv_wgrad(gh, gl, xh, xl, geom, k, stride, pad, splits=None):
             s.bh, s.bl = _ptr(xh, i, rows_in * Cin * 2), _ptr(xl, i, rows_in * Cin * 2)
             s.c0 = _ptr(parts, i, splits * Cout * k * Cin * 4)
             s.nseq, s.H = int(nseq), int(H)
+        _apply_limit(Cin, Cout)
         _lib.check(_lib.lib().vmasr_conv_mfma_wgrad(sl, n, Cin, Cout, k, stride, pad, splits, _lib.current_stream(dev)),
                    "conv_mfma_wgrad")
         if splits == 1:
