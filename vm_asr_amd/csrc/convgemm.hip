@@ -367,6 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
     constexpr int STAGE = 2 * TILE_G + 2 * TILE_X;              // g_hi, g_lo, x_hi, x_lo
     constexpr int CG = BCO / 8, CX = BKC / 8;                   // 16-byte chunks per row
     constexpr int PG = CW_BR * CG / NT, PX = (CW_BR * CX + NT - 1) / NT;   // staging passes (one chunk per thread and pass)
+    constexpr bool MID_STORE = MF == 16 && BCO * BKC >= 65536;   // (256 x 256: 567 -> 500 us, 1 020 -> 915 us on the two wide layers; the small tiles measured no gain)
     constexpr bool X_PART = CW_BR * CX < NT;                    // narrow x tile (32 channels): only the first CW_BR * CX threads stage it
     static_assert(PG >= 1 && (CW_BR * CG) % NT == 0 && (X_PART || (CW_BR * CX) % NT == 0), "staging geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -497,6 +498,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
             }
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
+                // the next stage's registers go to LDS in the MIDDLE of the MFMA sequence (their loads were issued a half step ago;
+                // nobody reads buf ^ 1 in this step): the ds_writes run under the second half's MFMAs instead of after them
+                if (MID_STORE && i == TI / 2 && more) CW_STORE(buf ^ 1);
                 const bf16x8 ah = cw_frag<RBG, 16>(s, 0, wm * WTM + i * 16, lane);
                 const bf16x8 al = cw_frag<RBG, 16>(s + TILE_G, 0, wm * WTM + i * 16, lane);
 #pragma unroll
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_wgrad_kernel(const 
                 }
             }
         }
-        if (more) CW_STORE(buf ^ 1);
+        if (!MID_STORE && more) CW_STORE(buf ^ 1);
         __syncthreads();
     }
 #undef CW_LOAD
