@@ -384,7 +384,7 @@ def main():
                    "parallelism": f"dp{world} (clip-sharded; one RCCL all-reduce per flat gradient buffer)",
                    "execution": (("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): one forward + backward graph with a fork / "
                                   "join — the period discriminator on a side stream beside the generator (trainer._two_streams), its convolution "
-                                  f"kernels on at most {os.environ.get('VMASR_SIDE_CUS', '192')} CUs while they overlap — and an optimiser graph")
+                                  f"kernels on at most {os.environ.get('VMASR_SIDE_CUS', '160')} CUs while they overlap — and an optimiser graph")
                                  if two_stream else
                                  ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
                                   "optimiser graph)")) if graphed else ("eager, two streams" if two_stream else "eager")},

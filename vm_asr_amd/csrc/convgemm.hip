@@ -548,8 +548,15 @@ int g_cg_cu_limit = 0;
 
 int cg_grid(int tiles, size_t smem) {
     if (g_cg_cu_limit <= 0) return tiles;
+    // Workgroups per CU by LDS; the limit is soft by 24 CUs where that saves a whole round of tiles (200 or 400 tiles under a limit of
+    // 192: 200 workgroups -> 1 / 2 rounds instead of 2 / 3), and the grid is the SMALLEST that keeps the number of rounds (480 tiles:
+    // 3 rounds either way -> 160 workgroups, not 192: the other stream gets the CUs that would idle in a ragged last round).
     const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(smem, 1)));
-    return std::min(tiles, g_cg_cu_limit * per_cu / 8 * 8);
+    static const int slack = [] { const char *e = getenv("VMASR_CONV_CU_SLACK"); return e ? atoi(e) : 24; }();
+    const int cap = std::min(256, g_cg_cu_limit + slack) * per_cu;
+    const int rounds = (tiles + cap - 1) / cap;
+    const int g = ((tiles + rounds - 1) / rounds + 7) / 8 * 8;
+    return std::min(tiles, std::min(g, cap));
 }
 
 template <int BM, int BN, int WM, int WN, int MF>

@@ -628,10 +628,10 @@ class Trainer(BaseTrainer):
 
     def _side_cus(self):
         """-> context: CUs the discriminator's convolution kernels may take while the generator's kernels run beside them
-        (VMASR_SIDE_CUS, default 192 of 256 — 160 ... 192 measured alike, 208+ and <= 144 slower —; 0 = all;
+        (VMASR_SIDE_CUS, default 160 of 256, soft by 24: csrc/convgemm.hip cg_grid — caps of 168 ... 184 workgroups measured alike, 160 and 200+ slower —; 0 = all;
         VMASR_SIDE_CUS_MINC: only layers at least that wide)."""
         from . import convgemm
-        return convgemm.cu_limit(int(os.environ.get("VMASR_SIDE_CUS", "192")), int(os.environ.get("VMASR_SIDE_CUS_MINC", "0")))
+        return convgemm.cu_limit(int(os.environ.get("VMASR_SIDE_CUS", "160")), int(os.environ.get("VMASR_SIDE_CUS_MINC", "0")))
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
