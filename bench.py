@@ -186,15 +186,16 @@ def run_point(config, args, device, rank, world, steps, warmup, timing, with_met
     if timing:
         g_saved, trainer._graphed = trainer._graphed, None
         _lib.prof_reset()
-        _lib.prof_enable(True)
-        for _ in range(steps):
-            trainer.train_step(*batch)
-        torch.cuda.synchronize()
-        _lib.prof_enable(False)
+        if not (getattr(trainer, "_two_streams", lambda: False)() and getattr(args, "timing_pass", "both") == "unshared"):
+            _lib.prof_enable(True)
+            for _ in range(steps):
+                trainer.train_step(*batch)
+            torch.cuda.synchronize()
+            _lib.prof_enable(False)
         prof = _lib.prof_collect() if rank == 0 else {}
         if rank == 0:
             prof["__shapes__"] = {k: _lib.prof_collect_shapes(k) for k in prof if k in SCAN_KERNELS or k.startswith("sscan") or k.startswith("conv_mfma")}
-        if getattr(trainer, "_two_streams", lambda: False)():
+        if getattr(trainer, "_two_streams", lambda: False)() and getattr(args, "timing_pass", "both") != "shared":
             # the step runs the discriminator's kernels BESIDE the generator's (two streams): the durations above are those of
             # kernels sharing the chip.  Third pass, one stream: every kernel alone on the chip — its own roofline figure.
             prev = os.environ.get("VMASR_TWO_STREAM")
@@ -299,6 +300,9 @@ def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, step
            "execution": "HIP graph replay" if graphed else "eager"}
     if tried:
         rec["out_of_memory_at_batch"] = tried
+    shared_prof = prof if "__unshared__" in prof and any(not k.startswith("__") for k in prof) else None
+    if "__unshared__" in prof:          # (two-stream step: kernels alone on the chip, see main()'s roofline block)
+        prof = prof["__unshared__"]
     kern, dom, op = scan_summary(prof, steps)
     if dom:
         d = kern[dom]
@@ -306,11 +310,11 @@ def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, step
                            "frac": d["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d["avg_us"], "launches": d["launches"],
                            "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "traffic": None,
                            "selective_scan_op": op, "shapes": shape_table(prof, dom)}
-        if "__unshared__" in prof:          # (two-stream step: see main()'s roofline.shared_chip)
-            kern1, _, op1 = scan_summary(prof["__unshared__"], steps)
-            d1 = kern1[dom]
-            rec["roofline"]["unshared"] = {"kernel": dom, "achieved": d1["gbs"], "frac": d1["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d1["avg_us"],
-                                           "selective_scan_op": op1, "shapes": shape_table(prof["__unshared__"], dom)}
+        if shared_prof is not None:
+            kern2, _, op2 = scan_summary(shared_prof, steps)
+            d2 = kern2[dom]
+            rec["roofline"]["shared_chip"] = {"kernel": dom, "achieved": d2["gbs"], "frac": d2["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d2["avg_us"],
+                                              "selective_scan_op": op2}
         rec["scan_alg_bytes_per_clip"] = op["alg_bytes_per_step"] / B if op else None
     top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:14]
     rec["top_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "ms_per_step": round(v["ms"] / steps, 3)} for k, v in top}
@@ -343,6 +347,9 @@ def main():
     ap.add_argument("--with-metrics", action="store_true",
                     help="evaluate SNR / LSD / LSD-HF / LSD-LF on the HIP STFT and read them on the host every step, as trainer/trainer.py:179-182 does")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timing-pass", choices=["both", "shared", "unshared"], default="both",
+                    help="two-stream step: which eager HIP-event passes follow the timed region — the step as it runs (kernels of both streams "
+                         "sharing the chip), a one-stream pass (every kernel alone on the chip: the `roofline` figures), or both (default)")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     args = ap.parse_args()
     if os.environ.get("VMASR_BENCH_WATCHDOG"):      # debugging aid: dump all stacks and exit if the run wedges
@@ -384,7 +391,8 @@ def main():
                    "parallelism": f"dp{world} (clip-sharded; one RCCL all-reduce per flat gradient buffer)",
                    "execution": (("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): one forward + backward graph with a fork / "
                                   "join — the period discriminator on a side stream beside the generator (trainer._two_streams), its convolution "
-                                  f"kernels on at most {os.environ.get('VMASR_SIDE_CUS', '160')} CUs while they overlap — and an optimiser graph")
+                                  f"kernels on at most {os.environ.get('VMASR_SIDE_CUS_FWD', os.environ.get('VMASR_SIDE_CUS', '128'))} (forward) / {os.environ.get('VMASR_SIDE_CUS', '160')} (backward) CUs, "
+                                  "soft by 24, while they overlap — and an optimiser graph")
                                  if two_stream else
                                  ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
                                   "optimiser graph)")) if graphed else ("eager, two streams" if two_stream else "eager")},
@@ -394,6 +402,12 @@ def main():
     if per_rank is not None:
         out["per_rank"] = per_rank
     if rank == 0 and timing:
+        # two-stream step: `roofline` is each kernel ALONE on the chip (the one-stream pass: the kernel's own roofline fraction, comparable with
+        # earlier rounds and with profiles/*_onestream_kernel_stats.csv); the durations in the step as it runs, where the generator's kernels
+        # share the chip with the discriminator's, are `roofline.shared_chip` (profiles/*_trainstep_kernel_stats.csv)
+        shared_prof = prof if "__unshared__" in prof and any(not k.startswith("__") for k in prof) else None
+        if "__unshared__" in prof:
+            prof = prof["__unshared__"]
         kern, dom, op = scan_summary(prof, args.steps)
         if dom:
             d = kern[dom]
@@ -422,25 +436,25 @@ def main():
                                     "ss2d_* kernels: the reference contract's Delta/B/C/direction streams that never reach HBM here "
                                     "are part of it, so `traffic` << algorithmic bytes is the fusion, not over-fetch)",
                 "avg_launch_us": d["avg_us"],
-                "timed_in": "eager pass of the same K steps right after the timed region (HIP events on the launch stream)",
+                "timed_in": "eager pass of the same K steps right after the timed region (HIP events on the launch stream)" +
+                            (", on ONE stream (see `chip`)" if two_stream and args.timing_pass != "shared" else ""),
                 "launches": d["launches"], "alg_bytes_per_launch": d["alg_bytes"] / d["launches"],
                 "selective_scan_op": op,
                 "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbs"], 1),
                                 "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in sorted(kern.items())},
             }
-            if "__unshared__" in prof:
-                kern1, dom1, op1 = scan_summary(prof["__unshared__"], args.steps)
-                d1 = kern1[dom]
-                out["roofline"]["shared_chip"] = (
-                    "the figures above are measured in the step as it runs: two streams, the period discriminator's MFMA kernels beside the "
-                    "generator's (rocprofv3 of this command sees the same durations); `unshared` = the same kernels in a one-stream pass of "
-                    "the same K steps (VMASR_TWO_STREAM=0), each alone on the chip — the kernel's own roofline fraction")
-                out["roofline"]["unshared"] = {
-                    "kernel": dom, "achieved": d1["gbs"], "frac": d1["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d1["avg_us"],
-                    "frac_traffic": (traffic / (d1["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                    "selective_scan_op": op1, "shapes": shape_table(prof["__unshared__"], dom),
+            out["roofline"]["chip"] = ("kernel alone on the chip: one-stream eager pass (VMASR_TWO_STREAM=0) of the same K steps" if two_stream and args.timing_pass != "shared"
+                                       else "step as it runs" + (": kernels of the two streams share the chip" if two_stream else ""))
+            if shared_prof is not None:
+                kern2, _, op2 = scan_summary(shared_prof, args.steps)
+                d2 = kern2[dom]
+                out["roofline"]["shared_chip"] = {
+                    "note": "the same kernels timed in the step as it runs — two streams, the period discriminator's MFMA kernels beside the generator's "
+                            "(what rocprofv3 of the two-stream step sees): durations of kernels that have a share of the chip, not a statement about the kernels",
+                    "kernel": dom, "achieved": d2["gbs"], "frac": d2["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d2["avg_us"],
+                    "selective_scan_op": op2,
                     "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbs"], 1),
-                                    "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in sorted(kern1.items())}}
+                                    "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in sorted(kern2.items())}}
     if rank == 0 and world == 1 and not args.no_extra_points and args.workload == "vm_asr_48k_MPD" and not args.batch and not args.no_graphs:
         # driver-visible secondary operating points: the reference-precision discriminator GEMMs, and
         # configs[4]'s yaml (DIMS 32, batch 8) with its own roofline block.  Never part of `value`.

@@ -15,7 +15,7 @@ cp $O/pmc_traffic.json profiles/r04_pmc_traffic.json          # (on the box: the
 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/gpu_parity.log 2>&1; tail -n 3 $O/gpu_parity.log
 timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cut -c1-260 $O/bench.json
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o e -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-points > $O/bench_prof.json 2> /tmp/prof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o e -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-points --timing-pass shared > $O/bench_prof.json 2> /tmp/prof.err
 find /tmp/prof_e -name "*kernel_stats.csv" -exec cp {} $O/trainstep_kernel_stats.csv \;
 VMASR_TWO_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_1 -o e -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-points > $O/bench_prof_onestream.json 2> /tmp/prof1.err
 find /tmp/prof_1 -name "*kernel_stats.csv" -exec cp {} $O/trainstep_onestream_kernel_stats.csv \;
@@ -50,5 +50,6 @@ VMASR_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-n
     bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/bench_2proc_gloo.log 2>&1
 python tools/rccl_single_rank_probe.py > $O/rccl_single_rank.log 2>&1
 python tools/kcat.py $O/trainstep_kernel_stats.csv 49 30
+python tools/kcat.py $O/trainstep_onestream_kernel_stats.csv 49 12
 python tools/kcat.py $O/gonly_b4_kernel_stats.csv 49 12
 for f in b8 gonly_b35 gonly_b4 amp_step onestream; do cut -c1-200 $O/bench_$f.json; done; tail -n 2 $O/bench_2proc_gloo.log | cut -c1-300

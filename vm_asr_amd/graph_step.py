@@ -1,17 +1,30 @@
 """HIP-graph capture of the training step (torch.cuda.CUDAGraph = hipGraph on ROCm).
 
-The step issues ~4 000 small kernels (the model is 3 M parameters; most launches are a few
-microseconds), so eager execution is bound by host launch overhead, not by the GPU.  Three graphs:
+The step issues ~1 600 kernels, most of them a few microseconds long (the generator is 3 M parameters), so eager execution is
+bound by host launch overhead, not by the GPU.
+
+Two-stream layout (default on the GPU: trainer._two_streams) — TWO graphs:
+
+    graph A   one graph with a fork / join.  main stream: G forward -> waveform losses -> ... -> G backward -> pack G gradient;
+              side stream: D(real) beside the G forward, then D(fake), the losses on its outputs, their backward down to d/d(wave)
+              (input gradients only), then the D loss' backward + pack of the MPD gradient BESIDE the G backward.  Branches of one
+              captured graph run concurrently on replay (a graph launch as a whole serialises with every other stream: measured,
+              tools/overlap_probe*.py), and nodes are enqueued in capture order — which is why _backward_two() issues the D loss'
+              backward before the generator's.
+    (eager)   async RCCL all-reduces of the MPD flat buffer (164 MB) and the generator's (9 MB)   [world_size > 1 only]
+    graph B   AdamW step for G and for D (capturable optimisers) + refresh of the bf16 shadow weights
+
+One-stream layout (VMASR_TWO_STREAM=0, deterministic mode, no shared fake pass) — three graphs:
 
     graph A1  G forward -> D loss + G losses -> backward(D loss) -> pack the MPD gradient
     (eager)   async RCCL all-reduce of the MPD flat buffer (164 MB)  [world_size > 1 only] — runs on RCCL's
               stream WHILE graph A2 replays, i.e. hidden behind the generator's backward
     graph A2  backward(G loss) -> pack the generator gradient
     (eager)   async all-reduce of the generator flat buffer (9 MB), join both collectives
-    graph B   AdamW step for G and for D (capturable optimisers) + refresh of the bf16 shadow weights
+    graph B   as above
 
-A1 and A2 share one memory pool and one autograd graph (built while A1 is captured, consumed while A2 is — the
-fwd/bwd split torch.cuda.make_graphed_callables uses).  The learning rate is a device tensor (trainer.lr_to_device),
+The graphs of a layout share one memory pool and one autograd graph (built while the first is captured, consumed while the
+next is — the fwd/bwd split torch.cuda.make_graphed_callables uses).  The learning rate is a device tensor (trainer.lr_to_device),
 so a scheduler update between replays takes effect in graph B.
 
 The library's own kernels are launched on the capturing stream through ctypes, so they are part of

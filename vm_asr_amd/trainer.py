@@ -626,12 +626,15 @@ class Trainer(BaseTrainer):
             return False
         return self._share_fake_pass()
 
-    def _side_cus(self):
+    def _side_cus(self, forward=False):
         """-> context: CUs the discriminator's convolution kernels may take while the generator's kernels run beside them
         (VMASR_SIDE_CUS, default 160 of 256, soft by 24: csrc/convgemm.hip cg_grid — caps of 168 ... 184 workgroups measured alike, 160 and 200+ slower —; 0 = all;
         VMASR_SIDE_CUS_MINC: only layers at least that wide)."""
         from . import convgemm
-        return convgemm.cu_limit(int(os.environ.get("VMASR_SIDE_CUS", "160")), int(os.environ.get("VMASR_SIDE_CUS_MINC", "0")))
+        cus = os.environ.get("VMASR_SIDE_CUS", "160")
+        if forward:      # D(real) has slack beside the generator's forward, which everything else waits for: a tighter limit (96 ... 128 alike, 144+ slower)
+            cus = os.environ.get("VMASR_SIDE_CUS_FWD", "128" if "VMASR_SIDE_CUS" not in os.environ else cus)
+        return convgemm.cu_limit(int(cus), int(os.environ.get("VMASR_SIDE_CUS_MINC", "0")))
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -658,7 +661,7 @@ class Trainer(BaseTrainer):
             mpd = unwrap(self.models["mpd"])
             with contextlib.ExitStack() as weights:
                 side.wait_stream(main)                       # fork: last step's optimiser, this step's inputs
-                with torch.cuda.stream(side), step_amp(), self._side_cus():       # (beside the generator's forward)
+                with torch.cuda.stream(side), step_amp(), self._side_cus(forward=True):       # (beside the generator's forward)
                     weights.enter_context(self._mpd_weights_once())
                     y_real, f_real = mpd.forward_single(wave_target)
                 with torch.autocast(device_type=dev_t, dtype=torch.bfloat16, enabled=self.amp):
