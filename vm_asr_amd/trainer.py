@@ -14,7 +14,8 @@ not have (README.md:31):
     (model/model.py:1187) — they are left out of the flat buffer / the DDP reducer statically
     instead of paying `find_unused_parameters` every step;
   * the step is replayed as two HIP graphs (graph_step.py): forward + losses + both backwards +
-    gradient packing, then the fused AdamW steps + bf16 shadow-weight refresh;
+    gradient packing — with the discriminator on a side stream BESIDE the generator (fork / join inside the graph:
+    _two_streams, _forward_losses, _backward_two; DESIGN.md 4g) —, then the fused AdamW steps + bf16 shadow-weight refresh;
   * the generator's adversarial/feature losses run through the discriminator with its
     parameters frozen, so the 164 MB MPD gradient is produced and all-reduced once per step
     (the reference fills and discards it during the G update, trainer/trainer.py:428-438);
