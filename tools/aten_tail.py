@@ -23,8 +23,13 @@ for _ in range(3):
     tr.train_step(*batch)
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
+fwd_only = os.environ.get("TAIL_FWD_ONLY") == "1"      # the generator's forward alone (autocast as in the step), autograd graph recorded
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    tr.train_step(*batch)
+    if fwd_only:
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            out = tr.models["generator"](batch[0], batch[2])
+    else:
+        tr.train_step(*batch)
     torch.cuda.synchronize()
 rows = []
 from torch.autograd import DeviceType  # noqa: E402

@@ -635,7 +635,7 @@ class Trainer(BaseTrainer):
         cus = os.environ.get("VMASR_SIDE_CUS", "160")
         if forward:      # D(real) has slack beside the generator's forward, which everything else waits for: a tighter limit (96 ... 128 alike, 144+ slower)
             cus = os.environ.get("VMASR_SIDE_CUS_FWD", "128" if "VMASR_SIDE_CUS" not in os.environ else cus)
-        return convgemm.cu_limit(int(cus), int(os.environ.get("VMASR_SIDE_CUS_MINC", "0")))
+        return convgemm.cu_limit(int(cus), 0 if forward else int(os.environ.get("VMASR_SIDE_CUS_MINC", "0")))
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
