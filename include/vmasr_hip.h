@@ -644,6 +644,9 @@ const char *vmasr_prof_name(int kernel_id);
 int vmasr_prof_collect(int kernel_id, int64_t *launches, double *total_ms, double *alg_bytes);
 /* the same per CALL SHAPE: launches of `kernel_id` grouped by their algorithmic byte count (<= max_groups groups, in order of
  * first appearance); returns the number of groups filled, negative on a HIP error */
+/* debug aid: *dst (device memory) = the device's constant-rate clock (100 MHz ticks) when `stream` reaches this point; a kernel launch,
+ * hence capturable into a HIP graph (tools/phase_probe.py) */
+int vmasr_mark_time(uint64_t *dst, vmasr_stream_t stream);
 int vmasr_prof_collect_shapes(int kernel_id, int max_groups, double *group_bytes, int64_t *group_launches, double *group_ms);
 
 #ifdef __cplusplus

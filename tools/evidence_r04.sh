@@ -35,6 +35,7 @@ python bench.py --batch 8 --no-cpu-baseline --no-extra-points > $O/bench_b8.json
 python bench.py --workload vm_asr_48k --no-cpu-baseline > $O/bench_gonly_b35.json 2> /dev/null
 python bench.py --amp-scope step --no-cpu-baseline --no-extra-points > $O/bench_amp_step.json 2> /dev/null
 VMASR_TWO_STREAM=0 python bench.py --no-cpu-baseline --no-extra-points > $O/bench_onestream.json 2> /dev/null
+python tools/phase_probe.py 2>&1 | grep -v amdgpu | tail -n 8 > $O/phase_probe.log; echo '--- VMASR_SIDE_CUS=0 (no CU limit)' >> $O/phase_probe.log; VMASR_SIDE_CUS=0 python tools/phase_probe.py 2>&1 | grep -v amdgpu | tail -n 8 >> $O/phase_probe.log
 python tools/overlap_probe.py 4 2>&1 | grep -v amdgpu > $O/overlap_probe.log
 python tools/overlap_probe2.py 2>&1 | grep -v amdgpu > $O/overlap_probe2.log
 python tools/overlap_probe3.py 2>&1 | grep -v amdgpu > $O/overlap_probe3.log

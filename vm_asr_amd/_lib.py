@@ -132,6 +132,7 @@ SYMBOLS = {
     "vmasr_weight_prep_split": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_gelu_bwd_split": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_conv_mfma_supported": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
+    "vmasr_mark_time": (ctypes.c_int, [c_vp, c_vp]),
     "vmasr_conv_set_cu_limit": (None, [c_i32]),
     "vmasr_conv_get_cu_limit": (c_i32, []),
     "vmasr_conv_mfma_fwd": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),

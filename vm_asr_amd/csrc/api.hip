@@ -145,3 +145,17 @@ VMASR_EXPORT int vmasr_prof_collect_shapes(int kid, int max_groups, double *grou
     }
     return ng;
 }
+
+
+// Debug aid: the device's constant-rate clock (100 MHz) written to *dst when the stream reaches this point.  A kernel, so it can be captured
+// into a HIP graph (timing events recorded in a capture cannot be read after a replay on ROCm 7.2): tools/phase_probe.py marks the phases of the
+// two-stream step with it.
+namespace {
+__global__ void mark_time_kernel(unsigned long long *dst) { *dst = wall_clock64(); }
+}  // namespace
+
+VMASR_EXPORT int vmasr_mark_time(uint64_t *dst, vmasr_stream_t stream) {
+    VMASR_REQUIRE(dst, VMASR_EINVAL, "mark_time: null destination");
+    hipLaunchKernelGGL(mark_time_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long *>(dst));
+    return vmasr::check_launch("mark_time");
+}

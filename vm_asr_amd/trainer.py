@@ -637,6 +637,18 @@ class Trainer(BaseTrainer):
             cus = os.environ.get("VMASR_SIDE_CUS_FWD", "128" if "VMASR_SIDE_CUS" not in os.environ else cus)
         return convgemm.cu_limit(int(cus), 0 if forward else int(os.environ.get("VMASR_SIDE_CUS_MINC", "0")))
 
+    def _mark(self, name, stream=None):
+        """VMASR_PHASE_EVENTS=1 (dev aid, tools/phase_probe.py): the device clock written to a buffer when `stream` reaches this point of the step
+        (vmasr_mark_time: a one-thread kernel, so it is captured into the step's graph and a replay yields the step's real timeline)."""
+        if os.environ.get("VMASR_PHASE_EVENTS") != "1":
+            return
+        from . import _lib
+        if not hasattr(self, "phase_marks"):
+            self.phase_marks, self._phase_buf = {}, torch.zeros(64, dtype=torch.int64, device=self.device)
+        slot = self.phase_marks.setdefault(name, len(self.phase_marks))
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        _lib.check(_lib.lib().vmasr_mark_time(self._phase_buf.data_ptr() + 8 * slot, st.cuda_stream), "mark_time")
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(self.device)
@@ -661,13 +673,16 @@ class Trainer(BaseTrainer):
             main, side = torch.cuda.current_stream(self.device), self._side_stream()
             mpd = unwrap(self.models["mpd"])
             with contextlib.ExitStack() as weights:
+                self._mark("start", main)
                 side.wait_stream(main)                       # fork: last step's optimiser, this step's inputs
                 with torch.cuda.stream(side), step_amp(), self._side_cus(forward=True):       # (beside the generator's forward)
                     weights.enter_context(self._mpd_weights_once())
                     y_real, f_real = mpd.forward_single(wave_target)
+                    self._mark("d_real_fwd_end", side)
                 with torch.autocast(device_type=dev_t, dtype=torch.bfloat16, enabled=self.amp):
                     wave_out = self.models["generator"](wave_input, highcut)
                 wave_f = wave_out.float()
+                self._mark("g_fwd_end", main)
                 # the autograd graph is CUT here: the discriminator sees a leaf, whose gradient _backward_two() hands to the
                 # generator's backward — so the order in which the three backward pieces are issued is ours, not the engine's
                 wave_d = wave_f.detach().requires_grad_(True)
@@ -680,6 +695,7 @@ class Trainer(BaseTrainer):
                     g_side = self._generator_losses(wave_d, wave_target, f_real, fake_pass=(y_fake, f_fake), parts=("mpd",))
                     total_d = sum(d_losses.values()) / acc
                     g_mpd = sum(g_side.values()) / acc if g_side else None
+                    self._mark("d_fake_fwd_losses_end", side)
                 with step_amp():
                     g_losses = self._generator_losses(wave_f, wave_target, parts=("signal",))
                     g_sig = sum(g_losses.values()) / acc if g_losses else None
@@ -766,11 +782,13 @@ class Trainer(BaseTrainer):
                         tw["g_mpd"].backward(inputs=[tw["wave_d"]], retain_graph=True)
                 handed = torch.cuda.Event()
                 handed.record(side)
+                self._mark("g_dgrad_end", side)
                 if zero:
                     self._zero_grads("mpd", self.optimizer_D)
                 with self._side_cus():                                            # (beside the generator's backward)
                     st["total_d"].backward(inputs=self._grad_targets("mpd"))
                 self._gather_grads("mpd")
+                self._mark("d_bwd_end", side)
             main.wait_event(handed)
             if zero:
                 self._zero_grads("generator", self.optimizer_G)
@@ -788,7 +806,9 @@ class Trainer(BaseTrainer):
             layernorm.DEFER_REDUCE = False
             layernorm.reset_uses()
         self._gather_grads("generator")
+        self._mark("g_bwd_end", main)
         main.wait_stream(side)
+        self._mark("join", main)
 
     def _backward_both(self, st, zero=True, after_d=None):
         """Both backward passes in the order the step's stream layout wants.
