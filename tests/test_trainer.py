@@ -308,6 +308,27 @@ def test_two_stream_step_gives_the_same_gradients(monkeypatch):
             assert abs(v - b[k]) <= 0.02 * abs(v) + 1e-4, (k, v, b[k])
 
 
+def test_generator_losses_in_parts_equal_the_whole():
+    """_generator_losses(parts=...) — the two-stream step evaluates the waveform losses and the ones through the discriminator on
+    different streams — returns the same terms, in the reference's order, as the one-call form (CPU, oracle STFT)."""
+    from oracle.torch_backend import oracle_stft_patch
+    cfg = _tiny_config()
+    tr = _make_trainer(cfg)
+    for m in tr.models.values():
+        m.train()
+    wave_in, wave_tgt, hf = _batch(cfg, 1)
+    with oracle_stft_patch(), tr._mpd_weights_once():      # (one set of spectral-norm weights for all three calls, as within a step)
+        torch.manual_seed(0)
+        wave_out = tr.models["generator"](wave_in, hf)
+        whole = tr._generator_losses(wave_out, wave_tgt)
+        sig = tr._generator_losses(wave_out, wave_tgt, parts=("signal",))
+        mpd = tr._generator_losses(wave_out, wave_tgt, parts=("mpd",))
+    assert list(whole) == list(sig) + list(mpd) and set(sig).isdisjoint(mpd) and sig and mpd
+    for k, v in whole.items():
+        assert torch.allclose(v, {**sig, **mpd}[k], rtol=1e-6, atol=0), k
+    assert not tr._two_streams()          # CPU: one stream
+
+
 # ---- round 2: batch contract, checkpoints, schedule, accumulation, multi-process decisions -------------------
 def test_synthetic_vctk_batch_contract():
     """H0: `(wave_in (1,T), wave_tgt (1,T), highcut int64, name, pad)` with T = int(SEGMENT * TARGET_SR) and
