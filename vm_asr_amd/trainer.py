@@ -629,8 +629,8 @@ class Trainer(BaseTrainer):
 
     def _side_cus(self, forward=False):
         """-> context: CUs the discriminator's convolution kernels may take while the generator's kernels run beside them
-        (VMASR_SIDE_CUS, default 160 of 256, soft by 24: csrc/convgemm.hip cg_grid — caps of 168 ... 184 workgroups measured alike, 160 and 200+ slower —; 0 = all;
-        VMASR_SIDE_CUS_MINC: only layers at least that wide)."""
+        (backward: VMASR_SIDE_CUS, default 160 of 256, soft by 24: csrc/convgemm.hip cg_grid — caps of 168 ... 184 workgroups measured alike,
+        160 and 200+ slower; forward: VMASR_SIDE_CUS_FWD, default 128; 0 = no limit; VMASR_SIDE_CUS_MINC: backward, only layers at least that wide)."""
         from . import convgemm
         cus = os.environ.get("VMASR_SIDE_CUS", "160")
         if forward:      # D(real) has slack beside the generator's forward, which everything else waits for: a tighter limit (96 ... 128 alike, 144+ slower)
@@ -667,8 +667,8 @@ class Trainer(BaseTrainer):
         d_losses = {}
         if two:
             # main stream: generator forward, losses on the waveform.   side stream: D(real) meanwhile, then D(fake) and
-            # the losses on its outputs.  autograd runs every backward node on its forward's stream, so the backward
-            # passes split the same way (see _backward_both).
+            # the losses on its outputs.  autograd runs every backward node on its forward's stream; the ORDER of the three
+            # backward pieces is set by _backward_two() (the graph is cut at the waveform for that).
             import contextlib
             main, side = torch.cuda.current_stream(self.device), self._side_stream()
             mpd = unwrap(self.models["mpd"])
