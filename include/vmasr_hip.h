@@ -631,6 +631,7 @@ enum {
     VMASR_K_CONV_MFMA_DGRAD,    /* its input gradient (residue classes of the stride, no col2im)                                               */
     VMASR_K_CONV_MFMA_WGRAD,    /* its weight gradient (transposed LDS reads)                                                                   */
     VMASR_K_WGRAD_FINISH,       /* sum over split-K slabs + bias column split-off of many weight gradients, one launch (csrc/wgrad.hip) */
+    VMASR_K_SKINNY_LINEAR,      /* y = x W^T + b for >= 4096 rows and <= 96 features each side (csrc/skinny.hip) */
     VMASR_K_COUNT
 };
 /* Deterministic-reduction switch (debug aid, off by default; the Python side turns it on for VMASR_DETERMINISTIC=1): the kernels whose
@@ -647,6 +648,14 @@ int vmasr_prof_collect(int kernel_id, int64_t *launches, double *total_ms, doubl
 /* debug aid: *dst (device memory) = the device's constant-rate clock (100 MHz ticks) when `stream` reaches this point; a kernel launch,
  * hence capturable into a HIP graph (tools/phase_probe.py) */
 int vmasr_mark_time(uint64_t *dst, vmasr_stream_t stream);
+
+/* Linear layers with many rows and few features (csrc/skinny.hip; the reference's nn.Linear / 1x1 and patch-embedding nn.Conv2d of the U-Net glue at the
+ * two highest resolutions, model/model.py:57-116,603-633, and their input gradients): y (rows, out) = x (rows, in) W^T + bias, rows >= 4096, in / out <= 96,
+ * as one streaming pass (fp32 accumulation in k order).  W is read as w[o * w_stride_out + i * w_stride_in] (elements, fp32): (out, in) row-major =
+ * (in, 1); the input gradient dx = g W of the same layer = the same call with in/out swapped and strides (1, in).  x / y: fp32 or bf16 (vmasr_dtype). */
+int vmasr_skinny_linear_supported(int64_t rows, int32_t in_f, int32_t out_f);
+int vmasr_skinny_linear(const void *x, const float *w, const float *bias, void *y, int64_t rows, int32_t in_f, int32_t out_f,
+                        int64_t w_stride_out, int64_t w_stride_in, int32_t x_dtype, int32_t y_dtype, vmasr_stream_t stream);
 int vmasr_prof_collect_shapes(int kernel_id, int max_groups, double *group_bytes, int64_t *group_launches, double *group_ms);
 
 #ifdef __cplusplus

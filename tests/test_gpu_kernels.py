@@ -628,3 +628,63 @@ def test_linear_f64acc_is_correctly_rounded():
         (x64 @ w64.t() + b64).backward(gy.double())
         for got, ref in ((x.grad, x64.grad), (w.grad, w64.grad), (b.grad, b64.grad)):
             assert (got.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K,N", [(4096 + 37, 9, 8), (65536, 72, 16), (8192, 16, 64), (5000, 96, 96), (4096, 64, 3), (300000, 16, 8)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_skinny_linear_matches_float64(rows, K, N, dt):
+    """csrc/skinny.hip: y = x W^T + b and the input gradient g W of the same layer (strides swapped) for many rows and few features,
+    against float64 on the values the kernel is given (bf16 inputs are exact in float64).  Tolerance: fp32 accumulation of <= 96 terms
+    (1e-6 of scale) + the output's own rounding (bf16: 2^-8)."""
+    from vm_asr_amd import linear as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(rows % 1000 + K)
+    x = torch.randn(rows, K, generator=g).to(dev).to(dt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    assert bool(L._lib.lib().vmasr_skinny_linear_supported(rows, K, N))
+    y = L._skinny(x, w, b, dt)
+    want = x.double() @ w.double().t() + b.double()
+    tol = (2 ** -8 if dt == torch.bfloat16 else 2e-6) * want.abs().max().item()
+    assert (y.double() - want).abs().max().item() <= tol
+    y0 = L._skinny(x, w, None, torch.float32)
+    assert (y0.double() - x.double() @ w.double().t()).abs().max().item() <= 2e-6 * want.abs().max().item()
+    gy = torch.randn(rows, N, generator=g).to(dev).to(dt)
+    dx = L._skinny(gy, w, None, dt, transposed=True)
+    wantx = gy.double() @ w.double()
+    tolx = (2 ** -8 if dt == torch.bfloat16 else 2e-6) * wantx.abs().max().item()
+    assert dx.shape == (rows, K) and (dx.double() - wantx).abs().max().item() <= tolx
+
+
+@pytest.mark.gpu
+def test_linear_takes_the_skinny_kernel_under_autocast_with_the_same_gradients():
+    """vm_asr_amd.linear.linear on (B, H, W, C) activations with many rows: same output and gradients as F.linear in float64, at bf16
+    tolerance; VMASR_SKINNY=0 gives the GEMM path."""
+    import os
+    from vm_asr_amd import linear as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = torch.randn(4, 256, 256, 9, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(12, 9, generator=g) / 3).to(dev).requires_grad_(True)
+    b = torch.randn(12, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(4, 256, 256, 12, generator=g).to(dev)
+    res = {}
+    for flag in ("1", "0"):
+        os.environ["VMASR_SKINNY"] = flag
+        try:
+            for t in (x, w, b):
+                t.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = L.linear(x, w, b)
+            y.float().backward(gy)
+            res[flag] = (y.detach().float(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+        finally:
+            os.environ.pop("VMASR_SKINNY", None)
+    x64, w64, b64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    y64 = torch.nn.functional.linear(x64, w64, b64)
+    y64.backward(gy.double())
+    want = (y64.detach(), x64.grad, w64.grad, b64.grad)
+    for flag in ("1", "0"):
+        for got, ref in zip(res[flag], want):
+            assert (got.double() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item(), flag

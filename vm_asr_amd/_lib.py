@@ -133,6 +133,8 @@ SYMBOLS = {
     "vmasr_gelu_bwd_split": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_conv_mfma_supported": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
     "vmasr_mark_time": (ctypes.c_int, [c_vp, c_vp]),
+    "vmasr_skinny_linear_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
+    "vmasr_skinny_linear": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_conv_set_cu_limit": (None, [c_i32]),
     "vmasr_conv_get_cu_limit": (c_i32, []),
     "vmasr_conv_mfma_fwd": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
@@ -225,7 +227,7 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-K_COUNT = 59
+K_COUNT = 60
 
 
 def zeros_f32(device, *shapes):

@@ -38,7 +38,7 @@ const char *kNames[VMASR_K_COUNT] = {
     "ss2d_transpose", "ss2d_fwd_agg", "ss2d_carry", "ss2d_fwd_apply", "ss2d_merge", "ss2d_bwd_agg", "ss2d_bwd_apply",
     "ss2d_pre", "ln_gate", "stack_rows", "feat_l1", "adamw", "conv_post", "mlp_fwd", "mlp_bwd", "inproj_fwd", "inproj_bwd",
     "ss2d_deep_xproj", "ss2d_deep_fwd", "ss2d_deep_bwd", "ss2d_deep_xbwd", "outproj_fwd", "outproj_bwd", "stft_loss",
-    "conv_mfma_fwd", "conv_mfma_dgrad", "conv_mfma_wgrad", "wgrad_finish"};
+    "conv_mfma_fwd", "conv_mfma_dgrad", "conv_mfma_wgrad", "wgrad_finish", "skinny_linear"};
 }  // namespace
 
 bool g_prof_on = false;

@@ -134,6 +134,33 @@ def _shadow(t, like, cdt):
     return sh if like is t else sh.view(like.shape)
 
 
+def _skinny_ok(rows, in_f, out_f, x2, weight):
+    """Many rows, few features: the streaming kernel of csrc/skinny.hip instead of a GEMM (VMASR_SKINNY=0: off)."""
+    # where it beats the GEMM library under graph replay (tools/bench_skinny.py): >= 131 072 rows with <= 16 features each side (6.6-9.2 us
+    # against 18.5-19.5 us); at 65 536 rows and 16-72 features hipBLASLt's 4-8 us are out of its reach (VMASR_SKINNY=all: every supported shape)
+    mode = os.environ.get("VMASR_SKINNY", "1")
+    if mode == "0" or not (x2.is_cuda and x2.dtype in (torch.float32, torch.bfloat16) and weight.dim() == 2):
+        return False
+    if mode != "all" and not (rows >= 131072 and in_f <= 16 and out_f <= 16):
+        return False
+    return bool(_lib.lib().vmasr_skinny_linear_supported(int(rows), int(in_f), int(out_f)))
+
+
+def _skinny(x2, w32, bias32, out_dtype, transposed=False):
+    """x2 (rows, in) contiguous, w32 fp32 (out, in) — or, transposed, the layer's (in, out)... weight read as W^T: y = x2 @ w32 (rows, w32.shape[1])."""
+    rows, in_f = x2.shape
+    if transposed:
+        out_f, s_out, s_in = w32.shape[1], w32.stride(1), w32.stride(0)
+    else:
+        out_f, s_out, s_in = w32.shape[0], w32.stride(0), w32.stride(1)
+    with torch.cuda.device(x2.device):
+        y = torch.empty((rows, out_f), dtype=out_dtype, device=x2.device)
+        _lib.check(_lib.lib().vmasr_skinny_linear(x2.data_ptr(), w32.data_ptr(), None if bias32 is None else bias32.data_ptr(), y.data_ptr(),
+                                                  rows, in_f, out_f, s_out, s_in, _lib.torch_dtype_code(x2.dtype), _lib.torch_dtype_code(out_dtype),
+                                                  _lib.current_stream(x2.device)), "skinny_linear")
+    return y
+
+
 class _LinearFn(torch.autograd.Function):
     """F.linear with (a) the operands cast to the compute dtype here - or taken from the trainer's
     shadow copies, which saves a cast kernel per weight per step -, (b) dW accumulated in fp32 by the
@@ -145,9 +172,14 @@ class _LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, in_f).to(cdt)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        wc = w_lp if w_lp is not None else weight.detach().to(cdt)
-        bc = None if bias is None else (b_lp if b_lp is not None else bias.detach().to(cdt))
-        y = F.linear(x2, wc, bc)
+        ctx.skinny = _skinny_ok(x2.shape[0], in_f, out_f, x2, weight) and cdt in (torch.float32, torch.bfloat16)
+        if ctx.skinny:      # many rows, few features: one streaming pass with the fp32 weight (csrc/skinny.hip)
+            wc = weight.detach().float()
+            y = _skinny(x2, wc, None if bias is None else bias.detach().float(), cdt)
+        else:
+            wc = w_lp if w_lp is not None else weight.detach().to(cdt)
+            bc = None if bias is None else (b_lp if b_lp is not None else bias.detach().to(cdt))
+            y = F.linear(x2, wc, bc)
         ctx.save_for_backward(x2, wc)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y.view(*x.shape[:-1], out_f)
@@ -159,7 +191,12 @@ class _LinearFn(torch.autograd.Function):
         gy2 = gy.reshape(x2.shape[0], wc.shape[0]).to(x2.dtype)
         if not gy2.is_contiguous():
             gy2 = gy2.contiguous()
-        dx = (gy2 @ wc).view(shape).to(xdt) if ctx.needs_input_grad[0] else None
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        elif ctx.skinny:
+            dx = _skinny(gy2, wc, None, gy2.dtype, transposed=True).view(shape).to(xdt)
+        else:
+            dx = (gy2 @ wc).view(shape).to(xdt)
         dw = weight_grad(gy2, x2).to(wdt) if ctx.needs_input_grad[1] else None
         db = None
         if bdt is not None and ctx.needs_input_grad[2]:
