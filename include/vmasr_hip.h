@@ -653,6 +653,13 @@ int vmasr_mark_time(uint64_t *dst, vmasr_stream_t stream);
  * two highest resolutions, model/model.py:57-116,603-633, and their input gradients): y (rows, out) = x (rows, in) W^T + bias, rows >= 4096, in / out <= 96,
  * as one streaming pass (fp32 accumulation in k order).  W is read as w[o * w_stride_out + i * w_stride_in] (elements, fp32): (out, in) row-major =
  * (in, 1); the input gradient dx = g W of the same layer = the same call with in/out swapped and strides (1, in).  x / y: fp32 or bf16 (vmasr_dtype). */
+/* 2-D im2col straight into GEMM rows and its adjoint (csrc/im2col.hip; the patch embedding's 3x3 stride-2 convolutions, model/model.py:603-633):
+ * cols (B Ho Wo, C kh kw) with column order (c, i, j) = conv.weight.flatten(1)'s, from x (B, C, H, W) with element strides x_strides[4] (any layout);
+ * dx (same logical shape / given strides) = sum of the row entries that read each pixel (a gather: no atomics).  dtypes: VMASR_F32 / VMASR_BF16 each side. */
+int vmasr_im2col2d_rows(const void *x, void *cols, int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                        int32_t ph, int32_t pw, const int64_t *x_strides, int32_t x_dtype, int32_t cols_dtype, vmasr_stream_t stream);
+int vmasr_col2im2d_rows(const void *gcols, void *dx, int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                        int32_t ph, int32_t pw, const int64_t *dx_strides, int32_t cols_dtype, int32_t dx_dtype, vmasr_stream_t stream);
 int vmasr_skinny_linear_supported(int64_t rows, int32_t in_f, int32_t out_f);
 int vmasr_skinny_linear(const void *x, const float *w, const float *bias, void *y, int64_t rows, int32_t in_f, int32_t out_f,
                         int64_t w_stride_out, int64_t w_stride_in, int32_t x_dtype, int32_t y_dtype, vmasr_stream_t stream);

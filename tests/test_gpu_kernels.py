@@ -688,3 +688,52 @@ def test_linear_takes_the_skinny_kernel_under_autocast_with_the_same_gradients()
     for flag in ("1", "0"):
         for got, ref in zip(res[flag], want):
             assert (got.double() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item(), flag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,k,s,p", [((2, 1, 64, 48), (3, 3), (2, 2), (1, 1)), ((3, 8, 33, 40), (3, 3), (2, 2), (1, 1)),
+                                         ((2, 4, 17, 19), (3, 2), (1, 2), (0, 1)), ((1, 5, 16, 16), (4, 4), (4, 4), (0, 0))])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("channel_last", [False, True])
+def test_im2col2d_rows_matches_unfold_and_its_adjoint(shape, k, s, p, dt, channel_last):
+    """vmasr_im2col2d_rows == F.unfold(x).transpose(1, 2) row for row (bit-exact: a gather), for dense inputs in either memory layout;
+    vmasr_col2im2d_rows == F.fold of the transposed gradient (fp32 sums of <= kh kw terms in a fixed order)."""
+    import torch.nn.functional as F
+    from vm_asr_amd.model import _Im2ColRowsFn, _rows_ok
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(dev).to(dt)
+    if channel_last:
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    assert _rows_ok(x)
+    x.requires_grad_(True)
+    cols = _Im2ColRowsFn.apply(x, k, s, p, dt)
+    want = F.unfold(x.detach().float(), k, padding=p, stride=s).transpose(1, 2).reshape(cols.shape)
+    assert torch.equal(cols.detach().float(), want)
+    gy = torch.randn(cols.shape, generator=g).to(dev).to(dt)
+    cols.backward(gy)
+    H, W = shape[2], shape[3]
+    wantx = F.fold(gy.float().view(shape[0], -1, cols.shape[1]).transpose(1, 2), (H, W), k, padding=p, stride=s)
+    tol = (2 ** -8 if dt == torch.bfloat16 else 1e-6) * max(1.0, wantx.abs().max().item())
+    assert x.grad.stride() == x.stride() and (x.grad.float() - wantx).abs().max().item() <= tol
+
+
+@pytest.mark.gpu
+def test_gemm_conv2d_rows_path_equals_the_unfold_path(monkeypatch):
+    """GemmConv2d through the one-pass rows gather == the F.unfold path (same GEMM, same values) under autocast, forward and gradients."""
+    from vm_asr_amd.model import GemmConv2d
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    conv = GemmConv2d(8, 16, kernel_size=3, stride=2, padding=1).to(dev)
+    x0 = torch.randn(2, 8, 64, 64, device=dev)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VMASR_IM2COL2D", flag)
+        x = x0.clone().requires_grad_(True)
+        conv.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(x)
+        y.float().square().sum().backward()
+        res[flag] = (y.detach().float(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    for a, b in zip(res["1"], res["0"]):
+        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()

@@ -133,6 +133,8 @@ SYMBOLS = {
     "vmasr_gelu_bwd_split": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_conv_mfma_supported": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
     "vmasr_mark_time": (ctypes.c_int, [c_vp, c_vp]),
+    "vmasr_im2col2d_rows": (ctypes.c_int, [c_vp, c_vp] + [c_i32] * 10 + [c_vp, c_i32, c_i32, c_vp]),
+    "vmasr_col2im2d_rows": (ctypes.c_int, [c_vp, c_vp] + [c_i32] * 10 + [c_vp, c_i32, c_i32, c_vp]),
     "vmasr_skinny_linear_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
     "vmasr_skinny_linear": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_conv_set_cu_limit": (None, [c_i32]),

@@ -448,3 +448,114 @@ VMASR_EXPORT int vmasr_stack_rows(const void *const *srcs, const int64_t *Ms, in
     }
     return check_launch("stack_rows");
 }
+
+// ---- 2-D im2col straight into GEMM ROWS (the generator's patch embedding: model/model.py:603-633, two 3x3 stride-2 convolutions) -------------
+// F.unfold writes (B, C kh kw, Ho Wo); the GEMM wants pixels as rows, (B Ho Wo, C kh kw), so the host path paid unfold + a transposing copy
+// (+ a cast under autocast) per convolution and the mirror image in the backward.  Here: one gather pass x (B, C, H, W; any strides) ->
+// rows in the GEMM's dtype, column order (c, i, j) = weight.flatten(1)'s; and its adjoint as a gather over the input pixels (each sums the
+// <= ceil(kh/sh) ceil(kw/sw) row entries that read it: no atomics).
+namespace vmasr {
+namespace {
+
+struct I2dGeom {
+    int B, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo;
+    long xs_b, xs_c, xs_h, xs_w;       // element strides of x / dx
+};
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void im2col2d_rows_kernel(const TI *__restrict__ x, TO *__restrict__ cols, const I2dGeom g, const long total) {
+    const int K = g.C * g.kh * g.kw;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / K;
+        const int kk = (int)(idx - r * K);
+        const int c = kk / (g.kh * g.kw), ij = kk - c * (g.kh * g.kw), i = ij / g.kw, j = ij - i * g.kw;
+        const int wo = (int)(r % g.Wo);
+        const long t = r / g.Wo;
+        const int ho = (int)(t % g.Ho), b = (int)(t / g.Ho);
+        const int h = ho * g.sh + i - g.ph, w = wo * g.sw + j - g.pw;
+        float v = 0.f;
+        if (h >= 0 && h < g.H && w >= 0 && w < g.W) v = (float)x[b * g.xs_b + c * g.xs_c + h * g.xs_h + w * g.xs_w];
+        cols[idx] = (TO)v;
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void col2im2d_rows_kernel(const TI *__restrict__ gcols, TO *__restrict__ dx, const I2dGeom g, const long total) {
+    const int K = g.C * g.kh * g.kw;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        // idx runs over (b, h, w, c) with c fastest: neighbouring threads read neighbouring row entries' column blocks
+        const int c = (int)(idx % g.C);
+        long t = idx / g.C;
+        const int w = (int)(t % g.W);
+        t /= g.W;
+        const int h = (int)(t % g.H), b = (int)(t / g.H);
+        float s = 0.f;
+        for (int i = 0; i < g.kh; ++i) {
+            const int hn = h + g.ph - i;
+            if (hn < 0 || hn % g.sh) continue;
+            const int ho = hn / g.sh;
+            if (ho >= g.Ho) continue;
+            for (int j = 0; j < g.kw; ++j) {
+                const int wn = w + g.pw - j;
+                if (wn < 0 || wn % g.sw) continue;
+                const int wo = wn / g.sw;
+                if (wo >= g.Wo) continue;
+                s += (float)gcols[(((long)b * g.Ho + ho) * g.Wo + wo) * K + (c * g.kh + i) * g.kw + j];
+            }
+        }
+        dx[b * g.xs_b + c * g.xs_c + h * g.xs_h + w * g.xs_w] = (TO)s;
+    }
+}
+
+template <typename F>
+int i2d_dispatch(int a, int b, F &&f) {        // (VMASR_F32 | VMASR_BF16) x (VMASR_F32 | VMASR_BF16)
+    if (a == VMASR_F32 && b == VMASR_F32) return f((const float *)nullptr, (float *)nullptr);
+    if (a == VMASR_F32 && b == VMASR_BF16) return f((const float *)nullptr, (bf16_t *)nullptr);
+    if (a == VMASR_BF16 && b == VMASR_F32) return f((const bf16_t *)nullptr, (float *)nullptr);
+    if (a == VMASR_BF16 && b == VMASR_BF16) return f((const bf16_t *)nullptr, (bf16_t *)nullptr);
+    return VMASR_EINVAL;
+}
+
+}  // namespace
+}  // namespace vmasr
+
+static int i2d_geom(vmasr::I2dGeom &g, int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw,
+                    const int64_t *strides) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || !strides) return 0;
+    g = {B, C, H, W, kh, kw, sh, sw, ph, pw, (H + 2 * ph - kh) / sh + 1, (W + 2 * pw - kw) / sw + 1, strides[0], strides[1], strides[2], strides[3]};
+    return g.Ho > 0 && g.Wo > 0;
+}
+
+VMASR_EXPORT int vmasr_im2col2d_rows(const void *x, void *cols, int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                                     int32_t ph, int32_t pw, const int64_t *x_strides, int32_t x_dtype, int32_t cols_dtype, vmasr_stream_t stream) {
+    vmasr::I2dGeom g;
+    VMASR_REQUIRE(x && cols && i2d_geom(g, B, C, H, W, kh, kw, sh, sw, ph, pw, x_strides), VMASR_EINVAL, "im2col2d_rows: bad argument");
+    const long total = (long)B * g.Ho * g.Wo * C * kh * kw;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 32);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double bytes = (double)B * C * H * W * (x_dtype == VMASR_F32 ? 4 : 2) + (double)total * (cols_dtype == VMASR_F32 ? 4 : 2);
+    return vmasr::i2d_dispatch(x_dtype, cols_dtype, [&](auto *pi, auto *po) {
+        using TI = std::remove_const_t<std::remove_pointer_t<decltype(pi)>>;
+        using TO = std::remove_pointer_t<decltype(po)>;
+        VMASR_LAUNCH(VMASR_K_IM2COL, bytes, (vmasr::im2col2d_rows_kernel<TI, TO>), dim3(blocks), dim3(256), 0, st, static_cast<const TI *>(x),
+                     static_cast<TO *>(cols), g, total);
+        return vmasr::check_launch("im2col2d_rows");
+    });
+}
+
+VMASR_EXPORT int vmasr_col2im2d_rows(const void *gcols, void *dx, int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                                     int32_t ph, int32_t pw, const int64_t *dx_strides, int32_t cols_dtype, int32_t dx_dtype, vmasr_stream_t stream) {
+    vmasr::I2dGeom g;
+    VMASR_REQUIRE(gcols && dx && i2d_geom(g, B, C, H, W, kh, kw, sh, sw, ph, pw, dx_strides), VMASR_EINVAL, "col2im2d_rows: bad argument");
+    const long total = (long)B * C * H * W;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 32);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double bytes = (double)total * (dx_dtype == VMASR_F32 ? 4 : 2) + (double)B * g.Ho * g.Wo * C * kh * kw * (cols_dtype == VMASR_F32 ? 4 : 2);
+    return vmasr::i2d_dispatch(cols_dtype, dx_dtype, [&](auto *pi, auto *po) {
+        using TI = std::remove_const_t<std::remove_pointer_t<decltype(pi)>>;
+        using TO = std::remove_pointer_t<decltype(po)>;
+        VMASR_LAUNCH(VMASR_K_COL2IM, bytes, (vmasr::col2im2d_rows_kernel<TI, TO>), dim3(blocks), dim3(256), 0, st, static_cast<const TI *>(gcols),
+                     static_cast<TO *>(dx), g, total);
+        return vmasr::check_launch("col2im2d_rows");
+    });
+}

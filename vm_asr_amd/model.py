@@ -56,6 +56,57 @@ class PatchExpanding(nn.Module):
         return self.norm(x)
 
 
+class _Im2ColRowsFn(torch.autograd.Function):
+    """x (B, C, H, W), any strides -> GEMM rows (B*Ho*Wo, C*kh*kw) in `dtype`, column order (c, i, j) = weight.flatten(1)'s, in one gather
+    pass (csrc/im2col.hip: vmasr_im2col2d_rows) instead of F.unfold + a transposing copy (+ a cast); backward: the adjoint gather."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p, dtype):
+        import ctypes
+        from . import _lib
+        B, C, H, W = x.shape
+        Ho, Wo = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+        dev = x.device
+        with torch.cuda.device(dev):
+            cols = torch.empty((B * Ho * Wo, C * k[0] * k[1]), dtype=dtype, device=dev)
+            st = (ctypes.c_int64 * 4)(*x.stride())
+            _lib.check(_lib.lib().vmasr_im2col2d_rows(x.data_ptr(), cols.data_ptr(), B, C, H, W, k[0], k[1], s[0], s[1], p[0], p[1], st,
+                                                      _lib.torch_dtype_code(x.dtype), _lib.torch_dtype_code(dtype), _lib.current_stream(dev)),
+                       "im2col2d_rows")
+        ctx.geom = (tuple(x.shape), tuple(x.stride()), x.dtype, k, s, p)
+        return cols
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import _lib
+        shape, strides, xdt, k, s, p = ctx.geom
+        B, C, H, W = shape
+        g = g.contiguous()
+        dev = g.device
+        with torch.cuda.device(dev):
+            dx = torch.empty_strided(shape, strides, dtype=xdt, device=dev)
+            st = (ctypes.c_int64 * 4)(*strides)
+            _lib.check(_lib.lib().vmasr_col2im2d_rows(g.data_ptr(), dx.data_ptr(), B, C, H, W, k[0], k[1], s[0], s[1], p[0], p[1], st,
+                                                      _lib.torch_dtype_code(g.dtype), _lib.torch_dtype_code(xdt), _lib.current_stream(dev)),
+                       "col2im2d_rows")
+        return dx, None, None, None, None
+
+
+def _rows_ok(x):
+    """dense input (every element of its storage addressed once: empty_strided in the backward is then a plain allocation)"""
+    import os
+    if os.environ.get("VMASR_IM2COL2D", "1") != "1" or x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    sz = sorted(zip(x.stride(), x.shape))
+    exp = 1
+    for st, n in sz:
+        if n != 1 and st != exp:
+            return False
+        exp *= n
+    return True
+
+
 class GemmConv2d(nn.Conv2d):
     """nn.Conv2d (same parameters / state_dict keys) evaluated as im2col + GEMM.
 
@@ -71,6 +122,12 @@ class GemmConv2d(nn.Conv2d):
         kh, kw = self.kernel_size
         Ho = (H + 2 * self.padding[0] - kh) // self.stride[0] + 1
         Wo = (W + 2 * self.padding[1] - kw) // self.stride[1] + 1
+        if _rows_ok(x) and self.dilation == (1, 1) and self.groups == 1:
+            cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+            if cdt in (torch.float32, torch.bfloat16):
+                cols = _Im2ColRowsFn.apply(x, tuple(self.kernel_size), tuple(self.stride), tuple(self.padding), cdt)     # (B*Ho*Wo, C*kh*kw)
+                y = _linear(cols, self.weight.flatten(1), self.bias, shadow_of=self.weight)                             # (B*Ho*Wo, Cout)
+                return y.view(B, Ho * Wo, -1).transpose(1, 2).reshape(B, -1, Ho, Wo)
         cols = F.unfold(x, self.kernel_size, padding=self.padding, stride=self.stride)  # (B, C*kh*kw, Ho*Wo)
         # pixels as the GEMM's M dimension: (B*Ho*Wo, C*kh*kw) @ (C*kh*kw, Cout).  The batched
         # (Cout x K) @ (K x Ho*Wo) form picks a 32x32 hipBLASLt tile and takes 1.5 ms per call.
