@@ -59,9 +59,16 @@ class DropPathPool:
         if self.keep.device != device:
             self.keep = self.keep.to(device)
         self.masks = torch.bernoulli(self.keep.expand(-1, batch)) / self.keep
+        self._cast = {}
 
-    def get(self, index, batch, ndim):
-        return self.masks[index, :batch].view((batch,) + (1,) * (ndim - 1))
+    def get(self, index, batch, ndim, dtype=torch.float32):
+        """layer `index`'s mask as a view of ONE cast of the whole table per dtype and forward (a `.to(bf16)` per layer was 28 launches a step)"""
+        m = self.masks
+        if dtype != torch.float32:
+            m = self._cast.get(dtype)
+            if m is None:
+                m = self._cast[dtype] = self.masks.to(dtype)
+        return m[index, :batch].view((batch,) + (1,) * (ndim - 1))
 
 
 class DropPath(nn.Module):
@@ -76,10 +83,10 @@ class DropPath(nn.Module):
     def active(self):
         return self.drop_prob != 0.0 and self.training
 
-    def _mask(self, x):
+    def _mask(self, x, dtype=torch.float32):
         pool = self._pool
         if pool is not None and pool.masks is not None and pool.masks.shape[1] >= x.shape[0] and pool.masks.device == x.device:
-            return pool.get(self._index, x.shape[0], x.ndim)
+            return pool.get(self._index, x.shape[0], x.ndim, dtype)
         keep = 1.0 - self.drop_prob
         mask = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), dtype=torch.float32, device=x.device).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
@@ -89,13 +96,14 @@ class DropPath(nn.Module):
     def forward(self, x):
         if not self.active():
             return x
-        return x * self._mask(x).to(x.dtype)
+        return x * self._mask(x, x.dtype).to(x.dtype)
 
     def residual(self, x, y):
         """x + drop_path(y) as ONE kernel (addcmul with the per-sample mask)."""
         if not self.active():
             return x + y
-        return torch.addcmul(x, y, self._mask(y).to(torch.promote_types(x.dtype, y.dtype)))
+        dt = torch.promote_types(x.dtype, y.dtype)
+        return torch.addcmul(x, y, self._mask(y, dt).to(dt))
 
     def extra_repr(self):
         return f"drop_prob={self.drop_prob:0.3f}"
