@@ -296,7 +296,7 @@ def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, step
     B = cfg.DATA.BATCH_SIZE
     rec = {"workload": f"{workload}.yaml, per-GPU batch {B}, DIMS {cfg.MODEL.VSSM.DIMS}, d_state {cfg.MODEL.VSSM.SSM_D_STATE}, "
                        f"n_fft {cfg.DATA.STFT.N_FFT}, MPD GEMMs {mpd_gemm}" + (", SNR/LSD/LSD-HF/LSD-LF evaluated and read every step" if with_metrics else ""),
-           "value": B * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "value": B * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "batch": B,
            "execution": "HIP graph replay" if graphed else "eager"}
     if tried:
         rec["out_of_memory_at_batch"] = tried
@@ -326,8 +326,98 @@ def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, step
     return rec
 
 
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def _pick(d, keys, nd=4):
+    return {k: _r(d[k], nd) for k in keys if d is not None and k in d}
+
+
+MAX_LINE = 3000      # the driver keeps an 8 000-character tail of stdout: the final line must fit with room to spare
+
+
+def compact(out):
+    """The driver's line: contract keys + `roofline`, `cpu_baseline`, `operating_points`, `distributed` reduced to their
+    headline numbers (<= MAX_LINE characters for any world size).  Per-kernel tables, per-shape tables, notes and per-rank
+    device records are the DETAIL record (`bench_detail.json`), never part of this line."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data") if k in out}
+    c["value"], c["ms_per_step"] = _r(c["value"], 3), _r(c["ms_per_step"], 4)
+    cfg = out.get("config", {})
+    c["config"] = {k: (v[:120] if isinstance(v, str) else v) for k, v in cfg.items() if not k.endswith("_note")}
+    c["dtype"] = str(c.get("dtype"))[:80]
+    r = out.get("roofline")
+    if r:
+        cr = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "avg_launch_us", "launches",
+                       "alg_bytes_per_launch"))
+        if r.get("selective_scan_op"):
+            cr["selective_scan_op"] = _pick(r["selective_scan_op"], ("achieved", "frac", "ms_per_step"))
+        sc = r.get("shared_chip")
+        if sc:
+            cr["shared_chip"] = {**_pick(sc, ("frac", "avg_launch_us")),
+                                 "op_frac": _r((sc.get("selective_scan_op") or {}).get("frac")),
+                                 "op_ms_per_step": _r((sc.get("selective_scan_op") or {}).get("ms_per_step"))}
+        c["roofline"] = cr
+    if "cpu_baseline" in out:
+        cb = dict(out["cpu_baseline"])
+        cb["value"] = _r(cb.get("value"), 5)
+        cb["sample"] = str(cb.get("sample", ""))[:160]
+        c["cpu_baseline"] = cb
+    pts = out.get("operating_points")
+    if pts:
+        cp = {}
+        for name, p in pts.items():
+            if "error" in p:
+                cp[name] = {"error": str(p["error"])[:80]}
+                continue
+            rr = p.get("roofline") or {}
+            cp[name] = {"value": _r(p.get("value"), 2), "ms_per_step": _r(p.get("ms_per_step"), 3), "batch": p.get("batch"),
+                        "scan_op_frac": _r((rr.get("selective_scan_op") or {}).get("frac")),
+                        **({"valu_frac": _r(rr["valu"]["frac"])} if rr.get("valu") else {})}
+        c["operating_points"] = cp
+    d = out.get("distributed")
+    if d:
+        c["distributed"] = _pick(d, ("world_size", "backend", "rccl_version", "distinct_devices"))
+    pr = out.get("per_rank")
+    if pr:          # max over ranks only: the per-rank lists are in the detail record
+        c["distributed"] = {**c.get("distributed", {}),
+                            "ms_per_step_max": max(pr["ms_per_step"]), "ms_per_step_min": min(pr["ms_per_step"]),
+                            "allreduce_exposed_ms_per_step": max(pr["allreduce_exposed_ms_per_step"])}
+    c["detail"] = out.get("detail_file", "bench_detail.json")
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > MAX_LINE:        # never let an unforeseen field push the line out of the driver's tail again
+        for k in ("operating_points", "distributed", "cpu_baseline"):
+            if len(line) <= MAX_LINE:
+                break
+            if k == "cpu_baseline" and k in c:
+                c[k] = _pick(c[k], ("value", "unit", "cores", "kind"))
+            elif k in c:
+                c[k] = {"see": c["detail"]}
+            line = json.dumps(c, separators=(",", ":"))
+    assert len(line) <= MAX_LINE, len(line)
+    return line
+
+
+def emit(out, detail_path):
+    """Write the full record to `detail_path` (and a pointer to stderr), then print the compact line LAST on stdout."""
+    out["detail_file"] = os.path.basename(detail_path)
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(out, f, indent=1)
+        print(f"[bench] full record ({len(json.dumps(out))} characters): {detail_path}", file=sys.stderr, flush=True)
+    except OSError as e:        # read-only checkout: the full record goes to stderr instead
+        print(f"[bench] could not write {detail_path} ({e}); full record follows on stderr", file=sys.stderr)
+        print(json.dumps(out), file=sys.stderr, flush=True)
+    sys.stderr.flush()
+    print(compact(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record (per-kernel / per-shape tables, notes, per-rank device records) is written; the "
+                         "stdout line is the compact record only")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -379,23 +469,29 @@ def main():
         "metric": "audio clips/sec (train step) 48kHz n_fft=1024", "value": world * B * args.steps / dt,
         "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32" if args.no_amp else
-                  "bf16 autocast over the generator forward as in the reference (selective scan / STFT fp32; losses and "
-                  "discriminator fp32" + ("; its three compute-bound GEMM layers as error-compensated bf16x3 MFMA products, fp32 "
-                                          "accumulation)" if args.mpd_gemm == "bf16x3" else ")") if args.amp_scope == "generator" else
-                  "bf16 autocast over generator, losses and discriminator (selective scan / STFT fp32)"), "data": "synthetic",
-        "config": {"workload": f"{args.workload}.yaml full train step (G fwd+bwd, "
-                               f"{'MR-STFT+LSGAN+feature losses, MPD fwd+bwd, ' if config.TRAIN.ADVERSARIAL.ENABLE else 'MR-STFT loss, '}"
-                               f"AdamW); DIMS {config.MODEL.VSSM.DIMS}, d_state {config.MODEL.VSSM.SSM_D_STATE}, clip 122640 @48 kHz, n_fft 1024 hop 240",
+        "dtype": ("f32" if args.no_amp else "bf16 (autocast over G; scan/STFT f32; MPD f32" + ("/bf16x3 MFMA)" if args.mpd_gemm == "bf16x3" else ")")
+                  if args.amp_scope == "generator" else "bf16 (autocast over G, losses, MPD; scan/STFT f32)"),
+        "dtype_note": ("f32" if args.no_amp else
+                       "bf16 autocast over the generator forward as in the reference (selective scan / STFT fp32; losses and "
+                       "discriminator fp32" + ("; its three compute-bound GEMM layers as error-compensated bf16x3 MFMA products, fp32 "
+                                               "accumulation)" if args.mpd_gemm == "bf16x3" else ")") if args.amp_scope == "generator" else
+                       "bf16 autocast over generator, losses and discriminator (selective scan / STFT fp32)"), "data": "synthetic",
+        "config": {"workload": f"{args.workload}.yaml full train step, DIMS {config.MODEL.VSSM.DIMS} d_state {config.MODEL.VSSM.SSM_D_STATE} "
+                               f"n_fft {config.DATA.STFT.N_FFT} clip 122640@48k",
+                   "workload_note": f"{args.workload}.yaml full train step (G fwd+bwd, "
+                                    f"{'MR-STFT+LSGAN+feature losses, MPD fwd+bwd, ' if config.TRAIN.ADVERSARIAL.ENABLE else 'MR-STFT loss, '}"
+                                    f"AdamW); DIMS {config.MODEL.VSSM.DIMS}, d_state {config.MODEL.VSSM.SSM_D_STATE}, clip 122640 @48 kHz, "
+                                    f"n_fft {config.DATA.STFT.N_FFT} hop 240",
                    "per_gpu_batch": B, "global_batch": B * world,
-                   "parallelism": f"dp{world} (clip-sharded; one RCCL all-reduce per flat gradient buffer)",
-                   "execution": (("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): one forward + backward graph with a fork / "
-                                  "join — the period discriminator on a side stream beside the generator (trainer._two_streams), its convolution "
-                                  f"kernels on at most {os.environ.get('VMASR_SIDE_CUS_FWD', os.environ.get('VMASR_SIDE_CUS', '128'))} (forward) / {os.environ.get('VMASR_SIDE_CUS', '160')} (backward) CUs, "
-                                  "soft by 24, while they overlap — and an optimiser graph")
-                                 if two_stream else
-                                 ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
-                                  "optimiser graph)")) if graphed else ("eager, two streams" if two_stream else "eager")},
+                   "parallelism": f"dp{world}",
+                   "parallelism_note": "clip-sharded; one RCCL all-reduce per flat gradient buffer",
+                   "execution": ("hipGraph replay" + (", 2 streams" if two_stream else "")) if graphed else ("eager, 2 streams" if two_stream else "eager"),
+                   "execution_note": (("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): one forward + backward graph with a fork / "
+                                       "join — the period discriminator on a side stream beside the generator (trainer._two_streams), its convolution "
+                                       "kernels under a CU limit while they overlap (trainer.side_cu_limits) — and an optimiser graph")
+                                      if two_stream else
+                                      ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
+                                       "optimiser graph)")) if graphed else ("eager, two streams" if two_stream else "eager")},
     }
     out["distributed"] = dinfo     # what the process group actually was: world size, backend, RCCL version, every rank's device
     out["config"]["per_step_metrics"] = bool(args.with_metrics)
@@ -478,7 +574,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
