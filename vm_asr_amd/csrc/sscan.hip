@@ -30,6 +30,7 @@
 // backward per clip.
 #include "common.h"
 #include "scan_prims.h"
+#include "sscan_n.h"
 
 #include <stdlib.h>
 
@@ -769,7 +770,23 @@ int dispatch_bwd(const vmasr_sscan_bwd_params &q, const Plan &pl, bool dyn, bool
 }  // namespace
 }  // namespace vmasr
 
+namespace vmasr {
+void sscan_launch_carry(bool reverse, float *x, int nseq, int n_chunks, int N, double bytes, hipStream_t st) {
+    if (reverse)
+        VMASR_LAUNCH(VMASR_K_SSCAN_BWD_CARRY, bytes, (sscan_carry_kernel<true>), dim3((nseq + 3) / 4), dim3(256), 0, st, x, nseq, n_chunks, N);
+    else
+        VMASR_LAUNCH(VMASR_K_SSCAN_FWD_CARRY, bytes, (sscan_carry_kernel<false>), dim3((nseq + 3) / 4), dim3(256), 0, st, x, nseq, n_chunks, N);
+}
+}  // namespace vmasr
+
 using namespace vmasr;
+
+// general d_state: the packed state-pair kernels of sscan_n.hip (VMASR_SSCAN_N_LEGACY=1: the one-state-at-a-time kernels of this
+// file, kept for A/B measurements)
+static bool n_legacy() {
+    static const bool v = [] { const char *e = getenv("VMASR_SSCAN_N_LEGACY"); return e && atoi(e) != 0; }();
+    return v;
+}
 
 VMASR_EXPORT int vmasr_sscan_chunk(void) { return kTile; }
 
@@ -791,6 +808,7 @@ VMASR_EXPORT int vmasr_sscan_fwd(const vmasr_sscan_params *pp, vmasr_stream_t st
                              p.B_dstate_stride, p.C_batch_stride, p.C_group_stride, p.C_dstate_stride});
     const Plan pl = make_plan(p, dyn, false);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dyn && !n_legacy()) return sscan_n_fwd(p, pl.split, pl.tiles_per_task, pl.nseg, vec, st);
     switch (p.dtype) {
         case VMASR_F32: return dispatch_fwd<float>(p, pl, dyn, vec, st);
         case VMASR_F16: return dispatch_fwd<f16_t>(p, pl, dyn, vec, st);
@@ -825,6 +843,7 @@ VMASR_EXPORT int vmasr_sscan_bwd(const vmasr_sscan_bwd_params *qq, vmasr_stream_
         VMASR_REQUIRE(q.ws_ptr && q.ws_bytes >= need, VMASR_ENOSPACE, "sscan_bwd: workspace too small (%zu < %zu)",
                       q.ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dyn && !n_legacy()) return sscan_n_bwd(q, pl.split, pl.tiles_per_task, pl.nseg, g_tune_rows, vec, st);
     switch (p.dtype) {
         case VMASR_F32: return dispatch_bwd<float>(q, pl, dyn, vec, st);
         case VMASR_F16: return dispatch_bwd<f16_t>(q, pl, dyn, vec, st);
