@@ -18,4 +18,6 @@ for k, d in agg.items():
     print(f"{k[0]:55s} grid {k[1]:8d} vgpr {k[2]:3d} n={n:2d} waves {d.get('SQ_WAVES',0)/n:9.0f} "
           f"wait_any {d.get('SQ_WAIT_ANY',0)/wc:5.2f} wait_inst {d.get('SQ_WAIT_INST_ANY',0)/wc:5.2f} active_any {d.get('SQ_ACTIVE_INST_ANY',0)/wc:5.2f} "
           f"valu {d.get('SQ_ACTIVE_INST_VALU',0)/wc:5.2f} insts_valu/wave {d.get('SQ_INSTS_VALU',0)/max(1,d.get('SQ_WAVES',1)):7.0f} "
-          f"salu/wave {d.get('SQ_INSTS_SALU',0)/max(1,d.get('SQ_WAVES',1)):7.0f} wavecyc/wave {4*wc/max(1,d.get('SQ_WAVES',1)):9.0f}")
+          f"salu/wave {d.get('SQ_INSTS_SALU',0)/max(1,d.get('SQ_WAVES',1)):7.0f} wavecyc/wave {4*wc/max(1,d.get('SQ_WAVES',1)):9.0f}"
+          + "".join(f" {c[3:].lower()}/wave {d[c]/max(1,d.get('SQ_WAVES',1)):9.0f}" for c in names if c not in
+                    ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES", "SQ_WAVE_CYCLES")))

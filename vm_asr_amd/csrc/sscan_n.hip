@@ -3,25 +3,29 @@
 // Same operator as sscan.hip (selective_scan_cuda_core.{fwd,bwd}: cus/selective_scan.cpp:157-349; kernels
 // cus/selective_scan_fwd_kernel.cuh:101-158 — the loop over states at :124 — and cus/selective_scan_bwd_kernel.cuh:125-241),
 // for the calls where every row carries N states (BASELINE configs[4]: `MODEL.VSSM.SSM_D_STATE 32`).  The work is
-// N * L * rows state-steps of ~10 (forward) / ~25 (backward) arithmetic instructions each against 12-20 bytes per ROW-step:
-// VALU-issue bound by a factor of N, not HBM bound.  The mapping is therefore chosen for instructions per state-step:
+// N * L * rows state-steps of ~14 (forward) / ~35 (backward) arithmetic instructions each against 12-20 bytes per ROW-step:
+// VALU-issue bound by a factor of N, not HBM bound.  The mapping is chosen for instructions per state-step and for enough
+// independent waves without extra passes:
 //
-//   * lanes = time (64 lanes x 4 consecutive steps = the 256-step tile of sscan.hip: coalesced 16-byte loads, the
-//     sums over states (y, du, ddelta) stay inside a lane), states are walked in PAIRS held in one 64-bit register
-//     pair: decay, recurrence and every gradient product run as v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 — two
-//     states per instruction;
+//   * lanes = time (64 lanes x 4 consecutive steps = the 256-step tile of sscan.hip; the sums over states (y, du, ddelta)
+//     stay inside a lane), states are walked in PAIRS held in one 64-bit register pair: decay, recurrence and every
+//     gradient product run as v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 — two states per instruction;
 //   * ONE decay exp(delta A) per (row, step, state), shared by the forward recompute and the adjoint recurrence of
 //     the backward: 2^(delta A log2 e) with the integer part split off by the 1.5*2^23 trick, a degree-6 polynomial
 //     on [-1/2, 1/2] in packed FMAs and the exponent added with v_lshl_add_u32 — 5.5 instructions per state-step
 //     (sscan.hip's scalar form: 7-13);
 //   * the 64 lane aggregates of the two states of a pair are scanned TOGETHER: the DPP stages of the two states are
 //     interleaved, which fills the two wait states a DPP read needs after the VALU write of its source (no s_nop);
-//   * the running state of a row (h per state, the adjoint carry G per state) lives in a per-wave LDS slice, read as
-//     one ds_read_b64 per pair; A (pre-multiplied by log2 e) is staged there once per task;
-//   * backward: a wave owns R rows of one (batch, group) and walks them INSIDE the pair loop, so B / C are loaded once
-//     per R rows and dB / dC are summed over those rows in registers; the W waves of a workgroup (other rows of the
-//     same group, same tile) reduce them through LDS once per block of pairs (one barrier pair per block, not per
-//     state) and leave as 256-byte runs of float atomics;
+//   * PAIR-OWNER WAVES: the W waves of a workgroup own different state pairs of the SAME rows and tile.  A wave loads
+//     the B / C tile of its pairs once per tile into registers and keeps it while the workgroup walks a block of RB rows
+//     of the group (B / C traffic / RB, no LDS staging), and in the backward it sums dB / dC of its pairs over those rows
+//     in registers (no cross-wave reduction for them at all).  What is summed over STATES (y; du, ddelta) is reduced
+//     across the waves through LDS once per batch of rows, by the threads that also did that batch's softplus: the
+//     per-row prologue (loads, softplus / sigmoid, delta u) runs once per position, not once per wave;
+//   * the workgroup walks its tiles sequentially (forward upwards, backward downwards) with the running state of every
+//     (row, state) in LDS: rows x pairs x W waves give the parallelism, so no aggregate pass is needed unless a call has
+//     very few rows (the 1024x512 output block: 2 rows per group), which takes the 3-phase split (aggregates -> carry
+//     kernel -> apply) of sscan.hip with the same kernels;
 //   * the adjoint uses G_t = a_t g_t (ss2d.hip): G_t = a_t (dout_t C_t + G_{t+1}) needs only the step's own decay, so a
 //     tile needs one scalar per state from its right neighbour.
 // Numerics: fp32, same recurrence, softplus and association as sscan.hip; the decay is within 1.3 * 2^-24 relative of
@@ -44,36 +48,51 @@ __device__ __forceinline__ v2f fma2(const v2f a, const v2f b, const v2f c) { ret
 constexpr float kMagic = 12582912.f;   // 1.5 * 2^23: adding it rounds to an integer and leaves that integer in the low mantissa bits
 constexpr float kZmax = 125.f;         // |delta A log2 e| up to here: the exponent add cannot leave the normal range
 
-// 2^f on |f| <= 1/2, near-minimax fit of (2^f - 1) / f (relative error 2e-9 before rounding)
-__device__ __forceinline__ v2f exp2_poly(const v2f f) {
-    v2f p = splat(1.5353427443187684e-4f);
-    p = fma2(p, f, splat(1.339887734502554e-3f));
-    p = fma2(p, f, splat(9.61843691766262e-3f));
-    p = fma2(p, f, splat(5.5503323674201965e-2f));
-    p = fma2(p, f, splat(2.4022647738456726e-1f));
-    p = fma2(p, f, splat(6.931471824645996e-1f));
-    return fma2(p, f, splat(1.f));
-}
-
-// a = exp(dl A) for a pair of states, A2 = A log2 e.  ROBUST false: the caller has checked |dl A2| <= kZmax for the whole
-// wave (a scalar branch), so the exponent is added to the bits directly.  z = dl A2 is never rounded: f = fma(dl, A2, -n).
+// a_i = exp(dl_i A) for a pair of states and the kItems steps of a lane, A2 = A log2 e.  The four evaluations run in
+// LOCK-STEP (coefficient by coefficient): a v_pk_fma_f32 that reads the result of the previous instruction costs a wait
+// state, four independent Horner chains side by side cost none.
+// ROBUST false: the caller has checked |dl A2| <= kZmax for the whole workgroup (a scalar branch), so the exponent is added to
+// the bits directly.  z = dl A2 is never rounded: f = fma(dl, A2, -n).
 template <bool ROBUST>
-__device__ __forceinline__ v2f decay2(const float dl, const v2f A2) {
+__device__ __forceinline__ void decay2x4(const float (&dl)[kItems], const v2f A2, v2f (&a)[kItems]) {
+    v2f t[kItems], f[kItems], p[kItems];
     if constexpr (!ROBUST) {
-        const v2f t = fma2(splat(dl), A2, splat(kMagic));
-        const v2f nf = t - splat(kMagic);
-        const v2f p = exp2_poly(fma2(splat(dl), A2, -nf));
-        v2f r;
-        r.x = __int_as_float(__float_as_int(p.x) + (__float_as_int(t.x) << 23));
-        r.y = __int_as_float(__float_as_int(p.y) + (__float_as_int(t.y) << 23));
-        return r;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) t[i] = fma2(splat(dl[i]), A2, splat(kMagic));
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) f[i] = fma2(splat(dl[i]), A2, splat(kMagic) - t[i]);
     } else {   // any finite argument: clamp, ldexp (underflows to 0, overflows to inf as exp does)
-        v2f z = splat(dl) * A2;
-        z.x = __builtin_amdgcn_fmed3f(z.x, -160.f, 160.f);
-        z.y = __builtin_amdgcn_fmed3f(z.y, -160.f, 160.f);
-        const v2f nf = (z + splat(kMagic)) - splat(kMagic);
-        const v2f p = exp2_poly(z - nf);
-        return (v2f){ldexpf(p.x, (int)nf.x), ldexpf(p.y, (int)nf.y)};
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            v2f z = splat(dl[i]) * A2;
+            z.x = __builtin_amdgcn_fmed3f(z.x, -160.f, 160.f);
+            z.y = __builtin_amdgcn_fmed3f(z.y, -160.f, 160.f);
+            t[i] = z + splat(kMagic);
+            f[i] = z - (t[i] - splat(kMagic));
+        }
+    }
+    // 2^f on |f| <= 1/2, near-minimax fit of (2^f - 1) / f (relative error 2e-9 before rounding)
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) p[i] = fma2(splat(1.5353427443187684e-4f), f[i], splat(1.339887734502554e-3f));
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(9.61843691766262e-3f));
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(5.5503323674201965e-2f));
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(2.4022647738456726e-1f));
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(6.931471824645996e-1f));
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(1.f));
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        if constexpr (!ROBUST) {
+            a[i].x = __int_as_float(__float_as_int(p[i].x) + (__float_as_int(t[i].x) << 23));
+            a[i].y = __int_as_float(__float_as_int(p[i].y) + (__float_as_int(t[i].y) << 23));
+        } else {
+            a[i].x = ldexpf(p[i].x, __float_as_int(t[i].x) - __float_as_int(kMagic));
+            a[i].y = ldexpf(p[i].y, __float_as_int(t[i].y) - __float_as_int(kMagic));
+        }
     }
 }
 
@@ -95,6 +114,7 @@ __device__ __forceinline__ Pair2 then2(const Pair2 first, const Pair2 second) {
 }
 
 // forward: excl = composition of lanes [0, lane), tot = all lanes (wave-uniform)
+template <bool TOT = true>
 __device__ __forceinline__ void wave_scan_fwd2(const Pair2 v, Pair2 &excl, Pair2 &tot) {
     float a0 = v.a.x, b0 = v.b.x, a1 = v.a.y, b1 = v.b.y;
     asm volatile("s_nop 1\n\t"
@@ -105,8 +125,10 @@ __device__ __forceinline__ void wave_scan_fwd2(const Pair2 v, Pair2 &excl, Pair2
                  VMASR_SCAN2_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf")
                  VMASR_SCAN2_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf")
                  : "+v"(b0), "+v"(a0), "+v"(b1), "+v"(a1));
-    tot.a = (v2f){readlane_f(a0, 63), readlane_f(a1, 63)};
-    tot.b = (v2f){readlane_f(b0, 63), readlane_f(b1, 63)};
+    if constexpr (TOT) {
+        tot.a = (v2f){readlane_f(a0, 63), readlane_f(a1, 63)};
+        tot.b = (v2f){readlane_f(b0, 63), readlane_f(b1, 63)};
+    }
     float ea0 = 1.f, eb0 = 0.f, ea1 = 1.f, eb1 = 0.f;   // exclusive = inclusive one lane down; lane 0 keeps the identity
     asm volatile("s_nop 1\n\t"
                  "v_mov_b32_dpp %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -119,7 +141,9 @@ __device__ __forceinline__ void wave_scan_fwd2(const Pair2 v, Pair2 &excl, Pair2
 }
 
 // reverse (g_l = b_l + a_l g_{l+1}): excl = composition of lanes (lane, 63] applied from the right, tot = all lanes.
-// Inside the 16-lane rows by DPP; across the rows (row_bcast only goes upwards) from the row totals read with v_readlane.
+// Inside the 16-lane rows by DPP.  Across the rows row_bcast only goes upwards, so the rows are closed from the right in three
+// steps: row 2 composes with the total of row 3 (v_readlane of lane 48), row 1 with the suffix at lane 32, row 0 with the one at
+// lane 16 — each step two FMAs and two multiplies under the row's exec mask, with the totals as scalar operands.
 __device__ __forceinline__ void wave_scan_rev2(const Pair2 v, const int lane, Pair2 &excl, Pair2 &tot) {
     float a0 = v.a.x, b0 = v.b.x, a1 = v.a.y, b1 = v.b.y;
     asm volatile("s_nop 1\n\t"
@@ -128,31 +152,39 @@ __device__ __forceinline__ void wave_scan_rev2(const Pair2 v, const int lane, Pa
                  VMASR_SCAN2_STAGE("row_shl:4 row_mask:0xf bank_mask:0xf")
                  VMASR_SCAN2_STAGE("row_shl:8 row_mask:0xf bank_mask:0xf")
                  : "+v"(b0), "+v"(a0), "+v"(b1), "+v"(a1));
-    const Pair2 t0{(v2f){readlane_f(a0, 0), readlane_f(a1, 0)}, (v2f){readlane_f(b0, 0), readlane_f(b1, 0)}};
-    const Pair2 t1{(v2f){readlane_f(a0, 16), readlane_f(a1, 16)}, (v2f){readlane_f(b0, 16), readlane_f(b1, 16)}};
-    const Pair2 t2{(v2f){readlane_f(a0, 32), readlane_f(a1, 32)}, (v2f){readlane_f(b0, 32), readlane_f(b1, 32)}};
-    const Pair2 t3{(v2f){readlane_f(a0, 48), readlane_f(a1, 48)}, (v2f){readlane_f(b0, 48), readlane_f(b1, 48)}};
-    const Pair2 s1 = then2(t3, t2), s0 = then2(s1, t1);   // rows to the right of row 1 / row 0
-    tot = then2(s0, t0);
     const int row = lane >> 4;
-    Pair2 suf;
-    suf.a = row == 3 ? splat(1.f) : (row == 2 ? t3.a : (row == 1 ? s1.a : s0.a));
-    suf.b = row == 3 ? splat(0.f) : (row == 2 ? t3.b : (row == 1 ? s1.b : s0.b));
-    // in-row exclusive suffix: the value one lane up (identity at the end of a row)
-    float ea0 = 1.f, eb0 = 0.f, ea1 = 1.f, eb1 = 0.f;
+#pragma unroll
+    for (int src = 48; src >= 16; src -= 16) {   // the suffix right of row (src / 16 - 1) sits at lane src
+        const float ta0 = readlane_f(a0, src), tb0 = readlane_f(b0, src), ta1 = readlane_f(a1, src), tb1 = readlane_f(b1, src);
+        if (row == src / 16 - 1) {
+            b0 = fmaf(a0, tb0, b0); a0 *= ta0;
+            b1 = fmaf(a1, tb1, b1); a1 *= ta1;
+        }
+    }
+    tot.a = (v2f){readlane_f(a0, 0), readlane_f(a1, 0)};
+    tot.b = (v2f){readlane_f(b0, 0), readlane_f(b1, 0)};
+    float ea0 = 1.f, eb0 = 0.f, ea1 = 1.f, eb1 = 0.f;   // exclusive = inclusive one lane up; lane 63 keeps the identity
     asm volatile("s_nop 1\n\t"
-                 "v_mov_b32_dpp %0, %4 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %1, %5 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %2, %6 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %3, %7 row_shl:1 row_mask:0xf bank_mask:0xf"
+                 "v_mov_b32_dpp %0, %4 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %2, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %3, %7 wave_shl:1 row_mask:0xf bank_mask:0xf"
                  : "+v"(eb0), "+v"(eb1), "+v"(ea0), "+v"(ea1) : "v"(b0), "v"(b1), "v"(a0), "v"(a1));
-    excl = then2(suf, Pair2{(v2f){ea0, ea1}, (v2f){eb0, eb1}});
+    excl.a = (v2f){ea0, ea1};
+    excl.b = (v2f){eb0, eb1};
 }
 
 // ---- geometry ------------------------------------------------------------------------------------------------------------
-struct NFwdGeom {
-    int tiles_per_task, nseg, np;   // np = state pairs = ceil(N / 2)
+struct PGeom {
+    int tiles_per_task, nseg;   // segments along L (split plan), tiles per segment
+    int np;                     // state pairs = ceil(N / 2)
+    int W;                      // waves per workgroup = ceil(np / PP): wave w owns pairs w PP .. w PP + PP - 1
+    int RB, RS, nrb;            // rows per workgroup, rows per batch (prologue / reduction granule), row blocks per group
+    unsigned *det;              // deterministic mode: the workgroups run one after the other (common.h), else null
 };
+
+
+__host__ __device__ inline int align4(int v) { return (v + 3) & ~3; }
 
 template <typename T, bool VEC>
 __device__ __forceinline__ void load_pair4(const T *__restrict__ base, const int64_t dstate_stride, const int n0, const bool has1,
@@ -169,129 +201,205 @@ __device__ __forceinline__ void load_pair4(const T *__restrict__ base, const int
     for (int i = 0; i < kItems; ++i) v[i] = (v2f){x0[i], x1[i]};
 }
 
+__device__ __forceinline__ void store_pair(float *xi, const bool xvec, const bool has1, const v2f a, const v2f b) {
+    if (xvec) {
+        *reinterpret_cast<float4 *>(xi) = make_float4(a.x, b.x, a.y, b.y);
+    } else {
+        *reinterpret_cast<float2 *>(xi) = make_float2(a.x, b.x);
+        if (has1) *reinterpret_cast<float2 *>(xi + 2) = make_float2(a.y, b.y);
+    }
+}
+
 // =====================================================================================================================
 // forward.  MODE 0 walk (carry-in zero at tile 0, sequential over [tile0, tile1), writes x per tile), 1 apply (carry-in
 // from x[tile0 - 1], already scanned by the carry kernel), 2 aggregates only (tile-local (prod a, h_end | h_in = 0) -> x).
-// One wave = one row.  Per-wave LDS slice: A log2e [2 np], h [2 np], p [2 np].
+// Workgroup = W pair-owner waves x RB rows of one (batch, group) x a segment of tiles.
+// LDS (floats): A log2e [RB][2 np] | h [RB][2 np] | p [RB][2 np] | bias, D, max|A log2e| [RB] | stage [RS][2][256] (delta,
+// delta u) | ypart [RS][W][256].
 // =====================================================================================================================
-template <typename T, bool VEC, int MODE>
-__global__ __launch_bounds__(256) void sscan_nfwd_kernel(const vmasr_sscan_params p, const NFwdGeom geo) {
+// Q: positions per thread in the prologue / epilogue of a batch = ceil(RS 256 / threads): 1 for W >= 4 waves, 2 for W = 2..3, 4 for W = 1
+template <typename T, bool VEC, int PP, int Q, int MODE>
+__global__ __launch_bounds__(1024) void sscan_pfwd_kernel(const vmasr_sscan_params p, const PGeom geo) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int L = p.seqlen, N = p.dstate, NP2 = 2 * geo.np;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = p.seqlen, N = p.dstate, NP2 = 2 * geo.np, RB = geo.RB, RS = geo.RS, W = geo.W;
     const int ntiles = (L + kTile - 1) / kTile;
-    // tasks: row fastest (the waves of a workgroup share B / C lines), then segment, then batch
-    const int task = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-    const int d = task % p.dim, rest = task / p.dim, seg = rest % geo.nseg, b = rest / geo.nseg;
-    if (b >= p.batch) return;
-    const int g = d / (p.dim / p.n_groups);
+    const int D = p.dim / p.n_groups;
+    // block -> (row block fastest: the workgroups that read the same B / C tiles are neighbours, group, segment, batch)
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = bid % geo.nrb; bid /= geo.nrb;
+    const int g = bid % p.n_groups; bid /= p.n_groups;
+    const int seg = bid % geo.nseg;
+    const int b = bid / geo.nseg;
+    const int d0 = g * D + rb * RB;
     const int tile0 = seg * geo.tiles_per_task, tile1 = min(ntiles, tile0 + geo.tiles_per_task);
 
-    float *sA = s_dyn + (size_t)wave * 3 * NP2, *sH = sA + NP2, *sP = sH + NP2;
+    float *sA = s_dyn, *sH = sA + RB * NP2, *sP = sH + RB * NP2, *sbias = sP + RB * NP2, *sDk = sbias + RB, *samax = sDk + RB;
+    float *stage = s_dyn + align4(3 * RB * NP2 + 3 * RB), *ypart = stage + RS * 2 * kTile;
+    int *sflag = reinterpret_cast<int *>(ypart + (size_t)RS * W * kTile);   // [2]
+
     const T *__restrict__ Bg = static_cast<const T *>(p.B_ptr) + b * p.B_batch_stride + g * p.B_group_stride;
     const T *__restrict__ Cg = static_cast<const T *>(p.C_ptr) + b * p.C_batch_stride + g * p.C_group_stride;
-    const float *__restrict__ Ap = static_cast<const float *>(p.A_ptr) + d * p.A_d_stride;
+    const T *__restrict__ ub = static_cast<const T *>(p.u_ptr) + b * p.u_batch_stride;
+    const T *__restrict__ dlb = static_cast<const T *>(p.delta_ptr) + b * p.delta_batch_stride;
+    T *__restrict__ ob = static_cast<T *>(p.out_ptr) + b * p.out_batch_stride;
     float *__restrict__ xp = static_cast<float *>(p.x_ptr);
-    const T *__restrict__ u_row = static_cast<const T *>(p.u_ptr) + b * p.u_batch_stride + d * p.u_d_stride;
-    const T *__restrict__ dl_row = static_cast<const T *>(p.delta_ptr) + b * p.delta_batch_stride + d * p.delta_d_stride;
-    T *__restrict__ out_row = static_cast<T *>(p.out_ptr) + b * p.out_batch_stride + d * p.out_d_stride;
-    const float Dv = p.D_ptr ? static_cast<const float *>(p.D_ptr)[d] : 0.f;
-    const float bias = p.delta_bias_ptr ? static_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
-    const size_t xrow = ((size_t)b * p.dim + d) * p.n_chunks;   // in chunks
+    const size_t xrow0 = ((size_t)b * p.dim + d0) * p.n_chunks;   // in chunks; row r: + r * n_chunks
 
-    float amax = 0.f;
-    for (int n = lane; n < NP2; n += kWave) {
-        const float a2 = n < N ? Ap[n * p.A_dstate_stride] * kLog2e : 0.f;   // the pad state of an odd N: a = 1, B = C = 0
-        float h = 0.f, pr = 1.f;
+    for (int e = tid; e < RB * NP2; e += nthr) {
+        const int r = e / NP2, n = e % NP2;
+        const float A = n < N ? static_cast<const float *>(p.A_ptr)[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride] : 0.f;
+        float h = 0.f, pr = 1.f;   // (the pad state of an odd N: a = 1, B = C = 0)
         if (MODE == 1 && tile0 > 0 && n < N) {
-            pr = xp[((xrow + tile0 - 1) * N + n) * 2 + 0];
-            h = xp[((xrow + tile0 - 1) * N + n) * 2 + 1];
+            const float *xi = xp + ((xrow0 + (size_t)r * p.n_chunks + tile0 - 1) * N + n) * 2;
+            pr = xi[0];
+            h = xi[1];
         }
-        sA[n] = a2; sH[n] = h; sP[n] = pr;
-        amax = fmaxf(amax, fabsf(a2));
+        sA[e] = A * kLog2e; sH[e] = h; sP[e] = pr;
     }
+    for (int r = tid; r < RB; r += nthr) {
+        sbias[r] = p.delta_bias_ptr ? static_cast<const float *>(p.delta_bias_ptr)[d0 + r] : 0.f;
+        sDk[r] = p.D_ptr ? static_cast<const float *>(p.D_ptr)[d0 + r] : 0.f;
+        float am = 0.f;
+        for (int n = 0; n < N; ++n) am = fmaxf(am, fabsf(static_cast<const float *>(p.A_ptr)[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride]));
+        samax[r] = am * kLog2e;
+    }
+    if (tid < 2) sflag[tid] = 0;
+    __syncthreads();
+    const bool xvec = (N & 1) == 0;   // (...) * N + n0 is even: 16-byte aligned pairs of (p, h)
+
+    float pre_u[Q], pre_d[Q];
+    auto prefetch = [&](const int tile, const int kb) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    const bool xvec = (N & 1) == 0;   // (…) * N + n0 is even: 16-byte aligned pairs of (p, h)
+        for (int qi = 0; qi < Q; ++qi) {
+            const int pos = qi * nthr + tid;
+            pre_u[qi] = 0.f; pre_d[qi] = 0.f;
+            if (pos < RS * kTile) {
+                const int r = kb + pos / kTile, t = tile * kTile + pos % kTile;
+                if (t < L) {
+                    pre_u[qi] = to_f32(ub[(d0 + r) * p.u_d_stride + t]);
+                    pre_d[qi] = to_f32(dlb[(d0 + r) * p.delta_d_stride + t]);
+                }
+            }
+        }
+    };
+    if (tile0 < tile1) prefetch(tile0, 0);
+    int batch = 0;
 
     for (int tile = tile0; tile < tile1; ++tile) {
         const int t0 = tile * kTile + lane * kItems;
         const bool full = (tile + 1) * kTile <= L;   // wave-uniform
-        float uv[kItems], dl[kItems], du[kItems];
-        load4u<T, VEC>(u_row, t0, L, uv, full);
-        // steps past the end of a ragged tile are identity steps (delta = 0: a = 1, b = 0)
-        load4u<T, VEC>(dl_row, t0, L, dl, full, p.delta_softplus ? -INFINITY : -bias);
-        float dmax = 0.f;
+        v2f Bv[PP][kItems], Cv[PP][kItems];
 #pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-            const float v = dl[i] + bias;
-            dl[i] = p.delta_softplus ? softplus_f(v) : v;
-            du[i] = dl[i] * uv[i];
-            dmax = fmaxf(dmax, fabsf(dl[i]));
-        }
-        const bool robust = __builtin_amdgcn_ballot_w64(!(dmax * amax <= kZmax)) != 0;   // scalar branch
-        v2f y2[kItems];
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) y2[i] = splat(0.f);
-
-        for (int n0 = 0; n0 < N; n0 += 2) {
-            const bool has1 = n0 + 1 < N;
-            v2f Bv[kItems], Cv[kItems], a[kItems], bb[kItems];
-            load_pair4<T, VEC>(Bg, p.B_dstate_stride, n0, has1, t0, L, full, Bv);
-            if (MODE != 2) load_pair4<T, VEC>(Cg, p.C_dstate_stride, n0, has1, t0, L, full, Cv);
-            const v2f A2 = *reinterpret_cast<const v2f *>(sA + n0);
-            if (robust) {
-#pragma unroll
-                for (int i = 0; i < kItems; ++i) a[i] = decay2<true>(dl[i], A2);
-            } else {
-#pragma unroll
-                for (int i = 0; i < kItems; ++i) a[i] = decay2<false>(dl[i], A2);
+        for (int j = 0; j < PP; ++j) {
+            const int n0 = 2 * (wave * PP + j);
+            if (n0 < N) {
+                load_pair4<T, VEC>(Bg, p.B_dstate_stride, n0, n0 + 1 < N, t0, L, full, Bv[j]);
+                if (MODE != 2) load_pair4<T, VEC>(Cg, p.C_dstate_stride, n0, n0 + 1 < N, t0, L, full, Cv[j]);
             }
+        }
+        for (int kb = 0; kb < RB; kb += RS) {
+            // ---- prologue of the batch: delta = softplus(.), delta u, D u — once per position, by whichever thread holds it
+            // (its loads were issued one batch ahead: pre_u / pre_d)
+            float Du[Q];
+            bool flag = false;
 #pragma unroll
-            for (int i = 0; i < kItems; ++i) bb[i] = splat(du[i]) * Bv[i];
-            Pair2 agg{a[0], bb[0]};
-#pragma unroll
-            for (int i = 1; i < kItems; ++i) agg = then2(agg, Pair2{a[i], bb[i]});
-            Pair2 excl, tot;
-            wave_scan_fwd2(agg, excl, tot);
-            float *xi = xp + ((xrow + tile) * N + n0) * 2;
-            if constexpr (MODE == 2) {
-                if (lane == 0) {
-                    if (xvec) *reinterpret_cast<float4 *>(xi) = make_float4(tot.a.x, tot.b.x, tot.a.y, tot.b.y);
-                    else {
-                        *reinterpret_cast<float2 *>(xi) = make_float2(tot.a.x, tot.b.x);
-                        if (has1) *reinterpret_cast<float2 *>(xi + 2) = make_float2(tot.a.y, tot.b.y);
+            for (int qi = 0; qi < Q; ++qi) {
+                const int pos = qi * nthr + tid;
+                if (pos < RS * kTile) {
+                    const int rr = pos / kTile, idx = pos % kTile, r = kb + rr, t = tile * kTile + idx;
+                    float u = 0.f, dlv = 0.f;   // steps past the end of a ragged tile are identity steps (delta = 0: a = 1, b = 0)
+                    if (t < L) {
+                        u = pre_u[qi];
+                        const float v = pre_d[qi] + sbias[r];
+                        dlv = p.delta_softplus ? softplus_f(v) : v;
                     }
+                    stage[(rr * 2 + 0) * kTile + idx] = dlv;
+                    stage[(rr * 2 + 1) * kTile + idx] = dlv * u;
+                    Du[qi] = sDk[r] * u;
+                    flag |= !(fabsf(dlv) * samax[r] <= kZmax);
                 }
-            } else {
-                const v2f hin = *reinterpret_cast<const v2f *>(sH + n0);
-                v2f h = fma2(excl.a, hin, excl.b);
+            }
+            {   // loads of the next batch (this tile's next rows, else the next tile's first rows): in flight during the pair work
+                int nkb = kb + RS, ntile = tile;
+                if (nkb >= RB) { nkb = 0; ntile = tile + 1; }
+                if (ntile < tile1) prefetch(ntile, nkb);
+            }
+            if (__builtin_amdgcn_ballot_w64(flag) != 0 && lane == 0) sflag[batch & 1] = 1;
+            lds_barrier();
+            const bool robust = sflag[batch & 1] != 0;
+            if (tid == 0) sflag[(batch + 1) & 1] = 0;   // the other slot: next set after the second barrier of this batch
+            ++batch;
+            // ---- my pairs of every row of the batch
+            for (int rr = 0; rr < RS; ++rr) {
+                const int r = kb + rr;
+                const float4 dl4 = *reinterpret_cast<const float4 *>(stage + (rr * 2 + 0) * kTile + lane * kItems);
+                const float4 du4 = *reinterpret_cast<const float4 *>(stage + (rr * 2 + 1) * kTile + lane * kItems);
+                const float dl[kItems] = {dl4.x, dl4.y, dl4.z, dl4.w}, du[kItems] = {du4.x, du4.y, du4.z, du4.w};
+                v2f y2[kItems];
 #pragma unroll
-                for (int i = 0; i < kItems; ++i) {
-                    h = fma2(a[i], h, bb[i]);
-                    y2[i] = fma2(h, Cv[i], y2[i]);
-                }
-                const v2f hout = fma2(tot.a, hin, tot.b);
-                if (lane == 0) {
-                    *reinterpret_cast<v2f *>(sH + n0) = hout;
-                    if constexpr (MODE == 0) {
-                        const v2f pout = tot.a * *reinterpret_cast<const v2f *>(sP + n0);
-                        *reinterpret_cast<v2f *>(sP + n0) = pout;
-                        if (xvec) *reinterpret_cast<float4 *>(xi) = make_float4(pout.x, hout.x, pout.y, hout.y);
-                        else {
-                            *reinterpret_cast<float2 *>(xi) = make_float2(pout.x, hout.x);
-                            if (has1) *reinterpret_cast<float2 *>(xi + 2) = make_float2(pout.y, hout.y);
+                for (int i = 0; i < kItems; ++i) y2[i] = splat(0.f);
+#pragma unroll
+                for (int j = 0; j < PP; ++j) {
+                    const int n0 = 2 * (wave * PP + j);
+                    if (n0 >= N) continue;
+                    const bool has1 = n0 + 1 < N;
+                    const v2f A2 = *reinterpret_cast<const v2f *>(sA + r * NP2 + n0);
+                    v2f a[kItems], bb[kItems];
+                    if (robust) decay2x4<true>(dl, A2, a);
+                    else decay2x4<false>(dl, A2, a);
+#pragma unroll
+                    for (int i = 0; i < kItems; ++i) bb[i] = splat(du[i]) * Bv[j][i];
+                    Pair2 agg{a[0], bb[0]};
+#pragma unroll
+                    for (int i = 1; i < kItems; ++i) agg = then2(agg, Pair2{a[i], bb[i]});
+                    Pair2 excl, tot;
+                    wave_scan_fwd2(agg, excl, tot);
+                    float *xi = xp + ((xrow0 + (size_t)r * p.n_chunks + tile) * N + n0) * 2;
+                    if constexpr (MODE == 2) {
+                        if (lane == 0) store_pair(xi, xvec, has1, tot.a, tot.b);
+                    } else {
+                        const v2f hin = *reinterpret_cast<const v2f *>(sH + r * NP2 + n0);
+                        v2f h = fma2(excl.a, hin, excl.b);
+#pragma unroll
+                        for (int i = 0; i < kItems; ++i) {
+                            h = fma2(a[i], h, bb[i]);
+                            y2[i] = fma2(h, Cv[j][i], y2[i]);
+                        }
+                        const v2f hout = fma2(tot.a, hin, tot.b);
+                        if (lane == 0) {
+                            *reinterpret_cast<v2f *>(sH + r * NP2 + n0) = hout;
+                            if constexpr (MODE == 0) {
+                                const v2f pout = tot.a * *reinterpret_cast<const v2f *>(sP + r * NP2 + n0);
+                                *reinterpret_cast<v2f *>(sP + r * NP2 + n0) = pout;
+                                store_pair(xi, xvec, has1, pout, hout);
+                            }
                         }
                     }
                 }
+                if constexpr (MODE != 2)
+                    *reinterpret_cast<float4 *>(ypart + (size_t)(rr * W + wave) * kTile + lane * kItems) =
+                        make_float4(y2[0].x + y2[0].y, y2[1].x + y2[1].y, y2[2].x + y2[2].y, y2[3].x + y2[3].y);
             }
-        }
-        if constexpr (MODE != 2) {
-            float outv[kItems];
+            lds_barrier();
+            // ---- epilogue: y = D u + sum over the pair-owner waves
+            if constexpr (MODE != 2) {
 #pragma unroll
-            for (int i = 0; i < kItems; ++i) outv[i] = fmaf(Dv, uv[i], y2[i].x + y2[i].y);
-            store4u<T, VEC>(out_row, t0, L, outv, full);
+                for (int qi = 0; qi < Q; ++qi) {
+                    const int pos = qi * nthr + tid;
+                    if (pos < RS * kTile) {
+                        const int rr = pos / kTile, idx = pos % kTile, r = kb + rr, t = tile * kTile + idx;
+                        float y = Du[qi];
+                        const float *yp = ypart + (size_t)rr * W * kTile + idx;
+                        int w = 0;
+                        for (; w + 4 <= W; w += 4)   // four independent LDS reads in flight
+                            y += (yp[(w + 0) * kTile] + yp[(w + 1) * kTile]) + (yp[(w + 2) * kTile] + yp[(w + 3) * kTile]);
+                        for (; w < W; ++w) y += yp[w * kTile];
+                        if (t < L) ob[(d0 + r) * p.out_d_stride + t] = from_f32<T>(y);
+                    }
+                }
+            }
         }
     }
 }
@@ -299,139 +407,180 @@ __global__ __launch_bounds__(256) void sscan_nfwd_kernel(const vmasr_sscan_param
 // =====================================================================================================================
 // backward.  MODE 0: the workgroup walks [tile0, tile1) from the right, adjoint carries G in LDS; 1: carry-in per task
 // read from ws (scanned by the reverse carry kernel); 2: per-tile reverse aggregates -> ws.
-// Workgroup = W waves; wave w owns rows d0 .. d0 + R - 1 of ONE group; the waves walk the same tiles in lockstep.
-// Dynamic LDS: per wave 4 R NP2 floats (A log2e | A | G | dA accumulators) + (W > 1) the dB / dC reduction buffer
-// [W][PB][4][256] floats.
+// Same workgroup shape as the forward.  LDS (floats): A log2e | A | G | dA accumulators [RB][2 np] each | bias, D,
+// max|A log2e| [RB] | dD, ddelta_bias partial sums [RB][4] each | stage [RS][4][256] (delta, u, dout, delta u) |
+// part [RS][W][2][256] (du, ddelta summed over the wave's states).
 // =====================================================================================================================
-struct NBwdGeom {
-    int tiles_per_task, nseg, W, wg_per_group, np, PB;
-    unsigned *det;   // deterministic mode: the workgroups run one after the other (common.h), else null
-};
-
-template <typename T, int R, bool VEC, int MODE>
-__global__ __launch_bounds__(512) void sscan_nbwd_kernel(const vmasr_sscan_bwd_params q, const NBwdGeom geo) {
+template <typename T, bool VEC, int PP, int Q, int MODE>
+__global__ __launch_bounds__(1024) void sscan_pbwd_kernel(const vmasr_sscan_bwd_params q, const PGeom geo) {
     const vmasr_sscan_params &p = q.f;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    det_enter(geo.det);
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W = geo.W, L = p.seqlen, N = p.dstate, NP2 = 2 * geo.np;
+    if (MODE != 2) det_enter(geo.det);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = p.seqlen, N = p.dstate, NP2 = 2 * geo.np, RB = geo.RB, RS = geo.RS, W = geo.W;
     const int ntiles = (L + kTile - 1) / kTile;
-    const int rpg = p.dim / p.n_groups;
-    // block -> (workgroup-in-group fastest, group, segment, batch)
+    const int D = p.dim / p.n_groups;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int wgi = bid % geo.wg_per_group; bid /= geo.wg_per_group;
+    const int rb = bid % geo.nrb; bid /= geo.nrb;
     const int g = bid % p.n_groups; bid /= p.n_groups;
     const int seg = bid % geo.nseg;
     const int b = bid / geo.nseg;
-    const int d0 = g * rpg + (wgi * W + wave) * R;
+    const int d0 = g * D + rb * RB;
     const int tile0 = seg * geo.tiles_per_task, tile1 = min(ntiles, tile0 + geo.tiles_per_task);
 
-    float *sA = s_dyn + (size_t)wave * 4 * R * NP2, *sAr = sA + R * NP2, *sG = sAr + R * NP2, *sdA = sG + R * NP2;
-    float *red = s_dyn + (size_t)W * 4 * R * NP2;   // [W][PB][4][kTile]
+    float *sA = s_dyn, *sAr = sA + RB * NP2, *sG = sAr + RB * NP2, *sdA = sG + RB * NP2;
+    float *sbias = sdA + RB * NP2, *sDk = sbias + RB, *samax = sDk + RB, *saccD = samax + RB, *saccB = saccD + 4 * RB;
+    float *stage = s_dyn + align4(4 * RB * NP2 + 11 * RB), *part = stage + RS * 4 * kTile;
+    int *sflag = reinterpret_cast<int *>(part + (size_t)RS * W * 2 * kTile);   // [2] (+ 2 pad)
+    float *xpose = part + (size_t)RS * W * 2 * kTile + 4;                        // [W][256]: transpose buffer of the dB / dC atomics
 
     const T *__restrict__ Bg = static_cast<const T *>(p.B_ptr) + b * p.B_batch_stride + g * p.B_group_stride;
     const T *__restrict__ Cg = static_cast<const T *>(p.C_ptr) + b * p.C_batch_stride + g * p.C_group_stride;
+    const T *__restrict__ ub = static_cast<const T *>(p.u_ptr) + b * p.u_batch_stride;
+    const T *__restrict__ dlb = static_cast<const T *>(p.delta_ptr) + b * p.delta_batch_stride;
+    const T *__restrict__ dob = static_cast<const T *>(q.dout_ptr) + b * q.dout_batch_stride;
+    T *__restrict__ dub = static_cast<T *>(q.du_ptr) + b * q.du_batch_stride;
+    T *__restrict__ ddb = static_cast<T *>(q.ddelta_ptr) + b * q.ddelta_batch_stride;
     const float *__restrict__ xp = static_cast<const float *>(p.x_ptr);
     float *__restrict__ ws = static_cast<float *>(q.ws_ptr);
     float *__restrict__ dBg = static_cast<float *>(q.dB_ptr) + ((size_t)b * p.n_groups + g) * N * L;
     float *__restrict__ dCg = static_cast<float *>(q.dC_ptr) + ((size_t)b * p.n_groups + g) * N * L;
-
-    const T *u_row[R], *dl_row[R], *do_row[R];
-    T *du_row[R], *dd_row[R];
-    float Dv[R], bias[R], amax[R], accD[R], accBias[R];
     const size_t xrow0 = ((size_t)b * p.dim + d0) * p.n_chunks;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int d = d0 + r;
-        u_row[r] = static_cast<const T *>(p.u_ptr) + b * p.u_batch_stride + d * p.u_d_stride;
-        dl_row[r] = static_cast<const T *>(p.delta_ptr) + b * p.delta_batch_stride + d * p.delta_d_stride;
-        do_row[r] = static_cast<const T *>(q.dout_ptr) + b * q.dout_batch_stride + d * q.dout_d_stride;
-        du_row[r] = static_cast<T *>(q.du_ptr) + b * q.du_batch_stride + d * q.du_d_stride;
-        dd_row[r] = static_cast<T *>(q.ddelta_ptr) + b * q.ddelta_batch_stride + d * q.ddelta_d_stride;
-        Dv[r] = p.D_ptr ? static_cast<const float *>(p.D_ptr)[d] : 0.f;
-        bias[r] = p.delta_bias_ptr ? static_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
-        accD[r] = 0.f; accBias[r] = 0.f;
-        const float *Ap = static_cast<const float *>(p.A_ptr) + d * p.A_d_stride;
-        const bool carry = MODE == 1 && tile1 * kTile < L;
-        float am = 0.f;
-        for (int n = lane; n < NP2; n += kWave) {
-            const float A = n < N ? Ap[n * p.A_dstate_stride] : 0.f;
-            sA[r * NP2 + n] = A * kLog2e;
-            sAr[r * NP2 + n] = A;
-            sG[r * NP2 + n] = (carry && n < N) ? ws[((xrow0 + (size_t)r * p.n_chunks + tile1 - 1) * N + n) * 2 + 1] : 0.f;
-            sdA[r * NP2 + n] = 0.f;
-            am = fmaxf(am, fabsf(A * kLog2e));
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
-        amax[r] = am;
+
+    const bool carry = MODE == 1 && tile1 * kTile < L;
+    for (int e = tid; e < RB * NP2; e += nthr) {
+        const int r = e / NP2, n = e % NP2;
+        const float A = n < N ? static_cast<const float *>(p.A_ptr)[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride] : 0.f;
+        sA[e] = A * kLog2e;
+        sAr[e] = A;
+        sG[e] = (carry && n < N) ? ws[((xrow0 + (size_t)r * p.n_chunks + tile1 - 1) * N + n) * 2 + 1] : 0.f;
+        sdA[e] = 0.f;
     }
+    for (int r = tid; r < RB; r += nthr) {
+        sbias[r] = p.delta_bias_ptr ? static_cast<const float *>(p.delta_bias_ptr)[d0 + r] : 0.f;
+        sDk[r] = p.D_ptr ? static_cast<const float *>(p.D_ptr)[d0 + r] : 0.f;
+        float am = 0.f;
+        for (int n = 0; n < N; ++n) am = fmaxf(am, fabsf(static_cast<const float *>(p.A_ptr)[(d0 + r) * p.A_d_stride + n * p.A_dstate_stride]));
+        samax[r] = am * kLog2e;
+    }
+    for (int e = tid; e < 8 * RB; e += nthr) saccD[e] = 0.f;   // saccD | saccB
+    if (tid < 2) sflag[tid] = 0;
+    __syncthreads();
     const bool xvec = (N & 1) == 0;
+
+    float pre_u[Q], pre_d[Q], pre_y[Q];
+    auto prefetch = [&](const int tile, const int kb) {
+#pragma unroll
+        for (int qi = 0; qi < Q; ++qi) {
+            const int pos = qi * nthr + tid;
+            pre_u[qi] = 0.f; pre_d[qi] = 0.f; pre_y[qi] = 0.f;
+            if (pos < RS * kTile) {
+                const int r = kb + pos / kTile, t = tile * kTile + pos % kTile;
+                if (t < L) {
+                    pre_d[qi] = to_f32(dlb[(d0 + r) * p.delta_d_stride + t]);
+                    pre_y[qi] = to_f32(dob[(d0 + r) * q.dout_d_stride + t]);
+                    if (MODE != 2) pre_u[qi] = to_f32(ub[(d0 + r) * p.u_d_stride + t]);
+                }
+            }
+        }
+    };
+    if (tile0 < tile1) prefetch(tile1 - 1, 0);
+    int batch = 0;
 
     for (int tile = tile1 - 1; tile >= tile0; --tile) {
         const int t0 = tile * kTile + lane * kItems;
         const bool full = (tile + 1) * kTile <= L;   // wave-uniform
-        float uv[R][kItems], dl[R][kItems], dov[R][kItems], sig[R][kItems], du_[R][kItems];
-        v2f du2[R][kItems], dd2[R][kItems];
-        float zmax = 0.f;
+        v2f Bv[PP][kItems], Cv[PP][kItems], dBv[PP][kItems], dCv[PP][kItems];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            load4u<T, VEC>(dl_row[r], t0, L, dl[r], full, p.delta_softplus ? -INFINITY : -bias[r]);   // identity steps past the end
-            load4u<T, VEC>(do_row[r], t0, L, dov[r], full);
-            if (MODE != 2) load4u<T, VEC>(u_row[r], t0, L, uv[r], full);
+        for (int j = 0; j < PP; ++j) {
+            const int n0 = 2 * (wave * PP + j);
+            if (n0 < N) {
+                load_pair4<T, VEC>(Cg, p.C_dstate_stride, n0, n0 + 1 < N, t0, L, full, Cv[j]);
+                if (MODE != 2) load_pair4<T, VEC>(Bg, p.B_dstate_stride, n0, n0 + 1 < N, t0, L, full, Bv[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) { dBv[j][i] = splat(0.f); dCv[j][i] = splat(0.f); }
         }
+        for (int kb = 0; kb < RB; kb += RS) {
+            // ---- prologue: delta = softplus(.), its derivative, delta u — once per position (loads issued one batch ahead)
+            float sg[Q], dyq[Q], pdq[Q];
+            bool flag = false;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float dmax = 0.f;
-#pragma unroll
-            for (int i = 0; i < kItems; ++i) {
-                const float v = dl[r][i] + bias[r];
-                if (MODE == 2) {
-                    dl[r][i] = p.delta_softplus ? softplus_f(v) : v;
-                } else if (p.delta_softplus) {
-                    softplus_sigmoid_f(v, dl[r][i], sig[r][i]);
-                } else {
-                    dl[r][i] = v;
-                    sig[r][i] = 1.f;
-                }
-                dmax = fmaxf(dmax, fabsf(dl[r][i]));
-                if (MODE != 2) {
-                    du_[r][i] = dl[r][i] * uv[r][i];
-                    accD[r] = fmaf(dov[r][i], uv[r][i], accD[r]);
-                    du2[r][i] = splat(0.f);
-                    dd2[r][i] = splat(0.f);
+            for (int qi = 0; qi < Q; ++qi) {
+                const int pos = qi * nthr + tid;
+                sg[qi] = 0.f; dyq[qi] = 0.f; pdq[qi] = 0.f;
+                if (pos < RS * kTile) {
+                    const int rr = pos / kTile, idx = pos % kTile, r = kb + rr, t = tile * kTile + idx;
+                    float u = 0.f, dlv = 0.f, dy = 0.f, s = 0.f;   // identity steps past the end of a ragged tile
+                    if (t < L) {
+                        const float v = pre_d[qi] + sbias[r];
+                        dy = pre_y[qi];
+                        if (MODE == 2) {
+                            dlv = p.delta_softplus ? softplus_f(v) : v;
+                        } else {
+                            u = pre_u[qi];
+                            if (p.delta_softplus) softplus_sigmoid_f(v, dlv, s);
+                            else { dlv = v; s = 1.f; }
+                        }
+                    }
+                    float *st = stage + (size_t)rr * 4 * kTile + idx;
+                    st[0] = dlv; st[kTile] = u; st[2 * kTile] = dy; st[3 * kTile] = dlv * u;
+                    sg[qi] = s; dyq[qi] = dy; pdq[qi] = dy * u;
+                    flag |= !(fabsf(dlv) * samax[r] <= kZmax);
                 }
             }
-            zmax = fmaxf(zmax, dmax * amax[r]);
-        }
-        const bool robust = __builtin_amdgcn_ballot_w64(!(zmax <= kZmax)) != 0;   // scalar branch
-
-        for (int pb0 = 0; pb0 < geo.np; pb0 += geo.PB) {
-            const int npb = min(geo.PB, geo.np - pb0);
-            for (int pp = 0; pp < npb; ++pp) {
-                const int n0 = 2 * (pb0 + pp);
-                const bool has1 = n0 + 1 < N;
-                v2f Bv[kItems], Cv[kItems], dBv[kItems], dCv[kItems];
-                load_pair4<T, VEC>(Cg, p.C_dstate_stride, n0, has1, t0, L, full, Cv);
-                if (MODE != 2) load_pair4<T, VEC>(Bg, p.B_dstate_stride, n0, has1, t0, L, full, Bv);
+            {   // loads of the next batch (this tile's next rows, else the first rows of the tile to the left)
+                int nkb = kb + RS, ntile = tile;
+                if (nkb >= RB) { nkb = 0; ntile = tile - 1; }
+                if (ntile >= tile0) prefetch(ntile, nkb);
+            }
+            // saved states entering this tile, for my pairs of the rows of this batch (uniform loads, used after the forward scan)
+            v2f hsave[2][PP];
+            if constexpr (MODE != 2) {
 #pragma unroll
-                for (int i = 0; i < kItems; ++i) { dBv[i] = splat(0.f); dCv[i] = splat(0.f); }
+                for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
+                    for (int j = 0; j < PP; ++j) {
+                        const int n0 = 2 * (wave * PP + j);
+                        hsave[rr][j] = splat(0.f);
+                        if (rr < RS && n0 < N && tile > 0) {
+                            const float *xi = xp + ((xrow0 + (size_t)(kb + rr) * p.n_chunks + tile - 1) * N + n0) * 2;
+                            hsave[rr][j].x = xi[1];
+                            if (n0 + 1 < N) hsave[rr][j].y = xi[3];
+                        }
+                    }
+            }
+            if (__builtin_amdgcn_ballot_w64(flag) != 0 && lane == 0) sflag[batch & 1] = 1;
+            lds_barrier();
+            const bool robust = sflag[batch & 1] != 0;
+            if (tid == 0) sflag[(batch + 1) & 1] = 0;
+            ++batch;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr >= RS) break;
+                const int r = kb + rr;
+                const float *st = stage + (size_t)rr * 4 * kTile + lane * kItems;
+                const float4 dl4 = *reinterpret_cast<const float4 *>(st), u4 = *reinterpret_cast<const float4 *>(st + kTile);
+                const float4 dy4 = *reinterpret_cast<const float4 *>(st + 2 * kTile), du4 = *reinterpret_cast<const float4 *>(st + 3 * kTile);
+                const float dl[kItems] = {dl4.x, dl4.y, dl4.z, dl4.w}, uv[kItems] = {u4.x, u4.y, u4.z, u4.w};
+                const float dov[kItems] = {dy4.x, dy4.y, dy4.z, dy4.w}, du_[kItems] = {du4.x, du4.y, du4.z, du4.w};
+                v2f du2[kItems], dd2[kItems];
+#pragma unroll
+                for (int i = 0; i < kItems; ++i) { du2[i] = splat(0.f); dd2[i] = splat(0.f); }
+#pragma unroll
+                for (int j = 0; j < PP; ++j) {
+                    const int n0 = 2 * (wave * PP + j);
+                    if (n0 >= N) continue;
+                    const bool has1 = n0 + 1 < N;
                     const v2f A2 = *reinterpret_cast<const v2f *>(sA + r * NP2 + n0);
                     v2f a[kItems], e[kItems], be[kItems];
-                    if (robust) {
-#pragma unroll
-                        for (int i = 0; i < kItems; ++i) a[i] = decay2<true>(dl[r][i], A2);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < kItems; ++i) a[i] = decay2<false>(dl[r][i], A2);
-                    }
+                    if (robust) decay2x4<true>(dl, A2, a);
+                    else decay2x4<false>(dl, A2, a);
                     // adjoint elements (a_t, a_t dout_t C_t), composed against the scan order
 #pragma unroll
                     for (int i = 0; i < kItems; ++i) {
-                        be[i] = splat(dov[r][i]) * Cv[i];
+                        be[i] = splat(dov[i]) * Cv[j][i];
                         e[i] = a[i] * be[i];
                     }
                     Pair2 ragg{a[kItems - 1], e[kItems - 1]};
@@ -441,30 +590,19 @@ __global__ __launch_bounds__(512) void sscan_nbwd_kernel(const vmasr_sscan_bwd_p
                     wave_scan_rev2(ragg, lane, rexcl, rtot);
                     const size_t ci = ((xrow0 + (size_t)r * p.n_chunks + tile) * N + n0) * 2;
                     if constexpr (MODE == 2) {
-                        if (lane == 0) {
-                            if (xvec) *reinterpret_cast<float4 *>(ws + ci) = make_float4(rtot.a.x, rtot.b.x, rtot.a.y, rtot.b.y);
-                            else {
-                                *reinterpret_cast<float2 *>(ws + ci) = make_float2(rtot.a.x, rtot.b.x);
-                                if (has1) *reinterpret_cast<float2 *>(ws + ci + 2) = make_float2(rtot.a.y, rtot.b.y);
-                            }
-                        }
+                        if (lane == 0) store_pair(ws + ci, xvec, has1, rtot.a, rtot.b);
                         continue;
                     }
                     // forward recurrence of this tile restarted from the saved state
-                    v2f hin = splat(0.f);
-                    if (tile > 0) {
-                        const float *xi = xp + ci - (size_t)N * 2;
-                        hin.x = xi[1];
-                        if (has1) hin.y = xi[3];
-                    }
+                    const v2f hin = hsave[rr][j];
                     v2f bb[kItems], hv[kItems];
 #pragma unroll
-                    for (int i = 0; i < kItems; ++i) bb[i] = splat(du_[r][i]) * Bv[i];
+                    for (int i = 0; i < kItems; ++i) bb[i] = splat(du_[i]) * Bv[j][i];
                     Pair2 agg{a[0], bb[0]};
 #pragma unroll
                     for (int i = 1; i < kItems; ++i) agg = then2(agg, Pair2{a[i], bb[i]});
                     Pair2 excl, tot;
-                    wave_scan_fwd2(agg, excl, tot);
+                    wave_scan_fwd2<false>(agg, excl, tot);   // (the end-of-tile state is not needed: x holds it)
                     v2f h = fma2(excl.a, hin, excl.b);
 #pragma unroll
                     for (int i = 0; i < kItems; ++i) { h = fma2(a[i], h, bb[i]); hv[i] = h; }
@@ -477,14 +615,14 @@ __global__ __launch_bounds__(512) void sscan_nbwd_kernel(const vmasr_sscan_bwd_p
                     for (int i = kItems - 1; i >= 0; --i) {
                         const v2f gcur = be[i] + Gn;          // adjoint of h at this step
                         Gn = a[i] * gcur;
-                        const v2f gB = gcur * Bv[i];
+                        const v2f gB = gcur * Bv[j][i];
                         const v2f ax = hv[i] - bb[i];         // a_t h_{t-1}
-                        du2[r][i] = fma2(gB, splat(dl[r][i]), du2[r][i]);
-                        dd2[r][i] = fma2(gB, splat(uv[r][i]), dd2[r][i]);
-                        dd2[r][i] = fma2(gcur * Ar, ax, dd2[r][i]);
-                        accA = fma2(gcur * splat(dl[r][i]), ax, accA);
-                        dBv[i] = fma2(gcur, splat(du_[r][i]), dBv[i]);
-                        dCv[i] = fma2(splat(dov[r][i]), hv[i], dCv[i]);
+                        du2[i] = fma2(gB, splat(dl[i]), du2[i]);
+                        dd2[i] = fma2(gB, splat(uv[i]), dd2[i]);
+                        dd2[i] = fma2(gcur * Ar, ax, dd2[i]);
+                        accA = fma2(gcur * splat(dl[i]), ax, accA);
+                        dBv[j][i] = fma2(gcur, splat(du_[i]), dBv[j][i]);
+                        dCv[j][i] = fma2(splat(dov[i]), hv[i], dCv[j][i]);
                     }
                     const float sA0 = wave_sum(accA.x), sA1 = wave_sum(accA.y);
                     const v2f Gout = fma2(rtot.a, Gin, rtot.b);
@@ -493,186 +631,245 @@ __global__ __launch_bounds__(512) void sscan_nbwd_kernel(const vmasr_sscan_bwd_p
                         v2f *acc = reinterpret_cast<v2f *>(sdA + r * NP2 + n0);
                         *acc = *acc + (v2f){sA0, sA1};
                     }
-                    __builtin_amdgcn_sched_barrier(0);   // one row at a time: interleaving the rows only multiplies the live registers
                 }
                 if constexpr (MODE != 2) {
-                    if (W == 1) {
-                        float *dst[4] = {dBg + (size_t)n0 * L, dBg + (size_t)(n0 + 1) * L, dCg + (size_t)n0 * L, dCg + (size_t)(n0 + 1) * L};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if ((k & 1) && !has1) continue;
-                            float v4[kItems];
-#pragma unroll
-                            for (int i = 0; i < kItems; ++i) v4[i] = k == 0 ? dBv[i].x : (k == 1 ? dBv[i].y : (k == 2 ? dCv[i].x : dCv[i].y));
-                            if (geo.wg_per_group == 1) {
-                                store4u<float, VEC>(dst[k], t0, L, v4, full);
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < kItems; ++i)
-                                    if (full || t0 + i < L) atomicAdd(dst[k] + t0 + i, v4[i]);
-                            }
-                        }
-                    } else {
-                        float *mine = red + ((size_t)(wave * geo.PB + pp) * 4) * kTile + lane * kItems;
-                        *reinterpret_cast<float4 *>(mine) = make_float4(dBv[0].x, dBv[1].x, dBv[2].x, dBv[3].x);
-                        *reinterpret_cast<float4 *>(mine + kTile) = make_float4(dBv[0].y, dBv[1].y, dBv[2].y, dBv[3].y);
-                        *reinterpret_cast<float4 *>(mine + 2 * kTile) = make_float4(dCv[0].x, dCv[1].x, dCv[2].x, dCv[3].x);
-                        *reinterpret_cast<float4 *>(mine + 3 * kTile) = make_float4(dCv[0].y, dCv[1].y, dCv[2].y, dCv[3].y);
-                    }
+                    float *pt = part + (size_t)(rr * W + wave) * 2 * kTile + lane * kItems;
+                    *reinterpret_cast<float4 *>(pt) = make_float4(du2[0].x + du2[0].y, du2[1].x + du2[1].y, du2[2].x + du2[2].y, du2[3].x + du2[3].y);
+                    *reinterpret_cast<float4 *>(pt + kTile) = make_float4(dd2[0].x + dd2[0].y, dd2[1].x + dd2[1].y, dd2[2].x + dd2[2].y, dd2[3].x + dd2[3].y);
                 }
             }
+            lds_barrier();
+            // ---- epilogue: du = D dout + sum over states, ddelta = (sum over states) * softplus'; dD, ddelta_bias partials
             if constexpr (MODE != 2) {
-                if (W > 1) {
-                    // sum the W partial tiles of this block of pairs; leave as contiguous runs along the sequence
-                    lds_barrier();
-                    const int tbase = tile * kTile;
-                    for (int eidx = threadIdx.x; eidx < npb * 4 * kTile; eidx += blockDim.x) {
-                        const int idx = eidx % kTile, k = (eidx / kTile) % 4, pp = eidx / (4 * kTile);
-                        const int n = 2 * (pb0 + pp) + (k & 1);
-                        const int t = tbase + idx;
-                        if (n >= N || t >= L) continue;
-                        float s = 0.f;
-                        for (int w = 0; w < W; ++w) s += red[((size_t)(w * geo.PB + pp) * 4 + k) * kTile + idx];
-                        float *dst = ((k & 2) ? dCg : dBg) + (size_t)n * L + t;
-                        if (geo.wg_per_group == 1) *dst = s; else atomicAdd(dst, s);
+#pragma unroll
+                for (int qi = 0; qi < Q; ++qi) {
+                    const int pos = qi * nthr + tid;
+                    if (qi * nthr + wave * kWave < RS * kTile) {   // wave-uniform: the 64 positions of a wave lie in one row
+                        const int rr = pos / kTile, idx = pos % kTile, r = kb + rr, t = tile * kTile + idx;
+                        float du = sDk[r] * dyq[qi], dd = 0.f;
+                        const float *pt = part + (size_t)rr * W * 2 * kTile + idx;
+                        int w = 0;
+                        for (; w + 4 <= W; w += 4) {   // eight independent LDS reads in flight
+                            du += (pt[(w + 0) * 2 * kTile] + pt[(w + 1) * 2 * kTile]) + (pt[(w + 2) * 2 * kTile] + pt[(w + 3) * 2 * kTile]);
+                            dd += (pt[(w + 0) * 2 * kTile + kTile] + pt[(w + 1) * 2 * kTile + kTile]) +
+                                  (pt[(w + 2) * 2 * kTile + kTile] + pt[(w + 3) * 2 * kTile + kTile]);
+                        }
+                        for (; w < W; ++w) {
+                            du += pt[w * 2 * kTile];
+                            dd += pt[w * 2 * kTile + kTile];
+                        }
+                        dd *= sg[qi];
+                        if (t < L) {
+                            dub[(d0 + r) * q.du_d_stride + t] = from_f32<T>(du);
+                            ddb[(d0 + r) * q.ddelta_d_stride + t] = from_f32<T>(dd);
+                        } else {
+                            dd = 0.f;
+                        }
+                        const float sD = wave_sum(pdq[qi]), sB = wave_sum(dd);
+                        if (lane == 0) {   // slot (row, wave & 3): written by this wave only
+                            saccD[r * 4 + (wave & 3)] += sD;
+                            saccB[r * 4 + (wave & 3)] += sB;
+                        }
                     }
-                    lds_barrier();
                 }
             }
         }
         if constexpr (MODE != 2) {
+            // dB / dC of my pairs, summed over the RB rows in registers.  One workgroup per group: 16-byte stores.  Otherwise float
+            // atomics, transposed through a per-wave LDS kilobyte so that every atomic instruction covers 64 CONSECUTIVE floats
+            // (two 128-byte lines) instead of one float out of every four (eight lines): the L2 performs one pass per line.
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float duv[kItems], ddv[kItems];
+            for (int j = 0; j < PP; ++j) {
+                const int n0 = 2 * (wave * PP + j);
+                if (n0 >= N) continue;
 #pragma unroll
-                for (int i = 0; i < kItems; ++i) {
-                    duv[i] = fmaf(Dv[r], dov[r][i], du2[r][i].x + du2[r][i].y);
-                    ddv[i] = (dd2[r][i].x + dd2[r][i].y) * sig[r][i];
-                    accBias[r] += (full || t0 + i < L) ? ddv[i] : 0.f;
+                for (int k = 0; k < 4; ++k) {
+                    const int n = n0 + (k & 1);
+                    if (n >= N) continue;
+                    float v4[kItems];
+#pragma unroll
+                    for (int i = 0; i < kItems; ++i) v4[i] = k == 0 ? dBv[j][i].x : (k == 1 ? dBv[j][i].y : (k == 2 ? dCv[j][i].x : dCv[j][i].y));
+                    float *dst = ((k & 2) ? dCg : dBg) + (size_t)n * L;
+                    if (geo.nrb == 1) {
+                        store4u<float, VEC>(dst, t0, L, v4, full);
+                    } else {
+                        float *tr = xpose + wave * kTile;
+                        *reinterpret_cast<float4 *>(tr + lane * kItems) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                        // (same wave writes and reads: LDS operations of a wave complete in order)
+#pragma unroll
+                        for (int i = 0; i < kItems; ++i) {
+                            const int t = tile * kTile + i * kWave + lane;
+                            const float v = tr[i * kWave + lane];
+                            if (full || t < L) atomicAdd(dst + t, v);
+                        }
+                    }
                 }
-                store4u<T, VEC>(du_row[r], t0, L, duv, full);
-                store4u<T, VEC>(dd_row[r], t0, L, ddv, full);
             }
         }
     }
     if constexpr (MODE != 2) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int d = d0 + r;
-            const float sD = wave_sum(accD[r]), sB = wave_sum(accBias[r]);
-            if (lane == 0) {
-                if (q.dD_ptr) atomicAdd(static_cast<float *>(q.dD_ptr) + d, sD);
-                if (q.ddelta_bias_ptr) atomicAdd(static_cast<float *>(q.ddelta_bias_ptr) + d, sB);
-            }
-            for (int n = lane; n < N; n += kWave)
-                atomicAdd(static_cast<float *>(q.dA_ptr) + d * q.dA_d_stride + n * q.dA_dstate_stride, sdA[r * NP2 + n]);
+        __syncthreads();
+        for (int e = tid; e < RB * N; e += nthr) {
+            const int r = e / N, n = e % N;
+            atomicAdd(static_cast<float *>(q.dA_ptr) + (d0 + r) * q.dA_d_stride + n * q.dA_dstate_stride, sdA[r * NP2 + n]);
         }
+        for (int r = tid; r < RB; r += nthr) {
+            if (q.dD_ptr) atomicAdd(static_cast<float *>(q.dD_ptr) + d0 + r, (saccD[r * 4] + saccD[r * 4 + 1]) + (saccD[r * 4 + 2] + saccD[r * 4 + 3]));
+            if (q.ddelta_bias_ptr)
+                atomicAdd(static_cast<float *>(q.ddelta_bias_ptr) + d0 + r, (saccB[r * 4] + saccB[r * 4 + 1]) + (saccB[r * 4 + 2] + saccB[r * 4 + 3]));
+        }
+        det_leave(geo.det);
     }
-    det_leave(geo.det);
 }
 
-}  // namespace
+// ---- launch plan -------------------------------------------------------------------------------------------------------
+struct PPlan {
+    int PP, W, RB, RS, nrb, nseg, tiles_per_task, split;
+};
 
-// ---- host side --------------------------------------------------------------------------------------------------------
-int sscan_n_fwd(const vmasr_sscan_params &p, int split, int tiles_per_task, int nseg, bool vec, hipStream_t st) {
+int g_plan_rb = 0;   // tuning override (VMASR_SSCAN_N_RB): rows per workgroup
+
+PPlan make_pplan(const vmasr_sscan_params &p, int split_req) {
+    PPlan pl{};
+    const int np = (p.dstate + 1) / 2, D = p.dim / p.n_groups;
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
+    pl.PP = np <= 16 ? 1 : (np <= 32 ? 2 : (np <= 64 ? 4 : 8));
+    pl.W = (np + pl.PP - 1) / pl.PP;
+    pl.RS = (pl.W >= 8 && D % 2 == 0) ? 2 : 1;
+    // workgroups wanted: one 16-wave workgroup per CU, or enough smaller ones for ~4096 waves
+    const long target = std::max(256L, 4096L / pl.W);
+    const long rows = (long)p.batch * p.dim;
+    static const int env_rb = [] { const char *e = getenv("VMASR_SSCAN_N_RB"); return e ? atoi(e) : 0; }();
+    long rb = env_rb > 0 ? env_rb : std::max(1L, rows / target);
+    rb = std::min<long>(rb, 64);
+    int RB = pl.RS;
+    for (int c = pl.RS; c <= D && c <= rb; c += pl.RS)
+        if (D % c == 0) RB = c;
+    pl.RB = RB;
+    pl.nrb = D / RB;
+    const long wgs = (long)p.batch * p.n_groups * pl.nrb;
+    int nseg = 1;
+    if (split_req == 1 || (split_req < 0 && wgs * 2 <= target)) nseg = (int)std::min<long>(ntiles, std::max(2L, (target + wgs - 1) / wgs));
+    if (ntiles < 2) nseg = 1;
+    pl.tiles_per_task = (ntiles + nseg - 1) / nseg;
+    pl.nseg = (ntiles + pl.tiles_per_task - 1) / pl.tiles_per_task;
+    pl.split = pl.nseg > 1 ? 1 : 0;
+    if (split_req == 1 && ntiles >= 2) pl.split = 1;
+    return pl;
+}
+
+size_t fwd_lds_floats(const PPlan &pl, int np) { return align4(3 * pl.RB * 2 * np + 3 * pl.RB) + (size_t)pl.RS * 2 * kTile + (size_t)pl.RS * pl.W * kTile + 4; }
+size_t bwd_lds_floats(const PPlan &pl, int np) {
+    return align4(4 * pl.RB * 2 * np + 11 * pl.RB) + (size_t)pl.RS * 4 * kTile + (size_t)pl.RS * pl.W * 2 * kTile + 4 + (pl.nrb > 1 ? (size_t)pl.W * kTile : 0);
+}
+
+template <typename T, bool VEC, int MODE>
+void launch_pfwd(int kid, double bytes, const vmasr_sscan_params &p, const PPlan &pl, hipStream_t st) {
     const int np = (p.dstate + 1) / 2;
-    const NFwdGeom geo{tiles_per_task, nseg, np};
-    const long ntasks = (long)p.batch * p.dim * nseg;
-    const int nblocks = (int)((ntasks + 3) / 4);
-    const size_t smem = (size_t)4 * 3 * 2 * np * sizeof(float);
+    const PGeom geo{pl.tiles_per_task, pl.nseg, np, pl.W, pl.RB, pl.RS, pl.nrb, nullptr};
+    const dim3 grid((unsigned)((long)p.batch * pl.nseg * p.n_groups * pl.nrb)), block(64 * pl.W);
+    const size_t smem = fwd_lds_floats(pl, np) * sizeof(float);
+#define VMASR_PF(PPV, QV)                                                                                                          \
+    do {                                                                                                                           \
+        if (smem > 64 * 1024)                                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sscan_pfwd_kernel<T, VEC, PPV, QV, MODE>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                      \
+        VMASR_LAUNCH(kid, bytes, (sscan_pfwd_kernel<T, VEC, PPV, QV, MODE>), grid, block, smem, st, p, geo);                       \
+    } while (0)
+    // (PP > 1 only when there are more than 16 pairs, i.e. W >= 9 waves: one position per thread)
+    if (pl.PP == 1) {
+        if (pl.W >= 4) VMASR_PF(1, 1); else if (pl.W >= 2) VMASR_PF(1, 2); else VMASR_PF(1, 4);
+    } else if (pl.PP == 2) VMASR_PF(2, 1);
+    else if (pl.PP == 4) VMASR_PF(4, 1);
+    else VMASR_PF(8, 1);
+#undef VMASR_PF
+}
+
+template <typename T, bool VEC, int MODE>
+void launch_pbwd(int kid, double bytes, const vmasr_sscan_bwd_params &q, const PPlan &pl, unsigned *det, hipStream_t st) {
+    const vmasr_sscan_params &p = q.f;
+    const int np = (p.dstate + 1) / 2;
+    const PGeom geo{pl.tiles_per_task, pl.nseg, np, pl.W, pl.RB, pl.RS, pl.nrb, det};
+    const dim3 grid((unsigned)((long)p.batch * pl.nseg * p.n_groups * pl.nrb)), block(64 * pl.W);
+    const size_t smem = bwd_lds_floats(pl, np) * sizeof(float);
+#define VMASR_PB(PPV, QV)                                                                                                          \
+    do {                                                                                                                           \
+        if (smem > 64 * 1024)                                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sscan_pbwd_kernel<T, VEC, PPV, QV, MODE>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                      \
+        VMASR_LAUNCH(kid, bytes, (sscan_pbwd_kernel<T, VEC, PPV, QV, MODE>), grid, block, smem, st, q, geo);                       \
+    } while (0)
+    if (pl.PP == 1) {
+        if (pl.W >= 4) VMASR_PB(1, 1); else if (pl.W >= 2) VMASR_PB(1, 2); else VMASR_PB(1, 4);
+    } else if (pl.PP == 2) VMASR_PB(2, 1);
+    else if (pl.PP == 4) VMASR_PB(4, 1);
+    else VMASR_PB(8, 1);
+#undef VMASR_PB
+}
+
+template <typename T, bool VEC>
+int run_pfwd(const vmasr_sscan_params &p, const PPlan &pl, hipStream_t st) {
+    const int ntiles = (p.seqlen + kTile - 1) / kTile;
     // algorithmic bytes: read u, delta, B, C; write out
-    const double es = p.dtype == VMASR_F32 ? 4 : 2, KD = p.dim, KN = (double)p.n_groups * p.dstate, BL = (double)p.batch * p.seqlen;
+    const double es = sizeof(T), KD = p.dim, KN = (double)p.n_groups * p.dstate, BL = (double)p.batch * p.seqlen;
     const double full = (3 * KD + 2 * KN) * BL * es, agg = (2 * KD + KN) * BL * es;
     const double xb = (double)p.batch * p.dim * ntiles * p.dstate * 2 * 4 * 2;
-#define VMASR_NFWD(MODE, KID, BYTES)                                                                                             \
-    do {                                                                                                                          \
-        if (p.dtype == VMASR_F32) {                                                                                               \
-            if (vec) VMASR_LAUNCH(KID, BYTES, (sscan_nfwd_kernel<float, true, MODE>), dim3(nblocks), dim3(256), smem, st, p, geo); \
-            else VMASR_LAUNCH(KID, BYTES, (sscan_nfwd_kernel<float, false, MODE>), dim3(nblocks), dim3(256), smem, st, p, geo);    \
-        } else if (p.dtype == VMASR_F16) {                                                                                        \
-            if (vec) VMASR_LAUNCH(KID, BYTES, (sscan_nfwd_kernel<f16_t, true, MODE>), dim3(nblocks), dim3(256), smem, st, p, geo); \
-            else VMASR_LAUNCH(KID, BYTES, (sscan_nfwd_kernel<f16_t, false, MODE>), dim3(nblocks), dim3(256), smem, st, p, geo);    \
-        } else {                                                                                                                  \
-            if (vec) VMASR_LAUNCH(KID, BYTES, (sscan_nfwd_kernel<bf16_t, true, MODE>), dim3(nblocks), dim3(256), smem, st, p, geo); \
-            else VMASR_LAUNCH(KID, BYTES, (sscan_nfwd_kernel<bf16_t, false, MODE>), dim3(nblocks), dim3(256), smem, st, p, geo);   \
-        }                                                                                                                         \
-    } while (0)
-    if (split != 1) {
-        VMASR_NFWD(0, VMASR_K_SSCAN_FWD, full);
+    if (!pl.split) {
+        launch_pfwd<T, VEC, 0>(VMASR_K_SSCAN_FWD, full, p, pl, st);
         return check_launch("sscan_fwd(N)");
     }
-    VMASR_NFWD(2, VMASR_K_SSCAN_FWD_AGG, agg);
+    launch_pfwd<T, VEC, 2>(VMASR_K_SSCAN_FWD_AGG, agg, p, pl, st);
     sscan_launch_carry(false, static_cast<float *>(p.x_ptr), p.batch * p.dim * p.dstate, ntiles, p.dstate, xb, st);
-    VMASR_NFWD(1, VMASR_K_SSCAN_FWD_APPLY, full);
-#undef VMASR_NFWD
+    launch_pfwd<T, VEC, 1>(VMASR_K_SSCAN_FWD_APPLY, full, p, pl, st);
     return check_launch("sscan_fwd(N, split)");
 }
 
-namespace {
-
-template <typename T, int R>
-int launch_nbwd(const vmasr_sscan_bwd_params &q, int split, int tiles_per_task, int nseg, bool vec, hipStream_t st) {
+template <typename T, bool VEC>
+int run_pbwd(const vmasr_sscan_bwd_params &q, const PPlan &pl, hipStream_t st) {
     const vmasr_sscan_params &p = q.f;
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
-    const int np = (p.dstate + 1) / 2;
-    const int rbg = (p.dim / p.n_groups) / R;   // row-blocks per group
-    static const int env_w = [] { const char *e = getenv("VMASR_NBWD_WAVES"); return e ? atoi(e) : 0; }();
-    static const int env_pb = [] { const char *e = getenv("VMASR_NBWD_PB"); return e ? atoi(e) : 0; }();
-    int W = env_w > 0 ? env_w : 4;
-    if (W > 8) W = 8;
-    while (rbg % W) W >>= 1;
-    const int PB = W > 1 ? std::min(np, env_pb > 0 ? env_pb : 2) : 1;
-    NBwdGeom geo{tiles_per_task, nseg, W, rbg / W, np, PB, nullptr};
-    const long nblocks = (long)p.batch * nseg * p.n_groups * geo.wg_per_group;
-    const size_t smem_state = (size_t)W * 4 * R * 2 * np * sizeof(float);
-    const size_t smem = smem_state + (W > 1 ? (size_t)W * PB * 4 * kTile * sizeof(float) : 0);
-    VMASR_REQUIRE(smem <= 160 * 1024, VMASR_EINVAL, "sscan_bwd: d_state %d needs %zu bytes of LDS", p.dstate, smem);
     // algorithmic bytes: read u, delta, dout, B, C; write du, ddelta, dB, dC (dB / dC fp32)
     const double es = sizeof(T), KD = p.dim, KN = (double)p.n_groups * p.dstate, BL = (double)p.batch * p.seqlen;
     const double full = (5 * KD * es + 2 * KN * es + 2 * KN * 4) * BL, agg = (2 * KD + KN) * BL * es;
     const double xb = (double)p.batch * p.dim * ntiles * p.dstate * 2 * 4 * 2;
-#define VMASR_NBWD(MODE, KID, BYTES, SM)                                                                                          \
-    do {                                                                                                                          \
-        if (vec) VMASR_LAUNCH(KID, BYTES, (sscan_nbwd_kernel<T, R, true, MODE>), dim3((int)nblocks), dim3(64 * W), SM, st, q, geo); \
-        else VMASR_LAUNCH(KID, BYTES, (sscan_nbwd_kernel<T, R, false, MODE>), dim3((int)nblocks), dim3(64 * W), SM, st, q, geo);    \
-    } while (0)
-    if (smem > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sscan_nbwd_kernel<T, R, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sscan_nbwd_kernel<T, R, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sscan_nbwd_kernel<T, R, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sscan_nbwd_kernel<T, R, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    }
-    if (split != 1) {
-        geo.det = det_ticket(VMASR_K_SSCAN_BWD);
-        VMASR_NBWD(0, VMASR_K_SSCAN_BWD, full, smem);
+    if (!pl.split) {
+        launch_pbwd<T, VEC, 0>(VMASR_K_SSCAN_BWD, full, q, pl, det_ticket(VMASR_K_SSCAN_BWD), st);
         return check_launch("sscan_bwd(N)");
     }
-    VMASR_NBWD(2, VMASR_K_SSCAN_BWD_AGG, agg, smem_state);
+    launch_pbwd<T, VEC, 2>(VMASR_K_SSCAN_BWD_AGG, agg, q, pl, nullptr, st);
     sscan_launch_carry(true, static_cast<float *>(q.ws_ptr), p.batch * p.dim * p.dstate, ntiles, p.dstate, xb, st);
-    geo.det = det_ticket(VMASR_K_SSCAN_BWD_APPLY);
-    VMASR_NBWD(1, VMASR_K_SSCAN_BWD_APPLY, full, smem);
-#undef VMASR_NBWD
+    launch_pbwd<T, VEC, 1>(VMASR_K_SSCAN_BWD_APPLY, full, q, pl, det_ticket(VMASR_K_SSCAN_BWD_APPLY), st);
     return check_launch("sscan_bwd(N, split)");
-}
-
-template <typename T>
-int dispatch_nbwd(const vmasr_sscan_bwd_params &q, int split, int tiles_per_task, int nseg, int rows, bool vec, hipStream_t st) {
-    const int rpg = q.f.dim / q.f.n_groups;
-    int R = rows > 0 ? rows : 2;
-    while (R > 1 && rpg % R) R >>= 1;
-    if (R >= 4) return launch_nbwd<T, 4>(q, split, tiles_per_task, nseg, vec, st);
-    if (R == 2) return launch_nbwd<T, 2>(q, split, tiles_per_task, nseg, vec, st);
-    return launch_nbwd<T, 1>(q, split, tiles_per_task, nseg, vec, st);
 }
 
 }  // namespace
 
-int sscan_n_bwd(const vmasr_sscan_bwd_params &q, int split, int tiles_per_task, int nseg, int rows, bool vec, hipStream_t st) {
-    switch (q.f.dtype) {
-        case VMASR_F32: return dispatch_nbwd<float>(q, split, tiles_per_task, nseg, rows, vec, st);
-        case VMASR_F16: return dispatch_nbwd<f16_t>(q, split, tiles_per_task, nseg, rows, vec, st);
-        default: return dispatch_nbwd<bf16_t>(q, split, tiles_per_task, nseg, rows, vec, st);
+// ---- entry points (called from sscan.hip) ------------------------------------------------------------------------------
+size_t sscan_n_bwd_ws_floats(const vmasr_sscan_params &p, int split_req) {
+    const PPlan pl = make_pplan(p, split_req);
+    if (!pl.split) return 0;
+    const size_t ntiles = (p.seqlen + kTile - 1) / kTile;
+    return (size_t)p.batch * p.dim * ntiles * p.dstate * 2;   // reverse aggregates -> adjoint carries
+}
+
+int sscan_n_fwd(const vmasr_sscan_params &p, int split_req, bool vec, hipStream_t st) {
+    const PPlan pl = make_pplan(p, split_req);
+    VMASR_REQUIRE(fwd_lds_floats(pl, (p.dstate + 1) / 2) * sizeof(float) <= 160 * 1024, VMASR_EINVAL, "sscan_fwd: d_state %d needs too much LDS", p.dstate);
+    switch (p.dtype) {
+        case VMASR_F32: return vec ? run_pfwd<float, true>(p, pl, st) : run_pfwd<float, false>(p, pl, st);
+        case VMASR_F16: return vec ? run_pfwd<f16_t, true>(p, pl, st) : run_pfwd<f16_t, false>(p, pl, st);
+        default: return vec ? run_pfwd<bf16_t, true>(p, pl, st) : run_pfwd<bf16_t, false>(p, pl, st);
+    }
+}
+
+int sscan_n_bwd(const vmasr_sscan_bwd_params &q, int split_req, bool vec, hipStream_t st) {
+    const vmasr_sscan_params &p = q.f;
+    const PPlan pl = make_pplan(p, split_req);
+    VMASR_REQUIRE(bwd_lds_floats(pl, (p.dstate + 1) / 2) * sizeof(float) <= 160 * 1024, VMASR_EINVAL, "sscan_bwd: d_state %d needs too much LDS", p.dstate);
+    switch (p.dtype) {
+        case VMASR_F32: return vec ? run_pbwd<float, true>(q, pl, st) : run_pbwd<float, false>(q, pl, st);
+        case VMASR_F16: return vec ? run_pbwd<f16_t, true>(q, pl, st) : run_pbwd<f16_t, false>(q, pl, st);
+        default: return vec ? run_pbwd<bf16_t, true>(q, pl, st) : run_pbwd<bf16_t, false>(q, pl, st);
     }
 }
 
