@@ -15,12 +15,12 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 sys.path.insert(0, GOLDEN)
 
 
-def _model(hop, dims=16, n_fft=1024, win=1024):
+def _model(hop, dims=16, n_fft=1024, win=1024, d_state=1):
     from synth import synth_state
     from vm_asr_amd.model import DualStreamInteractiveMambaUNet
     torch.manual_seed(123)
     m = DualStreamInteractiveMambaUNet(
-        in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=dims, ssm_d_state=1, ssm_ratio=2.0, ssm_dt_rank="auto",
+        in_chans=1, patch_size=4, depths=[2, 2, 2, 2], dims=dims, ssm_d_state=d_state, ssm_ratio=2.0, ssm_dt_rank="auto",
         ssm_act_layer="silu", ssm_conv=3, ssm_conv_bias=True, ssm_drop_rate=0.0, ssm_init="v0", forward_type="v5",
         mlp_ratio=4.0, mlp_act_layer="gelu", mlp_drop_rate=0.0, gmlp=False, drop_path_rate=0.1, patch_norm=True,
         norm_layer="LN", patchembed_version="v2", downsample_version="v1", upsample_version="v1",
@@ -435,3 +435,47 @@ def test_dstate32_nfft2048_model_forward_hip_vs_oracle():
     assert y.shape == (1, 1, T) and np.isfinite(y).all()
     assert e.max() <= K_MAX * ec.max() + 1e-4 * peak and _rms(e) <= K_RMS * _rms(ec) + 1e-5 * peak
     assert e.max() <= 5e-3 * peak and _rms(e) <= 2e-4 * peak
+
+
+@pytest.mark.gpu
+def test_dstate32_model_backward_hip_fp64_adjudicated():
+    """BASELINE configs[4] as worded (`MODEL.VSSM.SSM_D_STATE 32`, config.py:100) at MODEL level, BACKWARD: the general-N scan
+    (csrc/sscan_n.hip: cus/selective_scan_bwd_kernel.cuh:125-241 with its loop over 32 states) inside the real network — dims 32
+    (d_inner 4 .. 512, dt_rank 1 .. 16), n_fft 256 so that one clip is 128 x 128 bins (L = 16 384 .. 16 for the scan calls).
+    Every parameter gradient of the HIP fp32 path against the float64 evaluation of the same module (tests/f64ref.py on the GPU),
+    with the CPU oracle's fp32 backward beside it: the HIP path must be as close to float64 as the sequential fp32 reference."""
+    import f64ref
+    from oracle.torch_backend import oracle_stft_patch, use_oracle
+    n_fft, hop, dims = 256, 64, 32
+    T = hop * 127
+    g = torch.Generator().manual_seed(3232)
+    wave = 0.1 * torch.randn(1, 1, T, generator=g)
+    gy = torch.randn(1, 1, T, generator=g)
+    hf = torch.full((1,), int((n_fft // 2 + 1) * 16000 / 48000), dtype=torch.int64)
+    m_gpu = _model(hop, dims, n_fft, n_fft, d_state=32).to("cuda:0")
+    assert all(mod.d_state == 32 for mod in m_gpu.modules() if hasattr(mod, "d_state"))
+    m64 = f64ref.model64(m_gpu)
+    with f64ref.Patch(f64ref.FAMILIES):
+        (m64(wave.double().cuda(), hf.cuda()) * gy.double().cuda()).sum().backward()
+    y = m_gpu(wave.cuda(), hf.cuda()).float()
+    (y * gy.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    m_cpu = use_oracle(_model(hop, dims, n_fft, n_fft, d_state=32))
+    with oracle_stft_patch():
+        (m_cpu(wave, hf) * gy).sum().backward()
+    g64 = {n: p.grad for n, p in m64.named_parameters()}
+    got = {n: p.grad for n, p in m_gpu.named_parameters()}
+    ref = {n: p.grad for n, p in m_cpu.named_parameters()}
+    assert all((got[n] is None) == (g64[n] is None) == (ref[n] is None) for n in g64)
+    names = [n for n in g64 if g64[n] is not None]
+    assert any("A_logs" in n for n in names) and all(torch.isfinite(got[n]).all() for n in names)
+    floor = 1e-5 * max(g64[n].norm().item() for n in names)
+    e_hip = {n: (got[n].double() - g64[n]).norm().item() for n in names}
+    e_cpu = {n: (ref[n].double().cuda() - g64[n]).norm().item() for n in names}
+    tot64 = sum(g64[n].pow(2).sum() for n in names).sqrt().item()
+    t_hip, t_cpu = (sum(v ** 2 for v in e.values()) ** 0.5 / tot64 for e in (e_hip, e_cpu))
+    ratio = sorted(e_hip[n] / (e_cpu[n] + floor) for n in names)
+    print(f"[d_state 32, dims 32, 128x128] backward vs float64: whole-vector rel L2  hip {t_hip:.2e}  cpu-oracle fp32 {t_cpu:.2e}; "
+          f"per-tensor ratio median {ratio[len(ratio) // 2]:.2f}, 95th percentile {ratio[int(0.95 * len(ratio))]:.2f}, max {ratio[-1]:.2f}")
+    assert t_hip <= 3e-3 and t_hip <= 1.0 * t_cpu, (t_hip, t_cpu)          # measured 6.0e-4 vs 1.2e-3 (0.5x)
+    assert ratio[int(0.95 * len(ratio))] <= 2.0 and ratio[-1] <= 4.0, (ratio[int(0.95 * len(ratio))], ratio[-1])
