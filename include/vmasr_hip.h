@@ -302,6 +302,9 @@ typedef struct vmasr_cg_slot {
     int32_t reserved;
 } vmasr_cg_slot;
 int vmasr_conv_mfma_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride);
+/* The same for one stacked launch of `n` slots over `rows` operand rows (the largest of the layer's input and output row counts):
+ * also checks the launchers' slot and 32-bit row-offset bounds (forward, input gradient and weight gradient).  Dispatch on this. */
+int vmasr_conv_mfma_supported_launch(int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t n, int64_t rows);
 /* CUs the conv_mfma kernels may occupy from now on (process-wide; 0 = all, the default): launched with fewer workgroups than
  * tiles they loop over the tiles.  Used by the two-stream train step while other kernels run beside them; results do
  * not depend on it. */
@@ -636,8 +639,9 @@ enum {
 };
 /* Deterministic-reduction switch (debug aid, off by default; the Python side turns it on for VMASR_DETERMINISTIC=1): the kernels whose
  * parameter-gradient sums end in fp32 atomics take those atomics in workgroup order (csrc/common.h) -> bit-reproducible results, slower. */
-void vmasr_set_deterministic(int on);
+void vmasr_set_deterministic(int on);   /* on: allocates the per-device ticket words NOW (call outside a stream capture); one stream only */
 int vmasr_get_deterministic(void);
+int64_t vmasr_det_timeouts(void);       /* ordered waits that ran out since the mode was switched on (must be 0); -1 on a HIP error */
 void vmasr_prof_enable(int on);
 void vmasr_prof_reset(void);
 const char *vmasr_prof_name(int kernel_id);

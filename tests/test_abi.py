@@ -92,3 +92,15 @@ def test_invalid_params_rejected_by_c_abi():
     assert b"dividable" in lib.vmasr_last_error()
     assert lib.vmasr_stft(None, None, None, 1, 1000, 1000, 10, 1000, 1, 1, None) == -1
     assert lib.vmasr_cross_scan(None, None, 1, 1, 1, 1, 0, None) == -1
+
+
+def test_conv_mfma_launch_capability_covers_the_launchers_bounds():
+    """ADVICE r04: the dispatch predicate must know what the launchers refuse (slots per launch: dgrad 24 / (stride + 1), wgrad 8;
+    32-bit row offsets), so that an MPD with more periods or a longer segment falls back instead of failing mid-backward."""
+    from vm_asr_amd import _lib
+    q = _lib.lib().vmasr_conv_mfma_supported_launch
+    assert q(128, 512, 5, 3, 5, 400_000) == 1 and q(1024, 1024, 5, 1, 5, 100_000) == 1      # the shipped 5-period MPD
+    assert q(128, 512, 5, 3, 6, 400_000) == 1 and q(128, 512, 5, 3, 7, 400_000) == 0        # 7 x (3 + 1) > 24 dgrad problems
+    assert q(1024, 1024, 5, 1, 8, 100_000) == 1 and q(1024, 1024, 5, 1, 9, 100_000) == 0    # wgrad: 8 slots
+    assert q(128, 512, 5, 3, 5, (1 << 31) // (5 * 512)) == 0 and q(128, 512, 5, 3, 5, (1 << 31) // (5 * 512) - 1) == 1
+    assert q(100, 512, 5, 3, 5, 1000) == 0 and q(128, 512, 5, 3, 0, 1000) == 0

@@ -55,6 +55,7 @@ def test_train_step_gradients_are_bit_reproducible_in_deterministic_mode(workloa
         diff = [k for k in a if not torch.equal(a[k], b[k])]
         assert not diff, (len(diff), diff[:8])
         assert all(torch.isfinite(v).all() for v in a.values())
+        assert lib.vmasr_det_timeouts() == 0                  # no ordered wait ran out
     finally:
         lib.vmasr_set_deterministic(was)
 

@@ -940,6 +940,27 @@ def test_resume_builds_from_the_cli_config_then_adopts_the_stored_one(tmp_path):
     assert c.config is ev
 
 
+def test_resume_refuses_a_checkpoint_whose_step_config_differs(tmp_path, monkeypatch):
+    """the step reads TRAIN.LOSSES / TRAIN.ADVERSARIAL / accumulation from the adopted checkpoint config while the loss
+    modules, discriminators and buffers were built from the CLI config: a mismatch is refused (or, on request, logged and the
+    built values kept) instead of silently training another loss set."""
+    from oracle.torch_backend import oracle_stft_patch
+    cfg = _tiny_config()
+    cfg.defrost(); cfg.OUTPUT = str(tmp_path); cfg.freeze()
+    with oracle_stft_patch():
+        a = _resumable(cfg, tmp_path, "cpu")
+        a._save_checkpoint(1, save_best=True)
+    cli = _tiny_config()
+    cli.defrost(); cli.MODEL.RESUME_PATH = str(tmp_path); cli.OUTPUT = str(tmp_path / "c")
+    cli.TRAIN.ADVERSARIAL.FEATURE_LOSS_LAMBDA = cfg.TRAIN.ADVERSARIAL.FEATURE_LOSS_LAMBDA * 2 + 1; cli.freeze()
+    with pytest.raises(ValueError, match="FEATURE_LOSS_LAMBDA"):
+        _resumable(cli, tmp_path, "cpu")
+    monkeypatch.setenv("VMASR_RESUME_CONFIG_MISMATCH", "warn")
+    b = _resumable(cli, tmp_path, "cpu")
+    assert b.config is not cli and b.config.TRAIN.ADVERSARIAL.FEATURE_LOSS_LAMBDA == cli.TRAIN.ADVERSARIAL.FEATURE_LOSS_LAMBDA
+    assert b.config.is_frozen() and b.start_epoch == 2
+
+
 @pytest.mark.gpu
 def test_graph_warmup_leaves_the_training_state_untouched():
     """Trainer.enable_graphs runs real optimiser steps while warming up and capturing; with preserve_state (default) the

@@ -132,6 +132,7 @@ SYMBOLS = {
     "vmasr_weight_prep_split": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_gelu_bwd_split": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_conv_mfma_supported": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
+    "vmasr_conv_mfma_supported_launch": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_int64]),
     "vmasr_mark_time": (ctypes.c_int, [c_vp, c_vp]),
     "vmasr_im2col2d_rows": (ctypes.c_int, [c_vp, c_vp] + [c_i32] * 10 + [c_vp, c_i32, c_i32, c_vp]),
     "vmasr_col2im2d_rows": (ctypes.c_int, [c_vp, c_vp] + [c_i32] * 10 + [c_vp, c_i32, c_i32, c_vp]),
@@ -164,6 +165,7 @@ SYMBOLS = {
     "vmasr_ss2d_deep_bwd": (ctypes.c_int, [ctypes.POINTER(SS2DDeepParams), c_vp]),
     "vmasr_set_deterministic": (None, [ctypes.c_int]),
     "vmasr_get_deterministic": (ctypes.c_int, []),
+    "vmasr_det_timeouts": (ctypes.c_int64, []),
     "vmasr_prof_enable": (None, [ctypes.c_int]),
     "vmasr_prof_reset": (None, []),
     "vmasr_prof_name": (ctypes.c_char_p, [ctypes.c_int]),

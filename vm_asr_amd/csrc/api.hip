@@ -43,16 +43,37 @@ const char *kNames[VMASR_K_COUNT] = {
 
 bool g_prof_on = false;
 static bool g_det_on = false;
-static unsigned *g_det_buf = nullptr;
+// Deterministic mode: per device, VMASR_K_COUNT ticket words + VMASR_K_COUNT timeout counters (common.h: det_enter).  Allocated for
+// EVERY visible device when the mode is switched on (vmasr_set_deterministic) — never lazily inside a launcher, where a stream
+// capture could be active and a second GPU of the process would be handed the first one's pointer.
+constexpr int kMaxDev = 16;
+static unsigned *g_det_buf[kMaxDev] = {};
 
 unsigned *det_ticket(int kid) {
     if (!g_det_on || kid < 0 || kid >= VMASR_K_COUNT) return nullptr;
-    if (g_det_buf == nullptr) {      // one zeroed word per kernel id, allocated on first use (deterministic mode only)
-        if (hipMalloc(reinterpret_cast<void **>(&g_det_buf), VMASR_K_COUNT * sizeof(unsigned)) != hipSuccess) return nullptr;
-        (void)hipMemset(g_det_buf, 0, VMASR_K_COUNT * sizeof(unsigned));
-        (void)hipDeviceSynchronize();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev || g_det_buf[dev] == nullptr) {
+        set_error("deterministic mode: no ticket buffer for device %d (vmasr_set_deterministic(1) must run before the first launch)", dev);
+        return nullptr;
     }
-    return g_det_buf + kid;
+    return g_det_buf[dev] + kid;
+}
+static int det_prepare() {
+    int n = 0, cur = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;   // no GPU (CPU-side tests): nothing to allocate
+    (void)hipGetDevice(&cur);
+    int rc = 0;
+    for (int d = 0; d < n && d < kMaxDev; ++d) {
+        if (g_det_buf[d]) continue;
+        if (hipSetDevice(d) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&g_det_buf[d]), 2 * VMASR_K_COUNT * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(g_det_buf[d], 0, 2 * VMASR_K_COUNT * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            g_det_buf[d] = nullptr;
+            set_error("deterministic mode: cannot allocate the ticket buffer of device %d (switch the mode on outside a stream capture)", d);
+            rc = VMASR_EINVAL;
+        }
+    }
+    (void)hipSetDevice(cur);
+    return rc;
 }
 void det_set(bool on) { g_det_on = on; }
 bool det_get() { return g_det_on; }
@@ -86,7 +107,26 @@ VMASR_EXPORT const char *vmasr_last_error(void) { return g_err; }
 
 VMASR_EXPORT void vmasr_prof_enable(int on) { g_prof_on = on != 0; }
 
-VMASR_EXPORT void vmasr_set_deterministic(int on) { vmasr::det_set(on != 0); }
+VMASR_EXPORT void vmasr_set_deterministic(int on) {
+    if (on && vmasr::det_prepare() != 0) return;   // (vmasr_last_error says why; the mode stays as it was)
+    vmasr::det_set(on != 0);
+}
+// number of workgroups (all devices, all kernels) whose wait for their turn ran out since the mode was switched on: must be 0 —
+// a non-zero count means an ordering stalled (e.g. the same kernel on two streams) and the sums of that launch are not reproducible
+VMASR_EXPORT int64_t vmasr_det_timeouts(void) {
+    int64_t total = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < vmasr::kMaxDev; ++d) {
+        if (!vmasr::g_det_buf[d]) continue;
+        unsigned host[VMASR_K_COUNT];
+        if (hipSetDevice(d) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(host, vmasr::g_det_buf[d] + VMASR_K_COUNT, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) { total = -1; break; }
+        for (unsigned v : host) total += v;
+    }
+    (void)hipSetDevice(cur);
+    return total;
+}
 VMASR_EXPORT int vmasr_get_deterministic(void) { return vmasr::det_get() ? 1 : 0; }
 
 VMASR_EXPORT void vmasr_prof_reset(void) {

@@ -224,7 +224,9 @@ inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintp
 // waits for ticket == k, performs its atomics (they execute at the memory side; `s_waitcnt vmcnt(0)` = performed), then passes the
 // turn on; the last one resets the ticket.  The float additions to every address then happen in a fixed order -> bit-reproducible
 // results.  Slow by design (the tails serialise, ~1 us per workgroup): a debug aid, off by default (ticket == nullptr: plain atomics).
-// Safe: workgroups are dispatched in linear order, so every workgroup waits only for ones dispatched before it; the wait is bounded.
+// Safe: workgroups are dispatched in linear order, so every workgroup waits only for ones dispatched before it; the wait is bounded
+// (a wait that runs out is counted: vmasr_det_timeouts).  ONE STREAM ONLY: the ticket is per kernel id, so the same kernel must not
+// run on two streams at once in this mode (the trainer keeps its one-stream layout when VMASR_DETERMINISTIC=1).
 unsigned *det_ticket(int kernel_id);          // nullptr unless deterministic mode is on (host side, api.hip)
 void det_set(bool on);
 bool det_get();
@@ -237,6 +239,7 @@ __device__ __forceinline__ void det_enter(unsigned *ticket) {
         const unsigned me = det_me();
         unsigned spins = 0;
         while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != me && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(4);
+        if (spins >= (1u << 26)) atomicAdd(ticket + VMASR_K_COUNT, 1u);   // the wait ran out: counted, read by vmasr_det_timeouts()
     }
     __syncthreads();
 }

@@ -612,6 +612,17 @@ VMASR_EXPORT int vmasr_conv_mfma_supported(int32_t Cin, int32_t Cout, int32_t k,
     return in_ok && out_ok && k >= 1 && k <= 8 && stride >= 1 && stride <= 3;
 }
 
+// Capability query of a whole stacked launch: the shape AND what the three launchers bound — slots per launch (forward 24, the input
+// gradient 24 / (stride + 1) because every slot becomes `stride` residue-class problems plus a zero-fill one, the weight gradient 8)
+// and the rows a launch addresses.  A caller dispatches on THIS, so that an MPD built with more periods, or a batch / segment beyond
+// the row bound, takes its split-GEMM path instead of failing with VMASR_EINVAL in the middle of a backward pass.
+VMASR_EXPORT int vmasr_conv_mfma_supported_launch(int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t n, int64_t rows) {
+    if (!vmasr_conv_mfma_supported(Cin, Cout, k, stride)) return 0;
+    if (n < 1 || n > 8 || n * (stride + 1) > CG_MAXP) return 0;
+    const int64_t widest = std::max<int64_t>(std::max(Cin, Cout), (int64_t)k * std::max(Cin, Cout));
+    return rows >= 1 && rows < (1LL << 31) / widest ? 1 : 0;
+}
+
 VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
                                      int32_t pad, int64_t rows_out, int32_t act, vmasr_stream_t stream) {
     VMASR_REQUIRE(slots && n >= 1 && n <= CG_MAXP, VMASR_EINVAL, "conv_mfma_fwd: 1..%d slots", CG_MAXP);

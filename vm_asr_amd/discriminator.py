@@ -1250,7 +1250,10 @@ class MultiPeriodDiscriminator(nn.Module):
             elif (cdt == torch.float32 and os.environ.get("VMASR_MPD_GEMM", "bf16x3") == "bf16x3" and act and sgeom is not None
                   and os.environ.get("VMASR_MPD_CONV", "mfma") == "mfma"
                   and (cur[0].shape[3] >= 128 or os.environ.get("VMASR_MPD_CONV_L1", "0") == "1")
-                  and _lib.lib().vmasr_conv_mfma_supported(cur[0].shape[3], W.shape[1], k, stride)):
+                  # (shape, slot count and row count of the whole stacked launch: an MPD with more periods or a longer segment than
+                  #  the launchers address falls through to the split-GEMM path below)
+                  and _lib.lib().vmasr_conv_mfma_supported_launch(cur[0].shape[3], W.shape[1], k, stride, n,
+                                                                  max(_round_up(max(Ms), 256), max(g[0] * g[1] for g in sgeom)))):
                 # the three compute-bound layers (128 -> 512 -> 1024 -> 1024): one implicit-GEMM launch each way (csrc/convgemm.hip); the
                 # layer's epilogue leaves the bf16 pair of its activation for the next layer.  The 32 -> 128 layer CAN take the same
                 # kernels (256 x 128 / 256 x 32 / 128 x 32 tile configurations, VMASR_MPD_CONV_L1=1: 28.7 -> 28.0 ms per step) but stays on

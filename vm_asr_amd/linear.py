@@ -245,7 +245,14 @@ class _LinearF64AccFn(torch.autograd.Function):
 
 
 def _use_f64acc(x, weight, bias):
-    return (os.environ.get("VMASR_LINEAR_F64ACC", "1") == "1" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+    """The float64-accumulating fp32 Linear (the parity path's GEMM: 64 x 64 tiles, float64 FMAs — an order of magnitude slower
+    than hipBLASLt).  VMASR_LINEAR_F64ACC: "1" always, "0" never, default "auto" = only where no gradient is recorded (evaluation,
+    the Tester, inference: the fp32 forward + LSD parity claim) — an amp=False TRAINING run keeps the library GEMMs.  The parity
+    tests set "1" (tests/conftest.py) so that their fp32 backward is adjudicated at the same accuracy."""
+    mode = os.environ.get("VMASR_LINEAR_F64ACC", "auto")
+    if mode == "0" or (mode != "1" and torch.is_grad_enabled()):
+        return False
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
             and (bias is None or bias.dtype == torch.float32) and not torch.is_autocast_enabled("cuda") and weight.dim() == 2
             and weight.shape[1] >= 16)
 

@@ -374,11 +374,54 @@ class BaseTrainer:
                             cfg.defrost()
                             cfg.MODEL.RESUME_PATH = path
                             cfg.freeze()
+                            self._check_resumed_config(cfg)
                             self.config = cfg
                     self.logger.info(f"Resumed {name} from {f} (epoch {ck['epoch']})")
                     break
         if getattr(self, "_shadow_dst", None):
             self._refresh_shadows()
+
+    # what a step READS from `self.config` while everything it runs on (loss modules, discriminators, gradient accumulation, flat
+    # buffers, a captured graph) was BUILT from the CLI config: these must agree between the two, or the resumed run would either
+    # raise in the middle of a step or silently train another loss set than the one it was built for
+    _STEP_CONFIG_FIELDS = ("TRAIN.LOSSES", "TRAIN.ADVERSARIAL", "TRAIN.ACCUMULATION_STEPS")
+
+    def _check_resumed_config(self, stored):
+        """The reference swaps the config without looking (base/base_trainer.py:181-192).  Here a checkpoint whose step-level
+        fields differ from the CLI config's is refused with the list of differences (VMASR_RESUME_CONFIG_MISMATCH=warn: logged,
+        and the CLI config's values are kept for those fields, so that the step matches what was built)."""
+        def get(cfg, dotted):
+            for part in dotted.split("."):
+                if cfg is None or part not in cfg:
+                    return None
+                cfg = cfg[part]
+            return cfg
+
+        def flat(node, prefix):
+            if hasattr(node, "items"):
+                out = {}
+                for k, v in node.items():
+                    out.update(flat(v, f"{prefix}.{k}"))
+                return out
+            return {prefix: list(node) if isinstance(node, (list, tuple)) else node}
+        diffs = []
+        for f in self._STEP_CONFIG_FIELDS:
+            a, b = flat(get(self.config, f), f), flat(get(stored, f), f)
+            diffs += [f"{k}: built {a.get(k)!r}, checkpoint {b.get(k)!r}" for k in sorted(set(a) | set(b)) if a.get(k) != b.get(k)]
+        if not diffs:
+            return
+        msg = ("the checkpoint's config differs from the config this trainer was built from in fields the train step reads: "
+               + "; ".join(diffs))
+        if os.environ.get("VMASR_RESUME_CONFIG_MISMATCH", "raise") != "warn":
+            raise ValueError(msg + " (pass the matching --cfg / --opts, or set VMASR_RESUME_CONFIG_MISMATCH=warn to keep the built values)")
+        self.logger.warning(msg + " — keeping the values the trainer was built from")
+        stored.defrost()
+        for f in self._STEP_CONFIG_FIELDS:
+            parent, leaf = f.rsplit(".", 1)
+            src = get(self.config, f)
+            if src is not None:
+                get(stored, parent)[leaf] = src.clone() if hasattr(src, "clone") else src
+        stored.freeze()
 
     def _log_epoch(self, logs):
         if self.rank == 0:
