@@ -171,13 +171,17 @@ def run_point(config, args, device, rank, world, steps, warmup, timing, with_met
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        in_graph = bool(getattr(getattr(trainer, "_graphed", None), "collectives_in_graph", False))
         mine = torch.tensor([dt_own / steps * 1e3, trainer.reduce_exposed_ms() / steps], device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = {"ms_per_step": [round(float(v[0]), 3) for v in allr],
-                    "allreduce_exposed_ms_per_step": [round(float(v[1]), 3) for v in allr],
+                    # in-graph collectives cannot be bracketed by events (no timing inside a capture): null there — compare
+                    # ms_per_step with the N = 1 line instead (weak scaling: same per-GPU work)
+                    "allreduce_exposed_ms_per_step": [None if in_graph else round(float(v[1]), 3) for v in allr],
+                    "collectives": "branches of the step's graph (RCCL captured; MPD gradient as bf16)" if in_graph else "between the graphs",
                     "note": "exposed = time the compute stream waits at the join of the two asynchronous gradient all-reduces "
-                            "(MPD 164 MB launched before the generator backward, generator 9 MB after it)"}
+                            "(MPD 82 MB bf16 / 164 MB fp32 issued behind the D loss' backward, generator 9 MB after its pack)"}
 
     # per-kernel device time: HIP events recorded by the library around each of its launches, on the
     # launch stream.  Events cannot be read inside a replayed graph, so this is a second pass of the
@@ -383,7 +387,9 @@ def compact(out):
     if pr:          # max over ranks only: the per-rank lists are in the detail record
         c["distributed"] = {**c.get("distributed", {}),
                             "ms_per_step_max": max(pr["ms_per_step"]), "ms_per_step_min": min(pr["ms_per_step"]),
-                            "allreduce_exposed_ms_per_step": max(pr["allreduce_exposed_ms_per_step"])}
+                            "allreduce_exposed_ms_per_step": (None if any(v is None for v in pr["allreduce_exposed_ms_per_step"])
+                                                              else max(pr["allreduce_exposed_ms_per_step"])),
+                            "collectives": str(pr.get("collectives", ""))[:40]}
     c["detail"] = out.get("detail_file", "bench_detail.json")
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > MAX_LINE:        # never let an unforeseen field push the line out of the driver's tail again

@@ -11,7 +11,9 @@ Two-stream layout (default on the GPU: trainer._two_streams) — TWO graphs:
               captured graph run concurrently on replay (a graph launch as a whole serialises with every other stream: measured,
               tools/overlap_probe*.py), and nodes are enqueued in capture order — which is why _backward_two() issues the D loss'
               backward before the generator's.
-    (eager)   async RCCL all-reduces of the MPD flat buffer (164 MB) and the generator's (9 MB)   [world_size > 1 only]
+              world_size > 1 (RCCL): the MPD gradient's all-reduce (82 MB as bf16) is a THIRD branch, issued on the side stream right
+              behind the D loss' backward; the generator's (9 MB) follows its pack; both join at the end of the graph.
+              (VMASR_GRAPH_COLLECTIVES=0 or another backend: both all-reduces between graph A and graph B, fully exposed.)
     graph B   AdamW step for G and for D (capturable optimisers) + refresh of the bf16 shadow weights
 
 One-stream layout (VMASR_TWO_STREAM=0, deterministic mode, no shared fake pass) — three graphs:
@@ -113,13 +115,34 @@ class GraphedTrainStep:
             from .trainer import lr_to_device
             if any(torch.is_tensor(g["lr"]) and not g["lr"].is_cuda for g in opt.param_groups):
                 lr_to_device(opt, tr.device)      # a host lr would be frozen into graph B at capture
+        # world_size > 1 on RCCL: the gradient all-reduces are captured INTO graph A (branches of the same graph run concurrently on
+        # replay; a graph launch as a whole serialises with every other stream, so a collective issued between two replays is fully
+        # exposed: tools/overlap_probe*.py).  VMASR_GRAPH_COLLECTIVES=0 (or another backend): collectives between the graphs.
+        import os
+        import torch.distributed as dist
+        self.collectives_in_graph = (tr.world > 1 and tr.dp_mode == "flat" and dist.is_initialized() and dist.get_backend() == "nccl"
+                                     and os.environ.get("VMASR_GRAPH_COLLECTIVES", "1") == "1"
+                                     # (two-stream layout only: a collective forked in one capture cannot be joined in another,
+                                     #  so the one-stream layout's A1 | all-reduce | A2 overlap stays between its graphs)
+                                     and tr._two_streams())
+        if self.collectives_in_graph:
+            # the captured collectives go through RCCL's C API on a communicator of this trainer (vm_asr_amd/rccl.py); one eager
+            # round first: RCCL sets up its channels / buffers on the first collective of a communicator, which must not happen
+            # inside a capture
+            comm = tr.enable_direct_rccl()
+            for key in (["mpd"] if tr.gan else []) + ["generator"]:
+                comm.all_reduce_(torch.zeros_like(tr._flat[key], dtype=tr._comm_dtype(key)), avg=True, stream=tr._comm_stream())
+            torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
         # thread_local: only THIS thread's calls are checked during capture — RCCL's watchdog thread polls its events
         # (hipEventQuery) at any time, which in the default global mode would invalidate a capture in progress
         with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
             st = tr._forward_losses(*self.static_in)
             if st.get("two"):      # two-stream step: ONE graph with a fork / join (the branches run concurrently on replay)
-                tr._backward_both(st)
+                tr._backward_both(st, reduce=self.collectives_in_graph)
+                if self.collectives_in_graph:
+                    tr._reduce_grads("generator", async_op=True)
+                    tr._wait_reduces()                       # the join of the collective branches: last node(s) of graph A
             else:
                 tr._backward_d(st)
         self.graph_g = None
@@ -138,11 +161,12 @@ class GraphedTrainStep:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph_fb.replay()
-        if self.tr.gan:
-            self.tr._reduce_grads("mpd", async_op=True)       # overlaps graph A2 (one-stream layout)
-        if self.graph_g is not None:
-            self.graph_g.replay()
-        self.tr._reduce_grads("generator", async_op=True)
-        self.tr._wait_reduces()
+        if not self.collectives_in_graph:
+            if self.tr.gan:
+                self.tr._reduce_grads("mpd", async_op=True)   # (between the graphs: exposed — a graph launch does not overlap another stream)
+            if self.graph_g is not None:
+                self.graph_g.replay()
+            self.tr._reduce_grads("generator", async_op=True)
+            self.tr._wait_reduces()
         self.graph_opt.replay()
         return self.static_out, self.static_logs

@@ -432,6 +432,16 @@ class BaseTrainer:
             raise SystemExit(1)
 
 
+class _StreamWork:
+    """The join handle of a collective issued on a stream of ours: wait() = the current stream waits for its event."""
+
+    def __init__(self, event, device):
+        self.event, self.device = event, device
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+
+
 class Trainer(BaseTrainer):
     def __init__(self, models, metric_ftns, optimizers, config, device, data_loader_train, data_loader_val=None,
                  lr_schedulers=None, amp=False, gan=False, logger=None, len_epoch=None, dp_mode="flat",
@@ -454,6 +464,7 @@ class Trainer(BaseTrainer):
         self._pending = []              # in-flight gradient all-reduces (async work handles)
         self._graphed = None
         self.time_reduces, self._reduce_events = False, []
+        self._flat_lp = {}
         self.device = device[0] if isinstance(device, (tuple, list)) else device
         self.data_loader, self.data_loader_val = data_loader_train, data_loader_val
         self.len_epoch = len_epoch if len_epoch is not None else (len(data_loader_train) if data_loader_train is not None else 0)
@@ -612,10 +623,21 @@ class Trainer(BaseTrainer):
             p.grad = v
         torch._foreach_copy_(dst, src)
 
+    def _comm_dtype(self, key):
+        """Wire dtype of `key`'s gradient all-reduce.  VMASR_GRAD_COMM: "fp32" | "bf16" | "auto" (default): the period
+        discriminator's 164 MB buffer travels as bf16 (82 MB; the fp32 flat buffer stays the optimiser's input, AdamW's moments and
+        the weights stay fp32 — DDP's bf16 compression hook), the generator's 9 MB as fp32.  RCCL only: gloo is the
+        CPU test backend."""
+        mode = os.environ.get("VMASR_GRAD_COMM", "auto")
+        if mode == "fp32" or self.device.type != "cuda" or dist.get_backend() != "nccl":
+            return torch.float32
+        return torch.bfloat16 if (mode == "bf16" or key != "generator") else torch.float32
+
     def _reduce_grads(self, key, async_op=False):
-        """ONE all-reduce (mean) per model per step over RCCL/xGMI (generator 9 MB, MPD 164 MB fp32).
-        async_op: the call returns at once and the collective runs on RCCL's own stream — the caller overlaps it
-        with further work and joins it with _wait_reduces() before the optimiser reads the gradients."""
+        """ONE all-reduce (mean) per model per step over RCCL/xGMI (generator 9 MB fp32, MPD 82 MB bf16 / 164 MB fp32).
+        async_op: the call returns at once and the collective runs on RCCL's own stream, ordered after the CURRENT stream's work so
+        far — the caller overlaps it with further work and joins it with _wait_reduces() before the optimiser reads the gradients.
+        Capturable (RCCL): inside a stream capture the collective becomes a branch of the graph."""
         if self.world > 1 and self.dp_mode == "flat":
             if key not in self._flat:
                 self._setup_flat(key, None)
@@ -623,23 +645,57 @@ class Trainer(BaseTrainer):
             if os.environ.get("VMASR_OVERLAP_REDUCE", "1") != "1":
                 async_op = False                    # escape hatch: collectives strictly between the graphs, no overlap
             avg = dist.get_backend() == "nccl"      # RCCL averages in the collective; gloo has no AVG
-            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
-            self._pending.append((work if async_op else None, None if avg else flat))
+            buf = flat
+            if self._comm_dtype(key) != flat.dtype:
+                lp = self._flat_lp.get(key)
+                if lp is None:                      # (allocated before any capture: GraphedTrainStep's warm-up steps reduce too)
+                    lp = self._flat_lp[key] = torch.empty_like(flat, dtype=self._comm_dtype(key))
+                lp.copy_(flat)
+                buf = lp
+            if getattr(self, "_direct_rccl", None) is not None and (torch.cuda.is_current_stream_capturing()
+                                                                     or os.environ.get("VMASR_RCCL_DIRECT", "0") == "1"):
+                # RCCL's C API on a stream of its own, forked from the current one (vm_asr_amd/rccl.py: the process group's watchdog
+                # cannot live with captured collectives): a branch of the graph being captured
+                cs, cur = self._comm_stream(), torch.cuda.current_stream(self.device)
+                cs.wait_stream(cur)
+                self._direct_rccl.all_reduce_(buf, avg=True, stream=cs)
+                done = torch.cuda.Event()
+                done.record(cs)
+                self._pending.append((_StreamWork(done, self.device), flat, buf, False))
+                return
+            work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
+            self._pending.append((work if async_op else None, flat, buf, not avg))
             if not async_op:
                 self._wait_reduces()
 
+    def _comm_stream(self):
+        if getattr(self, "_comm_st", None) is None:
+            self._comm_st = torch.cuda.Stream(self.device)
+        return self._comm_st
+
+    def enable_direct_rccl(self):
+        """Create this trainer's own RCCL communicator (collective over the process group: every rank calls it, outside any capture)."""
+        if getattr(self, "_direct_rccl", None) is None:
+            from .rccl import RcclComm
+            self._direct_rccl = RcclComm(self.device)
+            self._comm_stream()
+        return self._direct_rccl
+
     def _wait_reduces(self):
-        """Join the pending collectives.  With `time_reduces` (bench.py, N > 1) an event pair brackets the join on the
-        compute stream: the time between them is what the collectives cost the step AFTER the overlap with the
-        generator backward — the EXPOSED all-reduce time (`reduce_exposed_ms()`)."""
-        timed = getattr(self, "time_reduces", False) and self.device.type == "cuda" and bool(self._pending)
+        """Join the pending collectives.  With `time_reduces` (bench.py, N > 1, collectives between the graphs) an event pair
+        brackets the join on the compute stream: the time between them is what the collectives cost the step AFTER the overlap
+        — the EXPOSED all-reduce time (`reduce_exposed_ms()`).  Inside a capture nothing is timed."""
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        timed = getattr(self, "time_reduces", False) and self.device.type == "cuda" and bool(self._pending) and not capturing
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for work, flat in self._pending:
+        for work, flat, buf, divide in self._pending:
             if work is not None:
                 work.wait()                # the current stream waits for the collective (no host block on RCCL)
-            if flat is not None:
+            if buf is not flat:
+                flat.copy_(buf)            # bf16 wire buffer -> the optimiser's fp32 gradients
+            if divide:
                 flat.div_(self.world)
         if timed:
             e1.record()
@@ -808,7 +864,7 @@ class Trainer(BaseTrainer):
             layernorm.reset_uses()
         self._gather_grads("generator")
 
-    def _backward_two(self, st, zero=True):
+    def _backward_two(self, st, zero=True, reduce=False):
         """The backward passes of the two-stream step, issued in the order that lets them overlap (capture order is replay
         enqueue order):  side: G losses -> through the discriminator -> d/d(wave)  [input gradients only]
                          side: D loss -> discriminator weight gradients, packed            } beside each other
@@ -832,6 +888,10 @@ class Trainer(BaseTrainer):
                     st["total_d"].backward(inputs=self._grad_targets("mpd"))
                 self._gather_grads("mpd")
                 self._mark("d_bwd_end", side)
+                if reduce and self.gan:
+                    # the MPD all-reduce starts HERE, ordered after the side stream: it runs on RCCL's stream beside whatever is
+                    # left of the generator's backward on the main stream (and, captured, as a third branch of the step's graph)
+                    self._reduce_grads("mpd", async_op=True)
             main.wait_event(handed)
             if zero:
                 self._zero_grads("generator", self.optimizer_G)
@@ -853,18 +913,17 @@ class Trainer(BaseTrainer):
         main.wait_stream(side)
         self._mark("join", main)
 
-    def _backward_both(self, st, zero=True, after_d=None):
-        """Both backward passes in the order the step's stream layout wants.
-        One stream : D loss, [after_d(): the MPD all-reduce starts], G loss.
-        Two streams: _backward_two(), then after_d()."""
+    def _backward_both(self, st, zero=True, reduce=False):
+        """Both backward passes in the order the step's stream layout wants; `reduce`: start each model's gradient all-reduce as
+        soon as its flat buffer is packed.
+        One stream : D loss, [the MPD all-reduce starts: it overlaps the whole generator backward], G loss.
+        Two streams: _backward_two() — the MPD all-reduce is issued on the SIDE stream right behind the D loss' backward."""
         if st.get("two"):
-            self._backward_two(st, zero)
-            if after_d is not None:
-                after_d()
+            self._backward_two(st, zero, reduce)
             return
         self._backward_d(st, zero)
-        if after_d is not None:
-            after_d()
+        if reduce and self.gan:
+            self._reduce_grads("mpd", async_op=True)
         self._backward_g(st, zero)
 
     def _forward_backward(self, wave_input, wave_target, highcut, zero=True):
@@ -1014,7 +1073,7 @@ class Trainer(BaseTrainer):
         first, last = self._micro % self._acc == 0, (self._micro + 1) % self._acc == 0
         self._micro += 1
         st = self._forward_losses(wave_input, wave_target, highcut)
-        self._backward_both(st, zero=first, after_d=(lambda: self._reduce_grads("mpd", async_op=True)) if last and self.gan else None)
+        self._backward_both(st, zero=first, reduce=last)
         if last:
             self._reduce_grads("generator", async_op=True)
             self._wait_reduces()
