@@ -118,6 +118,16 @@ int vmasr_cross_merge_cvt(const void *ys, void *y, int32_t B, int32_t C, int32_t
  *   xs (B,K,D,L) `dtype`; Wx (K, R+2N, D), Wdt (K, D, R) fp32  ->
  *   dts (B,K*D,L), Bs (B,K,N,L), Cs (B,K,N,L) fp32 contiguous (scan-ready), dtr (B,K,R,L) fp32 (the
  *   low-rank dt rows, kept by the caller for the backward).  R <= 8, R + 2N <= 16. */
+/* The same projections for a general state dimension (d_state > 1: csrc/xproj_n.hip, fp32 MFMA products).  Same tensors and
+ * meaning as vmasr_xproj_fwd / vmasr_xproj_bwd, except that `ws` of the backward holds only the gradient of the low-rank dt rows,
+ * (B, K, R, L) fp32 = vmasr_xproj_n_ws_floats() floats.  d_inner even, dt_rank <= 16. */
+int vmasr_xproj_n_supported(int32_t d_state, int32_t dt_rank, int32_t d_inner);
+size_t vmasr_xproj_n_ws_floats(int32_t B, int32_t K, int32_t R, int32_t L);
+int vmasr_xproj_n_fwd(const void *xs, const float *Wx, const float *Wdt, float *dts, float *Bs, float *Cs, float *dtr,
+                      int32_t B, int32_t K, int32_t D, int32_t N, int32_t R, int32_t L, int32_t dtype, vmasr_stream_t stream);
+int vmasr_xproj_n_bwd(const void *xs, const float *Wx, const float *Wdt, const float *dtr, const float *ddts, const float *dBs,
+                      const float *dCs, const float *du, void *dxs, float *dWx, float *dWdt, float *ws,
+                      int32_t B, int32_t K, int32_t D, int32_t N, int32_t R, int32_t L, int32_t dtype, vmasr_stream_t stream);
 int vmasr_xproj_supported(int32_t d_state, int32_t dt_rank, int32_t d_inner);
 int vmasr_xproj_fwd(const void *xs, const float *Wx, const float *Wdt, float *dts, float *Bs, float *Cs,
                     float *dtr, int32_t B, int32_t K, int32_t D, int32_t N, int32_t R, int32_t L,

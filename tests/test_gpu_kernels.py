@@ -426,7 +426,11 @@ def test_small_linear_vs_torch(io):
                                  # row-parallel kernels of the deep stages (d_inner >= 64, L % 4 == 0): full / ragged tiles, odd D
                                  (2, 64, 1, 2, 4096), (3, 128, 1, 4, 1000), (1, 100, 2, 3, 200), (2, 64, 1, 2, 16384),
                                  # matrix-core kernels (d_state 1, D % 32 == 0, L % 32 == 0, even dt_rank): the deep-stage call shapes
-                                 (4, 128, 1, 4, 1024), (8, 256, 1, 8, 256), (1, 512, 1, 8, 96)], ids=str)
+                                 (4, 128, 1, 4, 1024), (8, 256, 1, 8, 256), (1, 512, 1, 8, 96),
+                                 # general d_state (csrc/xproj_n.hip, fp32 MFMA products): configs[4]'s call shapes (d_state 32: C = 66 .. 80
+                                 # rows), ragged position tiles, d_inner not a multiple of 32, odd dt_rank, C above 96
+                                 (1, 64, 32, 2, 2048), (2, 2, 32, 1, 4096), (1, 32, 32, 1, 1000), (1, 256, 32, 8, 512), (1, 512, 32, 16, 96),
+                                 (2, 6, 5, 1, 77), (1, 34, 8, 3, 300), (1, 16, 48, 1, 260)], ids=str)
 def test_xproj_vs_einsum(cfg):
     from vm_asr_amd.xproj import x_proj_dt
     Bn, D, N, R, L = cfg

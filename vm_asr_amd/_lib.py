@@ -99,6 +99,10 @@ SYMBOLS = {
     "vmasr_xproj_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "vmasr_xproj_fwd": (ctypes.c_int, [c_vp] * 7 + [c_i32] * 7 + [c_vp]),
     "vmasr_xproj_bwd": (ctypes.c_int, [c_vp] * 12 + [c_i32] * 7 + [c_vp]),
+    "vmasr_xproj_n_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
+    "vmasr_xproj_n_ws_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "vmasr_xproj_n_fwd": (ctypes.c_int, [c_vp] * 7 + [c_i32] * 7 + [c_vp]),
+    "vmasr_xproj_n_bwd": (ctypes.c_int, [c_vp] * 12 + [c_i32] * 7 + [c_vp]),
     "vmasr_spectral_power_iter": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, ctypes.c_float, c_vp]),
     "vmasr_spectral_power_iter_batched": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i32, ctypes.c_float, c_vp, c_vp]),
     "vmasr_im2col_kx1": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),

@@ -726,14 +726,29 @@ class Trainer(BaseTrainer):
             return False
         return self._share_fake_pass()
 
+    def side_cu_limits(self):
+        """(forward, backward) CU limits of the discriminator's convolution kernels while the two streams overlap, DERIVED from the
+        device and the model instead of fixed numbers: the convolutions are compute-bound (time ~ 1 / CUs), the generator's small
+        kernels are not, so the best split gives the side stream the share of the chip that balances the two phases' ends —
+        3/8 of the CUs beside the generator's forward (D(real) has slack there: everything waits for the generator's output),
+        5/8 beside its backward, 1/2 when the generator is the wide one (DIMS >= 32: its backward is 2x the work).  Measured flat in
+        the batch (2, 4, 8) and within 1 % of the best point of every sweep: profiles/r05_side_cus_sweep_*.log (fwd 96 / bwd 160 of
+        256 CUs: 172.1 clips/s at batch 4, 198.5 at batch 8; DIMS 32: fwd 96 / bwd 128: 153.7).  Rounded to 8 CUs (one per XCD)."""
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        dims = self.config.MODEL.VSSM.DIMS
+        dims = dims[0] if isinstance(dims, (list, tuple)) else dims
+        r8 = lambda v: max(8, int(round(v / 8.0)) * 8)      # noqa: E731
+        return r8(cus * 3 / 8), r8(cus * (1 / 2 if dims >= 32 else 5 / 8))
+
     def _side_cus(self, forward=False):
         """-> context: CUs the discriminator's convolution kernels may take while the generator's kernels run beside them
-        (backward: VMASR_SIDE_CUS, default 160 of 256, soft by 24: csrc/convgemm.hip cg_grid — caps of 168 ... 184 workgroups measured alike,
-        160 and 200+ slower; forward: VMASR_SIDE_CUS_FWD, default 128; 0 = no limit; VMASR_SIDE_CUS_MINC: backward, only layers at least that wide)."""
+        (side_cu_limits(); soft by 24: csrc/convgemm.hip cg_grid).  Overrides: VMASR_SIDE_CUS (backward, and forward unless
+        VMASR_SIDE_CUS_FWD is given too), 0 = no limit; VMASR_SIDE_CUS_MINC: backward, only layers at least that wide."""
         from . import convgemm
-        cus = os.environ.get("VMASR_SIDE_CUS", "160")
-        if forward:      # D(real) has slack beside the generator's forward, which everything else waits for: a tighter limit (96 ... 128 alike, 144+ slower)
-            cus = os.environ.get("VMASR_SIDE_CUS_FWD", "128" if "VMASR_SIDE_CUS" not in os.environ else cus)
+        fwd_auto, bwd_auto = self.side_cu_limits()
+        cus = os.environ.get("VMASR_SIDE_CUS", str(bwd_auto))
+        if forward:
+            cus = os.environ.get("VMASR_SIDE_CUS_FWD", str(fwd_auto) if "VMASR_SIDE_CUS" not in os.environ else cus)
         return convgemm.cu_limit(int(cus), 0 if forward else int(os.environ.get("VMASR_SIDE_CUS_MINC", "0")))
 
     def _mark(self, name, stream=None):

@@ -20,7 +20,17 @@ def _p(t):
 
 
 def supported(d_state, dt_rank, d_inner):
-    return bool(_lib.lib().vmasr_xproj_supported(int(d_state), int(dt_rank), int(d_inner)))
+    """The memory-bound maps of csrc/xproj.hip (d_state 1 .. 4) or, for a general state dimension, the fp32-MFMA kernels of
+    csrc/xproj_n.hip."""
+    l = _lib.lib()
+    return bool(l.vmasr_xproj_supported(int(d_state), int(dt_rank), int(d_inner))
+                or l.vmasr_xproj_n_supported(int(d_state), int(dt_rank), int(d_inner)))
+
+
+def _general(N, R, D):
+    """-> the general-N entry points apply (and the small-C maps do not)."""
+    l = _lib.lib()
+    return not l.vmasr_xproj_supported(int(N), int(R), int(D)) and bool(l.vmasr_xproj_n_supported(int(N), int(R), int(D)))
 
 
 class _XProjFn(torch.autograd.Function):
@@ -36,9 +46,9 @@ class _XProjFn(torch.autograd.Function):
             Bs = torch.empty((B, K, N, L), **f32)
             Cs = torch.empty((B, K, N, L), **f32)
             dtr = torch.empty((B, K, R, L), **f32)
-            _lib.check(_lib.lib().vmasr_xproj_fwd(_p(xs), _p(wx32), _p(wdt32), _p(dts), _p(Bs), _p(Cs), _p(dtr), B, K, D, N, R,
-                                                  L, _lib.torch_dtype_code(xs.dtype), _lib.current_stream(xs.device)),
-                       "xproj_fwd")
+            fn = _lib.lib().vmasr_xproj_n_fwd if _general(N, R, D) else _lib.lib().vmasr_xproj_fwd
+            _lib.check(fn(_p(xs), _p(wx32), _p(wdt32), _p(dts), _p(Bs), _p(Cs), _p(dtr), B, K, D, N, R,
+                          L, _lib.torch_dtype_code(xs.dtype), _lib.current_stream(xs.device)), "xproj_fwd")
         ctx.save_for_backward(xs, wx32, wdt32, dtr)
         ctx.meta = (N, Wx.dtype, Wdt.dtype)
         return dts, Bs, Cs
@@ -56,11 +66,12 @@ class _XProjFn(torch.autograd.Function):
         with torch.cuda.device(xs.device):
             dxs = torch.empty_like(xs)
             dWx, dWdt = _lib.zeros_f32(xs.device, (K, C, D), (K, D, R))
-            ws = torch.empty((B, K, C, L), **f32)
-            _lib.check(_lib.lib().vmasr_xproj_bwd(_p(xs), _p(wx32), _p(wdt32), _p(dtr), _p(ddts), _p(dBs), _p(dCs), None,
-                                                  _p(dxs), _p(dWx), _p(dWdt), _p(ws), B, K, D, N, R, L,
-                                                  _lib.torch_dtype_code(xs.dtype), _lib.current_stream(xs.device)),
-                       "xproj_bwd")
+            gen = _general(N, R, D)
+            ws = torch.empty((B, K, R if gen else C, L), **f32)     # general N: only the low-rank dt rows' gradient is kept
+            fn = _lib.lib().vmasr_xproj_n_bwd if gen else _lib.lib().vmasr_xproj_bwd
+            _lib.check(fn(_p(xs), _p(wx32), _p(wdt32), _p(dtr), _p(ddts), _p(dBs), _p(dCs), None,
+                          _p(dxs), _p(dWx), _p(dWdt), _p(ws), B, K, D, N, R, L,
+                          _lib.torch_dtype_code(xs.dtype), _lib.current_stream(xs.device)), "xproj_bwd")
         return dxs, dWx.to(wxdt), dWdt.to(wdtdt), None
 
 
