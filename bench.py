@@ -276,6 +276,20 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9     # lane-instructions per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (157 TFLOP/s of packed fp32 FMA)
+VALU_SLOTS_FWD, VALU_SLOTS_BWD = 14.0, 35.0  # packed instructions per state-step of csrc/sscan_n.hip's forward / backward (ISA count)
+
+
+def scan_state_steps_per_clip(cfg):
+    """Sum over the 34 selective-scan calls of a clip of KD x L x d_state (per-stream block schedule, x2 streams):
+    the unit of the general-N scan's VALU roofline."""
+    d = cfg.MODEL.VSSM.DIMS
+    d = d[0] if isinstance(d, (list, tuple)) else d
+    F, T = cfg.DATA.STFT.N_FFT // 2, 512          # bins without DC x frames of one clip
+    stages = [(d, 4, 3), (2 * d, 8, 4), (4 * d, 16, 4), (8 * d, 32, 4), (d // 2, 2, 1), (1, 1, 1)]   # (d_model, downscale, blocks per stream); the last output block has d_model 1
+    return sum(2 * blocks * (4 * 2 * dm) * (F // ds) * (T // ds) for dm, ds, blocks in stages) * cfg.MODEL.VSSM.SSM_D_STATE
+
+
 def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, steps=10, with_metrics=False):
     """A second operating point measured in the same process after the headline (N = 1 only): compact record with its own
     roofline block.  `mpd_gemm`: VMASR_MPD_GEMM for this point (read when the discriminator's layers are built into the graph).
@@ -320,6 +334,13 @@ def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, step
             rec["roofline"]["shared_chip"] = {"kernel": dom, "achieved": d2["gbs"], "frac": d2["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d2["avg_us"],
                                               "selective_scan_op": op2}
         rec["scan_alg_bytes_per_clip"] = op["alg_bytes_per_step"] / B if op else None
+        if cfg.MODEL.VSSM.SSM_D_STATE > 1 and op:
+            # general d_state: the scan is VALU-issue bound by a factor of N, so its roofline is the vector ALU's, not HBM's
+            ss = scan_state_steps_per_clip(cfg) * B
+            floor_ms = ss * (VALU_SLOTS_FWD + VALU_SLOTS_BWD) / VALU_LANE_RATE * 1e3
+            rec["roofline"]["valu"] = {"state_steps_per_step": ss, "slots_per_state_step": {"fwd": VALU_SLOTS_FWD, "bwd": VALU_SLOTS_BWD},
+                                       "floor_ms_per_step": floor_ms, "scan_op_ms_per_step": op["ms_per_step"], "frac": floor_ms / op["ms_per_step"],
+                                       "achieved_slots_per_state_step": op["ms_per_step"] * 1e-3 * VALU_LANE_RATE / ss}
     top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:14]
     rec["top_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "ms_per_step": round(v["ms"] / steps, 3)} for k, v in top}
     rec["unfused_chain_kernels"] = sorted(k for k in kern if k in ("cross_scan", "cross_merge", "xproj_fwd", "xproj_bwd_a", "xproj_bwd_b")

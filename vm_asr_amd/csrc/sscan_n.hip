@@ -32,7 +32,7 @@
 // exp (rms 0.45), unbiased (tests/test_gpu_kernels.py: goldens n8 / n32, oracle, L = 524 288 stress).
 #include "sscan_n.h"
 
-#include "scan_prims.h"
+#include "sscan_n_prims.h"
 
 #include <stdlib.h>
 
@@ -41,145 +41,13 @@
 namespace vmasr {
 namespace {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f splat(const float x) { return (v2f){x, x}; }
-__device__ __forceinline__ v2f fma2(const v2f a, const v2f b, const v2f c) { return __builtin_elementwise_fma(a, b, c); }
-
-constexpr float kMagic = 12582912.f;   // 1.5 * 2^23: adding it rounds to an integer and leaves that integer in the low mantissa bits
-constexpr float kZmax = 125.f;         // |delta A log2 e| up to here: the exponent add cannot leave the normal range
-
-// a_i = exp(dl_i A) for a pair of states and the kItems steps of a lane, A2 = A log2 e.  The four evaluations run in
-// LOCK-STEP (coefficient by coefficient): a v_pk_fma_f32 that reads the result of the previous instruction costs a wait
-// state, four independent Horner chains side by side cost none.
-// ROBUST false: the caller has checked |dl A2| <= kZmax for the whole workgroup (a scalar branch), so the exponent is added to
-// the bits directly.  z = dl A2 is never rounded: f = fma(dl, A2, -n).
-template <bool ROBUST>
-__device__ __forceinline__ void decay2x4(const float (&dl)[kItems], const v2f A2, v2f (&a)[kItems]) {
-    v2f t[kItems], f[kItems], p[kItems];
-    if constexpr (!ROBUST) {
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) t[i] = fma2(splat(dl[i]), A2, splat(kMagic));
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) f[i] = fma2(splat(dl[i]), A2, splat(kMagic) - t[i]);
-    } else {   // any finite argument: clamp, ldexp (underflows to 0, overflows to inf as exp does)
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-            v2f z = splat(dl[i]) * A2;
-            z.x = __builtin_amdgcn_fmed3f(z.x, -160.f, 160.f);
-            z.y = __builtin_amdgcn_fmed3f(z.y, -160.f, 160.f);
-            t[i] = z + splat(kMagic);
-            f[i] = z - (t[i] - splat(kMagic));
-        }
-    }
-    // 2^f on |f| <= 1/2, near-minimax fit of (2^f - 1) / f (relative error 2e-9 before rounding)
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) p[i] = fma2(splat(1.5353427443187684e-4f), f[i], splat(1.339887734502554e-3f));
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(9.61843691766262e-3f));
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(5.5503323674201965e-2f));
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(2.4022647738456726e-1f));
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(6.931471824645996e-1f));
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) p[i] = fma2(p[i], f[i], splat(1.f));
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        if constexpr (!ROBUST) {
-            a[i].x = __int_as_float(__float_as_int(p[i].x) + (__float_as_int(t[i].x) << 23));
-            a[i].y = __int_as_float(__float_as_int(p[i].y) + (__float_as_int(t[i].y) << 23));
-        } else {
-            a[i].x = ldexpf(p[i].x, __float_as_int(t[i].x) - __float_as_int(kMagic));
-            a[i].y = ldexpf(p[i].y, __float_as_int(t[i].y) - __float_as_int(kMagic));
-        }
-    }
-}
-
-// ---- scans of the lane aggregates of TWO independent recurrences (the two states of a pair) ---------------------------
-// One Hillis-Steele stage for both: b <- a b_src + b, a <- a a_src (lanes without a source lane keep their value: the
-// identity the scan needs).  Order b0 b1 a0 a1: every DPP read is at least two instructions behind the write of its source.
-#define VMASR_SCAN2_STAGE(CTRL)                                     \
-    "v_fmac_f32_dpp %0, %0, %1 " CTRL "\n\t"                        \
-    "v_fmac_f32_dpp %2, %2, %3 " CTRL "\n\t"                        \
-    "v_mul_f32_dpp %1, %1, %1 " CTRL "\n\t"                         \
-    "v_mul_f32_dpp %3, %3, %3 " CTRL "\n\t"
-
-struct Pair2 {
-    v2f a, b;   // h -> a h + b, two states
-};
-
-__device__ __forceinline__ Pair2 then2(const Pair2 first, const Pair2 second) {
-    return {second.a * first.a, fma2(second.a, first.b, second.b)};
-}
-
-// forward: excl = composition of lanes [0, lane), tot = all lanes (wave-uniform)
-template <bool TOT = true>
-__device__ __forceinline__ void wave_scan_fwd2(const Pair2 v, Pair2 &excl, Pair2 &tot) {
-    float a0 = v.a.x, b0 = v.b.x, a1 = v.a.y, b1 = v.b.y;
-    asm volatile("s_nop 1\n\t"
-                 VMASR_SCAN2_STAGE("row_shr:1 row_mask:0xf bank_mask:0xf")
-                 VMASR_SCAN2_STAGE("row_shr:2 row_mask:0xf bank_mask:0xf")
-                 VMASR_SCAN2_STAGE("row_shr:4 row_mask:0xf bank_mask:0xf")
-                 VMASR_SCAN2_STAGE("row_shr:8 row_mask:0xf bank_mask:0xf")
-                 VMASR_SCAN2_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 VMASR_SCAN2_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                 : "+v"(b0), "+v"(a0), "+v"(b1), "+v"(a1));
-    if constexpr (TOT) {
-        tot.a = (v2f){readlane_f(a0, 63), readlane_f(a1, 63)};
-        tot.b = (v2f){readlane_f(b0, 63), readlane_f(b1, 63)};
-    }
-    float ea0 = 1.f, eb0 = 0.f, ea1 = 1.f, eb1 = 0.f;   // exclusive = inclusive one lane down; lane 0 keeps the identity
-    asm volatile("s_nop 1\n\t"
-                 "v_mov_b32_dpp %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %1, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %2, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %3, %7 wave_shr:1 row_mask:0xf bank_mask:0xf"
-                 : "+v"(eb0), "+v"(eb1), "+v"(ea0), "+v"(ea1) : "v"(b0), "v"(b1), "v"(a0), "v"(a1));
-    excl.a = (v2f){ea0, ea1};
-    excl.b = (v2f){eb0, eb1};
-}
-
-// reverse (g_l = b_l + a_l g_{l+1}): excl = composition of lanes (lane, 63] applied from the right, tot = all lanes.
-// Inside the 16-lane rows by DPP.  Across the rows row_bcast only goes upwards, so the rows are closed from the right in three
-// steps: row 2 composes with the total of row 3 (v_readlane of lane 48), row 1 with the suffix at lane 32, row 0 with the one at
-// lane 16 — each step two FMAs and two multiplies under the row's exec mask, with the totals as scalar operands.
-__device__ __forceinline__ void wave_scan_rev2(const Pair2 v, const int lane, Pair2 &excl, Pair2 &tot) {
-    float a0 = v.a.x, b0 = v.b.x, a1 = v.a.y, b1 = v.b.y;
-    asm volatile("s_nop 1\n\t"
-                 VMASR_SCAN2_STAGE("row_shl:1 row_mask:0xf bank_mask:0xf")
-                 VMASR_SCAN2_STAGE("row_shl:2 row_mask:0xf bank_mask:0xf")
-                 VMASR_SCAN2_STAGE("row_shl:4 row_mask:0xf bank_mask:0xf")
-                 VMASR_SCAN2_STAGE("row_shl:8 row_mask:0xf bank_mask:0xf")
-                 : "+v"(b0), "+v"(a0), "+v"(b1), "+v"(a1));
-    const int row = lane >> 4;
-#pragma unroll
-    for (int src = 48; src >= 16; src -= 16) {   // the suffix right of row (src / 16 - 1) sits at lane src
-        const float ta0 = readlane_f(a0, src), tb0 = readlane_f(b0, src), ta1 = readlane_f(a1, src), tb1 = readlane_f(b1, src);
-        if (row == src / 16 - 1) {
-            b0 = fmaf(a0, tb0, b0); a0 *= ta0;
-            b1 = fmaf(a1, tb1, b1); a1 *= ta1;
-        }
-    }
-    tot.a = (v2f){readlane_f(a0, 0), readlane_f(a1, 0)};
-    tot.b = (v2f){readlane_f(b0, 0), readlane_f(b1, 0)};
-    float ea0 = 1.f, eb0 = 0.f, ea1 = 1.f, eb1 = 0.f;   // exclusive = inclusive one lane up; lane 63 keeps the identity
-    asm volatile("s_nop 1\n\t"
-                 "v_mov_b32_dpp %0, %4 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %1, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %2, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %3, %7 wave_shl:1 row_mask:0xf bank_mask:0xf"
-                 : "+v"(eb0), "+v"(eb1), "+v"(ea0), "+v"(ea1) : "v"(b0), "v"(b1), "v"(a0), "v"(a1));
-    excl.a = (v2f){ea0, ea1};
-    excl.b = (v2f){eb0, eb1};
-}
-
 // ---- geometry ------------------------------------------------------------------------------------------------------------
 struct PGeom {
     int tiles_per_task, nseg;   // segments along L (split plan), tiles per segment
     int np;                     // state pairs = ceil(N / 2)
     int W;                      // waves per workgroup = ceil(np / PP): wave w owns pairs w PP .. w PP + PP - 1
     int RB, RS, nrb;            // rows per workgroup, rows per batch (prologue / reduction granule), row blocks per group
+    int dA_lanes;               // backward: dA partial sums per LANE in LDS ([W][RB][64] pairs), summed once at the end
     unsigned *det;              // deterministic mode: the workgroups run one after the other (common.h), else null
 };
 
@@ -218,12 +86,14 @@ __device__ __forceinline__ void store_pair(float *xi, const bool xvec, const boo
 // delta u) | ypart [RS][W][256].
 // =====================================================================================================================
 // Q: positions per thread in the prologue / epilogue of a batch = ceil(RS 256 / threads): 1 for W >= 4 waves, 2 for W = 2..3, 4 for W = 1
-template <typename T, bool VEC, int PP, int Q, int MODE>
+template <typename T, bool VEC, int PP, int Q, int RSV, int MODE>
 __global__ __launch_bounds__(1024) void sscan_pfwd_kernel(const vmasr_sscan_params p, const PGeom geo) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), nthr = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = p.seqlen, N = p.dstate, NP2 = 2 * geo.np, RB = geo.RB, RS = geo.RS, W = geo.W;
+    const int L = p.seqlen, N = p.dstate, NP2 = 2 * geo.np, RB = geo.RB, W = geo.W;
+    constexpr int RS = RSV;    // rows per batch: compile-time, so that the rows of a batch are unrolled side by side (two independent
+                               // dependency chains per wave: the scan and the recurrences are serial inside a row)
     const int ntiles = (L + kTile - 1) / kTile;
     const int D = p.dim / p.n_groups;
     // block -> (row block fastest: the workgroups that read the same B / C tiles are neighbours, group, segment, batch)
@@ -332,6 +202,7 @@ __global__ __launch_bounds__(1024) void sscan_pfwd_kernel(const vmasr_sscan_para
             if (tid == 0) sflag[(batch + 1) & 1] = 0;   // the other slot: next set after the second barrier of this batch
             ++batch;
             // ---- my pairs of every row of the batch
+#pragma unroll
             for (int rr = 0; rr < RS; ++rr) {
                 const int r = kb + rr;
                 const float4 dl4 = *reinterpret_cast<const float4 *>(stage + (rr * 2 + 0) * kTile + lane * kItems);
@@ -434,6 +305,7 @@ __global__ __launch_bounds__(1024) void sscan_pbwd_kernel(const vmasr_sscan_bwd_
     float *stage = s_dyn + align4(4 * RB * NP2 + 11 * RB), *part = stage + RS * 4 * kTile;
     int *sflag = reinterpret_cast<int *>(part + (size_t)RS * W * 2 * kTile);   // [2] (+ 2 pad)
     float *xpose = part + (size_t)RS * W * 2 * kTile + 4;                        // [W][256]: transpose buffer of the dB / dC atomics
+    float *sdAl = xpose + (geo.nrb > 1 ? (size_t)W * kTile : 0);                 // [W][RB][64][2]: per-lane dA partial sums (geo.dA_lanes)
 
     const T *__restrict__ Bg = static_cast<const T *>(p.B_ptr) + b * p.B_batch_stride + g * p.B_group_stride;
     const T *__restrict__ Cg = static_cast<const T *>(p.C_ptr) + b * p.C_batch_stride + g * p.C_group_stride;
@@ -465,6 +337,8 @@ __global__ __launch_bounds__(1024) void sscan_pbwd_kernel(const vmasr_sscan_bwd_
         samax[r] = am * kLog2e;
     }
     for (int e = tid; e < 8 * RB; e += nthr) saccD[e] = 0.f;   // saccD | saccB
+    if (geo.dA_lanes)
+        for (int e = tid; e < W * RB * 128; e += nthr) sdAl[e] = 0.f;
     if (tid < 2) sflag[tid] = 0;
     __syncthreads();
     const bool xvec = (N & 1) == 0;
@@ -624,12 +498,18 @@ __global__ __launch_bounds__(1024) void sscan_pbwd_kernel(const vmasr_sscan_bwd_
                         dBv[j][i] = fma2(gcur, splat(du_[i]), dBv[j][i]);
                         dCv[j][i] = fma2(splat(dov[i]), hv[i], dCv[j][i]);
                     }
-                    const float sA0 = wave_sum(accA.x), sA1 = wave_sum(accA.y);
                     const v2f Gout = fma2(rtot.a, Gin, rtot.b);
-                    if (lane == 0) {
-                        *reinterpret_cast<v2f *>(sG + r * NP2 + n0) = Gout;
-                        v2f *acc = reinterpret_cast<v2f *>(sdA + r * NP2 + n0);
-                        *acc = *acc + (v2f){sA0, sA1};
+                    if (PP == 1 && geo.dA_lanes) {            // my lane's slot of (wave, row): summed over the lanes at the end
+                        v2f *slot = reinterpret_cast<v2f *>(sdAl + ((size_t)(wave * RB + r) * kWave + lane) * 2);
+                        *slot = *slot + accA;
+                        if (lane == 0) *reinterpret_cast<v2f *>(sG + r * NP2 + n0) = Gout;
+                    } else {
+                        const float sA0 = wave_sum(accA.x), sA1 = wave_sum(accA.y);
+                        if (lane == 0) {
+                            *reinterpret_cast<v2f *>(sG + r * NP2 + n0) = Gout;
+                            v2f *acc = reinterpret_cast<v2f *>(sdA + r * NP2 + n0);
+                            *acc = *acc + (v2f){sA0, sA1};
+                        }
                     }
                 }
                 if constexpr (MODE != 2) {
@@ -708,6 +588,17 @@ __global__ __launch_bounds__(1024) void sscan_pbwd_kernel(const vmasr_sscan_bwd_
         }
     }
     if constexpr (MODE != 2) {
+        if (PP == 1 && geo.dA_lanes) {       // fold the per-lane partial sums of my pair, row by row
+            const int n0 = 2 * wave;
+            for (int r = 0; r < RB; ++r) {
+                const v2f v = *reinterpret_cast<const v2f *>(sdAl + ((size_t)(wave * RB + r) * kWave + lane) * 2);
+                const float s0 = wave_sum(v.x), s1 = wave_sum(v.y);
+                if (lane == 0 && n0 < N) {
+                    sdA[r * NP2 + n0] = s0;
+                    sdA[r * NP2 + n0 + 1] = s1;       // (the pad state of an odd N: never read)
+                }
+            }
+        }
         __syncthreads();
         for (int e = tid; e < RB * N; e += nthr) {
             const int r = e / N, n = e % N;
@@ -759,22 +650,31 @@ PPlan make_pplan(const vmasr_sscan_params &p, int split_req) {
 }
 
 size_t fwd_lds_floats(const PPlan &pl, int np) { return align4(3 * pl.RB * 2 * np + 3 * pl.RB) + (size_t)pl.RS * 2 * kTile + (size_t)pl.RS * pl.W * kTile + 4; }
+// dA: every (row, pair) unit ends in two 64-lane sums.  With one pair per wave and a small row block the lanes keep their partial
+// sums in LDS instead ([W][RB][64] float pairs, each slot owned by one lane: plain read-modify-write) and sum them ONCE per task.
+bool bwd_dA_lanes(const PPlan &pl) { return pl.PP == 1 && (size_t)pl.W * pl.RB * 128 * sizeof(float) <= 64 * 1024; }
 size_t bwd_lds_floats(const PPlan &pl, int np) {
-    return align4(4 * pl.RB * 2 * np + 11 * pl.RB) + (size_t)pl.RS * 4 * kTile + (size_t)pl.RS * pl.W * 2 * kTile + 4 + (pl.nrb > 1 ? (size_t)pl.W * kTile : 0);
+    return align4(4 * pl.RB * 2 * np + 11 * pl.RB) + (size_t)pl.RS * 4 * kTile + (size_t)pl.RS * pl.W * 2 * kTile + 4 + (pl.nrb > 1 ? (size_t)pl.W * kTile : 0) +
+           (bwd_dA_lanes(pl) ? (size_t)pl.W * pl.RB * 128 : 0);
 }
 
 template <typename T, bool VEC, int MODE>
 void launch_pfwd(int kid, double bytes, const vmasr_sscan_params &p, const PPlan &pl, hipStream_t st) {
     const int np = (p.dstate + 1) / 2;
-    const PGeom geo{pl.tiles_per_task, pl.nseg, np, pl.W, pl.RB, pl.RS, pl.nrb, nullptr};
+    const PGeom geo{pl.tiles_per_task, pl.nseg, np, pl.W, pl.RB, pl.RS, pl.nrb, 0, nullptr};
     const dim3 grid((unsigned)((long)p.batch * pl.nseg * p.n_groups * pl.nrb)), block(64 * pl.W);
     const size_t smem = fwd_lds_floats(pl, np) * sizeof(float);
-#define VMASR_PF(PPV, QV)                                                                                                          \
+#define VMASR_PF_(PPV, QV, RSV_)                                                                                                        \
     do {                                                                                                                           \
         if (smem > 64 * 1024)                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sscan_pfwd_kernel<T, VEC, PPV, QV, MODE>),                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sscan_pfwd_kernel<T, VEC, PPV, QV, RSV_, MODE>),             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                      \
-        VMASR_LAUNCH(kid, bytes, (sscan_pfwd_kernel<T, VEC, PPV, QV, MODE>), grid, block, smem, st, p, geo);                       \
+        VMASR_LAUNCH(kid, bytes, (sscan_pfwd_kernel<T, VEC, PPV, QV, RSV_, MODE>), grid, block, smem, st, p, geo);                 \
+    } while (0)
+#define VMASR_PF(PPV, QV)                      \
+    do {                                       \
+        if (pl.RS == 2) VMASR_PF_(PPV, QV, 2); \
+        else VMASR_PF_(PPV, QV, 1);            \
     } while (0)
     // (PP > 1 only when there are more than 16 pairs, i.e. W >= 9 waves: one position per thread)
     if (pl.PP == 1) {
@@ -783,13 +683,14 @@ void launch_pfwd(int kid, double bytes, const vmasr_sscan_params &p, const PPlan
     else if (pl.PP == 4) VMASR_PF(4, 1);
     else VMASR_PF(8, 1);
 #undef VMASR_PF
+#undef VMASR_PF_
 }
 
 template <typename T, bool VEC, int MODE>
 void launch_pbwd(int kid, double bytes, const vmasr_sscan_bwd_params &q, const PPlan &pl, unsigned *det, hipStream_t st) {
     const vmasr_sscan_params &p = q.f;
     const int np = (p.dstate + 1) / 2;
-    const PGeom geo{pl.tiles_per_task, pl.nseg, np, pl.W, pl.RB, pl.RS, pl.nrb, det};
+    const PGeom geo{pl.tiles_per_task, pl.nseg, np, pl.W, pl.RB, pl.RS, pl.nrb, bwd_dA_lanes(pl) ? 1 : 0, det};
     const dim3 grid((unsigned)((long)p.batch * pl.nseg * p.n_groups * pl.nrb)), block(64 * pl.W);
     const size_t smem = bwd_lds_floats(pl, np) * sizeof(float);
 #define VMASR_PB(PPV, QV)                                                                                                          \
