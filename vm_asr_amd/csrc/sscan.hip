@@ -810,7 +810,7 @@ VMASR_EXPORT int vmasr_sscan_fwd(const vmasr_sscan_params *pp, vmasr_stream_t st
                              p.B_dstate_stride, p.C_batch_stride, p.C_group_stride, p.C_dstate_stride});
     const Plan pl = make_plan(p, dyn, false);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dyn && !n_legacy()) return sscan_n_fwd(p, n_split_req(), vec, st);
+    if (dyn && p.dstate <= 128 && !n_legacy()) return sscan_n_fwd(p, n_split_req(), vec, st);
     switch (p.dtype) {
         case VMASR_F32: return dispatch_fwd<float>(p, pl, dyn, vec, st);
         case VMASR_F16: return dispatch_fwd<f16_t>(p, pl, dyn, vec, st);
@@ -822,7 +822,7 @@ VMASR_EXPORT size_t vmasr_sscan_bwd_workspace(const vmasr_sscan_bwd_params *q) {
     if (!q) return 0;
     const vmasr_sscan_params &p = q->f;
     if (p.batch <= 0 || p.dim <= 0 || p.seqlen <= 0 || p.dstate <= 0 || p.n_groups <= 0 || p.dim % p.n_groups) return 0;
-    if (p.dstate != 1 && !n_legacy()) return sscan_n_bwd_ws_floats(p, n_split_req()) * sizeof(float);
+    if (p.dstate != 1 && p.dstate <= 128 && !n_legacy()) return sscan_n_bwd_ws_floats(p, n_split_req()) * sizeof(float);
     return bwd_ws_floats(p, make_plan(p, p.dstate != 1, true)) * sizeof(float);
 }
 
@@ -841,12 +841,12 @@ VMASR_EXPORT int vmasr_sscan_bwd(const vmasr_sscan_bwd_params *qq, vmasr_stream_
                              q.ddelta_batch_stride, q.ddelta_d_stride, p.B_batch_stride, p.B_group_stride,
                              p.B_dstate_stride, p.C_batch_stride, p.C_group_stride, p.C_dstate_stride, (int64_t)p.seqlen});
     const Plan pl = make_plan(p, dyn, true);
-    const size_t need = ((dyn && !n_legacy()) ? sscan_n_bwd_ws_floats(p, n_split_req()) : bwd_ws_floats(p, pl)) * sizeof(float);
+    const size_t need = ((dyn && p.dstate <= 128 && !n_legacy()) ? sscan_n_bwd_ws_floats(p, n_split_req()) : bwd_ws_floats(p, pl)) * sizeof(float);
     if (need)
         VMASR_REQUIRE(q.ws_ptr && q.ws_bytes >= need, VMASR_ENOSPACE, "sscan_bwd: workspace too small (%zu < %zu)",
                       q.ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dyn && !n_legacy()) return sscan_n_bwd(q, n_split_req(), vec, st);
+    if (dyn && p.dstate <= 128 && !n_legacy()) return sscan_n_bwd(q, n_split_req(), vec, st);
     switch (p.dtype) {
         case VMASR_F32: return dispatch_bwd<float>(q, pl, dyn, vec, st);
         case VMASR_F16: return dispatch_bwd<f16_t>(q, pl, dyn, vec, st);

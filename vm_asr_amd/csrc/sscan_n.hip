@@ -87,7 +87,7 @@ __device__ __forceinline__ void store_pair(float *xi, const bool xvec, const boo
 // =====================================================================================================================
 // Q: positions per thread in the prologue / epilogue of a batch = ceil(RS 256 / threads): 1 for W >= 4 waves, 2 for W = 2..3, 4 for W = 1
 template <typename T, bool VEC, int PP, int Q, int RSV, int MODE>
-__global__ __launch_bounds__(1024) void sscan_pfwd_kernel(const vmasr_sscan_params p, const PGeom geo) {
+__global__ __launch_bounds__(PP == 1 ? 1024 : 512) void sscan_pfwd_kernel(const vmasr_sscan_params p, const PGeom geo) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), nthr = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(1024) void sscan_pfwd_kernel(const vmasr_sscan_para
 // part [RS][W][2][256] (du, ddelta summed over the wave's states).
 // =====================================================================================================================
 template <typename T, bool VEC, int PP, int Q, int MODE>
-__global__ __launch_bounds__(1024) void sscan_pbwd_kernel(const vmasr_sscan_bwd_params q, const PGeom geo) {
+__global__ __launch_bounds__(PP == 1 ? 1024 : 512) void sscan_pbwd_kernel(const vmasr_sscan_bwd_params q, const PGeom geo) {
     const vmasr_sscan_params &p = q.f;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     if (MODE != 2) det_enter(geo.det);
@@ -624,20 +624,31 @@ PPlan make_pplan(const vmasr_sscan_params &p, int split_req) {
     PPlan pl{};
     const int np = (p.dstate + 1) / 2, D = p.dim / p.n_groups;
     const int ntiles = (p.seqlen + kTile - 1) / kTile;
-    pl.PP = np <= 16 ? 1 : (np <= 32 ? 2 : (np <= 64 ? 4 : 8));
-    pl.W = (np + pl.PP - 1) / pl.PP;
-    pl.RS = (pl.W >= 8 && D % 2 == 0) ? 2 : 1;
-    // workgroups wanted: one 16-wave workgroup per CU, or enough smaller ones for ~4096 waves
-    const long target = std::max(256L, 4096L / pl.W);
     const long rows = (long)p.batch * p.dim;
     static const int env_rb = [] { const char *e = getenv("VMASR_SSCAN_N_RB"); return e ? atoi(e) : 0; }();
-    long rb = env_rb > 0 ? env_rb : std::max(1L, rows / target);
-    rb = std::min<long>(rb, 64);
-    int RB = pl.RS;
-    for (int c = pl.RS; c <= D && c <= rb; c += pl.RS)
-        if (D % c == 0) RB = c;
-    pl.RB = RB;
-    pl.nrb = D / RB;
+    static const int env_pp = [] { const char *e = getenv("VMASR_SSCAN_N_PP"); return e ? atoi(e) : 0; }();
+    // pairs per wave: one while there are at most 16 pairs (d_state <= 32: up to 16 pair-owner waves), else as many as keep <= 16 waves.
+    // (Giving the waves of shallow calls — the output blocks' 2 .. 32 rows per group — 2 or 4 pairs each, to amortise the per-tile costs
+    // over more units, was measured 2.5-4x SLOWER: with 4-8 waves per workgroup at ~250 VGPRs the SIMDs hold 2 waves, and this kernel's
+    // serial scan / recurrence chains need >= 4 to hide their latency: profiles/r05_scan_n_microbench_pp.log.  VMASR_SSCAN_N_PP forces it.)
+    int PP = np <= 16 ? 1 : (np <= 32 ? 2 : 4);      // (d_state <= 128 here; above that sscan.hip's one-state-at-a-time kernels)
+    auto plan_rows = [&](int pp) {
+        pl.PP = pp;
+        pl.W = (np + pp - 1) / pp;
+        pl.RS = (pl.W >= 8 && D % 2 == 0) ? 2 : 1;
+        const long target = std::max(256L, 4096L / pl.W);          // one 16-wave workgroup per CU, or enough smaller ones for ~4096 waves
+        long rb = env_rb > 0 ? env_rb : std::max(1L, rows / target);
+        rb = std::min<long>(rb, 64);
+        int RB = pl.RS;
+        for (int c = pl.RS; c <= D && c <= rb; c += pl.RS)
+            if (D % c == 0) RB = c;
+        pl.RB = RB;
+        pl.nrb = D / RB;
+        return target;
+    };
+    long target = plan_rows(PP);
+    if (env_pp > 0 && (env_pp == 1 || env_pp == 2 || env_pp == 4) && (np + env_pp - 1) / env_pp <= 16 && (env_pp == 1 || (np + env_pp - 1) / env_pp >= 4))
+        target = plan_rows(env_pp);
     const long wgs = (long)p.batch * p.n_groups * pl.nrb;
     int nseg = 1;
     if (split_req == 1 || (split_req < 0 && wgs * 2 <= target)) nseg = (int)std::min<long>(ntiles, std::max(2L, (target + wgs - 1) / wgs));
@@ -676,12 +687,13 @@ void launch_pfwd(int kid, double bytes, const vmasr_sscan_params &p, const PPlan
         if (pl.RS == 2) VMASR_PF_(PPV, QV, 2); \
         else VMASR_PF_(PPV, QV, 1);            \
     } while (0)
-    // (PP > 1 only when there are more than 16 pairs, i.e. W >= 9 waves: one position per thread)
+    // (several pairs per wave only with >= 4 waves: one position per thread in the prologue)
     if (pl.PP == 1) {
-        if (pl.W >= 4) VMASR_PF(1, 1); else if (pl.W >= 2) VMASR_PF(1, 2); else VMASR_PF(1, 4);
+        if (pl.W >= 4) VMASR_PF(1, 1);
+        else if (pl.W >= 2) VMASR_PF_(1, 2, 1);
+        else VMASR_PF_(1, 4, 1);
     } else if (pl.PP == 2) VMASR_PF(2, 1);
-    else if (pl.PP == 4) VMASR_PF(4, 1);
-    else VMASR_PF(8, 1);
+    else VMASR_PF(4, 1);
 #undef VMASR_PF
 #undef VMASR_PF_
 }
@@ -703,8 +715,7 @@ void launch_pbwd(int kid, double bytes, const vmasr_sscan_bwd_params &q, const P
     if (pl.PP == 1) {
         if (pl.W >= 4) VMASR_PB(1, 1); else if (pl.W >= 2) VMASR_PB(1, 2); else VMASR_PB(1, 4);
     } else if (pl.PP == 2) VMASR_PB(2, 1);
-    else if (pl.PP == 4) VMASR_PB(4, 1);
-    else VMASR_PB(8, 1);
+    else VMASR_PB(4, 1);
 #undef VMASR_PB
 }
 
@@ -758,8 +769,8 @@ int sscan_n_fwd(const vmasr_sscan_params &p, int split_req, bool vec, hipStream_
     VMASR_REQUIRE(fwd_lds_floats(pl, (p.dstate + 1) / 2) * sizeof(float) <= 160 * 1024, VMASR_EINVAL, "sscan_fwd: d_state %d needs too much LDS", p.dstate);
     switch (p.dtype) {
         case VMASR_F32: return vec ? run_pfwd<float, true>(p, pl, st) : run_pfwd<float, false>(p, pl, st);
-        case VMASR_F16: return vec ? run_pfwd<f16_t, true>(p, pl, st) : run_pfwd<f16_t, false>(p, pl, st);
-        default: return vec ? run_pfwd<bf16_t, true>(p, pl, st) : run_pfwd<bf16_t, false>(p, pl, st);
+        case VMASR_F16: return run_pfwd<f16_t, false>(p, pl, st);      // (16-bit I/O: element-wise loads only — every shipped config scans fp32)
+        default: return run_pfwd<bf16_t, false>(p, pl, st);
     }
 }
 
@@ -769,8 +780,8 @@ int sscan_n_bwd(const vmasr_sscan_bwd_params &q, int split_req, bool vec, hipStr
     VMASR_REQUIRE(bwd_lds_floats(pl, (p.dstate + 1) / 2) * sizeof(float) <= 160 * 1024, VMASR_EINVAL, "sscan_bwd: d_state %d needs too much LDS", p.dstate);
     switch (p.dtype) {
         case VMASR_F32: return vec ? run_pbwd<float, true>(q, pl, st) : run_pbwd<float, false>(q, pl, st);
-        case VMASR_F16: return vec ? run_pbwd<f16_t, true>(q, pl, st) : run_pbwd<f16_t, false>(q, pl, st);
-        default: return vec ? run_pbwd<bf16_t, true>(q, pl, st) : run_pbwd<bf16_t, false>(q, pl, st);
+        case VMASR_F16: return run_pbwd<f16_t, false>(q, pl, st);      // (16-bit I/O: element-wise loads only — every shipped config scans fp32)
+        default: return run_pbwd<bf16_t, false>(q, pl, st);
     }
 }
 
