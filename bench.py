@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PMC_FILE = "r04_pmc_traffic.json"
+PMC_FILE = "r05_pmc_traffic.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 
@@ -536,7 +536,7 @@ def main():
         if dom:
             d = kern[dom]
             # HBM bytes per launch from the PMC passes of this same workload (rocprofv3 cannot run inside bench.py): profiles/<PMC_FILE>,
-            # made by tools/evidence_r04.sh / tools/pmc_bench_report.py, which records the digest of the kernel sources it measured;
+            # made by tools/evidence_r05.sh / tools/pmc_bench_report.py, which records the digest of the kernel sources it measured;
             # a file measured on other sources is NOT quoted (traffic = null, traffic_note says why)
             traffic, traffic_note, pmc_file = None, None, PMC_FILE
             try:
