@@ -121,7 +121,7 @@ def cpu_baseline(config, budget_s=60.0):
     return {"value": 1.0 / dt, "unit": "clips/s", "cores": oracle.num_threads(), "kind": "port",
             "sample": f"1 clip x 1 full train step ({'G+MPD' if cfg.TRAIN.ADVERSARIAL.ENABLE else 'G'}, fp32) "
                       f"in {dt:.1f} s: torch-CPU modules + oracle C kernels (OpenMP)",
-            "spread": "one cold step: 0.070-0.094 clips/s between boxes of the pool (rounds 4-5)"}
+            "spread": "one cold step: 0.037-0.094 clips/s between boxes of the pool (rounds 4-5)"}
 
 
 def run_point(config, args, device, rank, world, steps, warmup, timing, with_metrics=False):
