@@ -157,18 +157,30 @@ __global__ __launch_bounds__(PP == 1 ? 1024 : 512) void sscan_pfwd_kernel(const 
     if (tile0 < tile1) prefetch(tile0, 0);
     int batch = 0;
 
-    for (int tile = tile0; tile < tile1; ++tile) {
+    // B / C of my pairs: this tile's in (Bv, Cv), the next tile's loading into (Bn, Cn) while this one is worked on
+    v2f Bv[PP][kItems], Cv[PP][kItems], Bn[PP][kItems], Cn[PP][kItems];
+    auto load_bc = [&](const int tile, v2f (&Bd)[PP][kItems], v2f (&Cd)[PP][kItems]) {
         const int t0 = tile * kTile + lane * kItems;
-        const bool full = (tile + 1) * kTile <= L;   // wave-uniform
-        v2f Bv[PP][kItems], Cv[PP][kItems];
+        const bool full = (tile + 1) * kTile <= L;
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
             const int n0 = 2 * (wave * PP + j);
             if (n0 < N) {
-                load_pair4<T, VEC>(Bg, p.B_dstate_stride, n0, n0 + 1 < N, t0, L, full, Bv[j]);
-                if (MODE != 2) load_pair4<T, VEC>(Cg, p.C_dstate_stride, n0, n0 + 1 < N, t0, L, full, Cv[j]);
+                load_pair4<T, VEC>(Bg, p.B_dstate_stride, n0, n0 + 1 < N, t0, L, full, Bd[j]);
+                if (MODE != 2) load_pair4<T, VEC>(Cg, p.C_dstate_stride, n0, n0 + 1 < N, t0, L, full, Cd[j]);
             }
         }
+    };
+    if (tile0 < tile1) load_bc(tile0, Bn, Cn);
+
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int t0 = tile * kTile + lane * kItems;
+        const bool full = (tile + 1) * kTile <= L;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < PP; ++j)
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) { Bv[j][i] = Bn[j][i]; Cv[j][i] = Cn[j][i]; }
+        if (tile + 1 < tile1) load_bc(tile + 1, Bn, Cn);
         for (int kb = 0; kb < RB; kb += RS) {
             // ---- prologue of the batch: delta = softplus(.), delta u, D u — once per position, by whichever thread holds it
             // (its loads were issued one batch ahead: pre_u / pre_d)
@@ -362,10 +374,12 @@ __global__ __launch_bounds__(PP == 1 ? 1024 : 512) void sscan_pbwd_kernel(const 
     if (tile0 < tile1) prefetch(tile1 - 1, 0);
     int batch = 0;
 
-    for (int tile = tile1 - 1; tile >= tile0; --tile) {
+    // B / C of my pairs for a tile: loaded once per tile, into the SAME registers right after the tile's last unit — in flight
+    // behind the dB / dC write-out, the epilogue and the next tile's first prologue (no second buffer: the backward has no registers to spare)
+    v2f Bv[PP][kItems], Cv[PP][kItems];
+    auto load_bc = [&](const int tile) {
         const int t0 = tile * kTile + lane * kItems;
-        const bool full = (tile + 1) * kTile <= L;   // wave-uniform
-        v2f Bv[PP][kItems], Cv[PP][kItems], dBv[PP][kItems], dCv[PP][kItems];
+        const bool full = (tile + 1) * kTile <= L;
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
             const int n0 = 2 * (wave * PP + j);
@@ -373,9 +387,18 @@ __global__ __launch_bounds__(PP == 1 ? 1024 : 512) void sscan_pbwd_kernel(const 
                 load_pair4<T, VEC>(Cg, p.C_dstate_stride, n0, n0 + 1 < N, t0, L, full, Cv[j]);
                 if (MODE != 2) load_pair4<T, VEC>(Bg, p.B_dstate_stride, n0, n0 + 1 < N, t0, L, full, Bv[j]);
             }
+        }
+    };
+    if (tile0 < tile1) load_bc(tile1 - 1);
+
+    for (int tile = tile1 - 1; tile >= tile0; --tile) {
+        const int t0 = tile * kTile + lane * kItems;
+        const bool full = (tile + 1) * kTile <= L;   // wave-uniform
+        v2f dBv[PP][kItems], dCv[PP][kItems];
+#pragma unroll
+        for (int j = 0; j < PP; ++j)
 #pragma unroll
             for (int i = 0; i < kItems; ++i) { dBv[j][i] = splat(0.f); dCv[j][i] = splat(0.f); }
-        }
         for (int kb = 0; kb < RB; kb += RS) {
             // ---- prologue: delta = softplus(.), its derivative, delta u — once per position (loads issued one batch ahead)
             float sg[Q], dyq[Q], pdq[Q];
@@ -554,6 +577,7 @@ __global__ __launch_bounds__(PP == 1 ? 1024 : 512) void sscan_pbwd_kernel(const 
                 }
             }
         }
+        if (tile > tile0) load_bc(tile - 1);
         if constexpr (MODE != 2) {
             // dB / dC of my pairs, summed over the RB rows in registers.  One workgroup per group: 16-byte stores.  Otherwise float
             // atomics, transposed through a per-wave LDS kilobyte so that every atomic instruction covers 64 CONSECUTIVE floats
