@@ -161,6 +161,33 @@ def test_scan_fp64_adjudicated(shape):
     ss.tune(-1, -1)
 
 
+def test_scan_general_n_large_decay_arguments():
+    """csrc/sscan_n.hip adds the exponent of 2^(delta A log2 e) to the bits directly while |delta A log2 e| <= 125 for the whole
+    workgroup and takes a clamped ldexp form otherwise (a wave-uniform branch per batch of rows): inputs that force the second
+    form (delta up to 20, A down to -10: arguments down to -290, decays that underflow to 0) and a mix of both in one call."""
+    from vm_asr_amd import selective_scan as ss
+    for N, scale in ((8, 40.0), (32, 40.0), (6, 8.0)):
+        shape = (2, 16, 4, N, 700)
+        u, delta, A, Bm, Cm, D, bias, dout = _scan_inputs(*shape, seed=21)
+        delta = delta * scale
+        delta[:, ::2] *= 0.02                       # every other row stays in the direct-exponent range
+        A = A * 20.0
+        cpu = (u, delta, A, Bm, Cm, D, bias, dout)
+        want = oracle.sscan_fwd(*[t.numpy() for t in cpu[:7]], True)
+        wants = oracle.sscan_bwd(*[t.numpy() for t in cpu[:7]], dout.numpy(), True)
+        dev = [t.to(DEV) for t in cpu]
+        for tune in ((-1, -1), (1, 1)):
+            ss.tune(*tune)
+            out, x = ss.fwd(*dev[:7], True, 1)
+            assert torch.isfinite(out).all()
+            _close(out, want, 1e-4, _scaled(want), f"out N={N} tune={tune}")
+            got = ss.bwd(*dev[:7], dev[7], x, True, 1)
+            for name, g, w in zip(("du", "ddelta", "dA", "dB", "dC", "dD", "dbias"), got, wants):
+                assert torch.isfinite(g).all(), name
+                _close(g, w, 1e-4, _scaled(w), f"{name} N={N} tune={tune}")
+    ss.tune(-1, -1)
+
+
 def test_scan_long_sequence_dstate32_stress():
     """BASELINE.json configs[4]: d_state 32 with the n_fft 2048 geometry — the 1024x512 output block, L = 524 288,
     8 rows, 32 states per row (the general-N path, 2 049 saved chunks).  Forward and every gradient vs the
