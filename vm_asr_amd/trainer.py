@@ -1141,23 +1141,35 @@ class Trainer(BaseTrainer):
         multi = self.world > 1 and dist.is_initialized()
         if multi:
             dist.barrier()          # every rank has built its models / communicator before anybody starts capturing
-        try:
-            self._graphed = GraphedTrainStep(self, example_batch, warmup)
-            ok = True
-        except Exception as e:  # pragma: no cover - depends on the runtime
-            self._graphed = None
-            self.graph_error = f"{type(e).__name__}: {e}"
-            self.logger.warning(f"HIP graph capture unavailable ({self.graph_error}); running eagerly")
-            ok = False
-        if multi:
-            # all ranks replay graphs or none does: a rank that fell back to the eager step would issue its collectives in a
-            # different order relative to its kernels and run ~2x slower — the others would sit in the all-reduce
-            dev = torch.device("cpu") if dist.get_backend() == "gloo" else self.device
-            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if ok and flag.item() == 0.0:
-                self._graphed, ok = None, False
-                self.graph_error = "graph capture failed on another rank"
+        def attempt():
+            try:
+                self._graphed = GraphedTrainStep(self, example_batch, warmup)
+                ok = True
+            except Exception as e:  # pragma: no cover - depends on the runtime
+                self._graphed = None
+                self.graph_error = f"{type(e).__name__}: {e}"
+                self.logger.warning(f"HIP graph capture unavailable ({self.graph_error})")
+                ok = False
+            if multi:
+                # all ranks replay graphs or none does: a rank that fell back to the eager step would issue its collectives in a
+                # different order relative to its kernels and run ~2x slower — the others would sit in the all-reduce
+                dev = torch.device("cpu") if dist.get_backend() == "gloo" else self.device
+                flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if ok and flag.item() == 0.0:
+                    self._graphed, ok = None, False
+                    self.graph_error = "graph capture failed on another rank"
+            return ok
+        ok = attempt()
+        if (not ok and multi and dist.get_backend() == "nccl" and os.environ.get("VMASR_GRAPH_COLLECTIVES", "1") == "1"):
+            # the gradient all-reduces are captured into the step's graph by default (graph_step.py): if that capture fails on any
+            # rank, every rank tries once more with the collectives BETWEEN the graphs (the round-4 layout) before giving graphs up
+            self.logger.warning("retrying the capture with the collectives between the graphs (VMASR_GRAPH_COLLECTIVES=0)")
+            os.environ["VMASR_GRAPH_COLLECTIVES"] = "0"
+            torch.cuda.synchronize(self.device)
+            ok = attempt()
+        if not ok:
+            self.logger.warning("running eagerly")
         if snap is not None:
             torch.cuda.synchronize(self.device)
             self._restore_training_state(snap)
