@@ -76,3 +76,14 @@ def test_emit_prints_the_compact_line_last(tmp_path, capsys):
     assert len(lines) == 1 and len(lines[0]) <= bench.MAX_LINE
     full = json.load(open(tmp_path / "bench_detail.json"))
     assert "kernels" in full["roofline"] and json.loads(lines[0])["detail"] == "bench_detail.json"
+
+
+def test_compact_line_with_in_graph_collectives():
+    """world > 1 on RCCL: the collectives are branches of the step's graph and cannot be bracketed by events — the per-rank exposed
+    times are null and the line says where the collectives run."""
+    out = _recorded(8)
+    out["per_rank"]["allreduce_exposed_ms_per_step"] = [None] * 8
+    out["per_rank"]["collectives"] = "branches of the step's graph (RCCL captured; MPD gradient as bf16)"
+    rec = json.loads(bench.compact(out))
+    assert rec["distributed"]["allreduce_exposed_ms_per_step"] is None and rec["distributed"]["collectives"].startswith("branches of the step")
+    assert len(bench.compact(out)) <= bench.MAX_LINE
