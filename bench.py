@@ -21,6 +21,7 @@ import sys
 import time
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # vm_asr_amd/hip_env.py: before the GPU is initialised
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # vm_asr_amd/hip_env.py: stream-K GEMMs of two streams can stall the device
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

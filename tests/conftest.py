@@ -1,6 +1,7 @@
 import os
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # vm_asr_amd/hip_env.py: before the GPU is initialised
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # vm_asr_amd/hip_env.py: stream-K GEMMs of two streams can stall the device
 # the fp32 parity suite adjudicates forward AND backward with the float64-accumulating Linear (vm_asr_amd/linear.py:_use_f64acc; the
 # product's default keeps it to gradient-free evaluation, where the LSD parity claim lives)
 os.environ.setdefault("VMASR_LINEAR_F64ACC", "1")

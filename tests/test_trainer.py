@@ -273,6 +273,11 @@ def test_two_stream_step_gives_the_same_gradients(monkeypatch):
         for m in tr.models.values():
             m.train()
         assert tr._two_streams() == (flag == "1")
+        if flag == "1":      # not without data-parallel library GEMMs (stream-K GEMMs of two streams can stall the device: hip_env.py)
+            with monkeypatch.context() as mp, pytest.warns(UserWarning, match="TENSILE_STREAMK_DATA_PARALLEL"):
+                mp.delenv("TENSILE_STREAMK_DATA_PARALLEL")
+                assert not tr._two_streams()
+            assert tr._two_streams()
         res = []
         for b in batches:
             _, logs = tr._forward_backward(*b)
@@ -737,6 +742,62 @@ def test_fullsize_graph_replay_matches_eager_on_new_batches():
     for i, (a, b) in enumerate(zip(logs["eager"], logs["graph"])):
         for k in a:
             assert abs(a[k] - b[k]) <= (5e-3 if i == 0 else 5e-2) * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+
+
+@pytest.mark.gpu
+def test_generator_only_graph_with_the_phase_lane_matches_eager():
+    """Generator-only training (vm_asr_48k: no discriminator): the captured step runs the generator's phase branch on a second
+    HIP stream (model._lanes, trainer.enable_graphs sets phase_lane).  Two optimisation steps on NEW batches through the replayed
+    graph give the eager step's losses from the same state, and the lane is really in the graph (VMASR_GEN_STREAMS=1 gives a graph
+    with fewer concurrent branches: checked through the model's flag and the stream pool)."""
+    import bench
+    from vm_asr_amd import model as gen_model
+    from vm_asr_amd.trainer import unwrap
+    cfg = bench.make_config("vm_asr_48k", 3)
+    cfg.defrost()
+    cfg.MODEL.VSSM.DROP_PATH_RATE = 0.0
+    cfg.freeze()
+    dev = torch.device("cuda", 0)
+    batches = [bench.synth_batch(cfg, dev, s) for s in range(3)]
+    logs = {}
+    for mode in ("eager", "graph"):
+        tr = bench.build_trainer(cfg, dev, amp=True, capturable=True)
+        for m in tr.models.values():
+            m.train()
+        tr.train_step(*batches[0])
+        if mode == "graph":
+            gen_model._PHASE_STREAMS.clear()
+            assert tr.enable_graphs(batches[0], warmup=2)
+            assert unwrap(tr.models["generator"]).phase_lane and dev in gen_model._PHASE_STREAMS     # the lane was used in the capture
+        out = []
+        for b in batches[1:]:
+            _, lg = tr.train_step(*b)
+            out.append({k: float(v) for k, v in lg.items()})
+        logs[mode] = out
+        del tr
+        torch.cuda.empty_cache()
+    for i, (a, b) in enumerate(zip(logs["eager"], logs["graph"])):
+        for k in a:
+            assert abs(a[k] - b[k]) <= (5e-3 if i == 0 else 5e-2) * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+
+
+@pytest.mark.gpu
+def test_two_stream_step_at_batch_35_finishes():
+    """Regression: with hipBLASLt's stream-K GEMMs (every gfx950 kernel of this stack is one) the two-stream step stopped the device
+    for good at batch 35 — two concurrent GEMMs waiting for each other's partial tiles (vm_asr_amd/hip_env.py,
+    profiles/r05_streamk_stall.md).  TENSILE_STREAMK_DATA_PARALLEL=1 (set by every entry point) removes the cross-workgroup
+    wait.  Run in a child process under a timeout, so that a regression fails this test instead of hanging the suite."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"
+    for extra in (["--batch", "35"], ["--workload", "vm_asr_48k", "--batch", "35"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                            "--no-extra-points", "--no-kernel-timing"] + extra, capture_output=True, text=True, timeout=240, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line.get("value", 0) > 50, line
 
 
 @pytest.mark.gpu

@@ -133,6 +133,20 @@ class GraphedTrainStep:
             for key in (["mpd"] if tr.gan else []) + ["generator"]:
                 comm.all_reduce_(torch.zeros_like(tr._flat[key], dtype=tr._comm_dtype(key)), avg=True, stream=tr._comm_stream())
             torch.cuda.synchronize()
+        # No cyclic garbage collection while a capture is open: an old CUDAGraph (a trainer <-> GraphedTrainStep cycle left by an earlier
+        # trainer of this process) whose destructor runs inside a capture frees device memory there, which the runtime refuses — the
+        # process aborts.  torch.cuda.graph() only collects first when torch.compiler.config.force_cudagraph_gc is set (2.9+).
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture(tr)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _capture(self, tr):
         self.graph_fb = torch.cuda.CUDAGraph()
         # thread_local: only THIS thread's calls are checked during capture — RCCL's watchdog thread polls its events
         # (hipEventQuery) at any time, which in the default global mode would invalidate a capture in progress

@@ -7,7 +7,17 @@ multi-block ATen reduction zeroes its semaphores with hipMemsetAsync, so from th
 (re-used) semaphore buffer return stale or partial results — silently, and invisibly when the graph is replayed on the SAME
 data (tools/graph_debug6.py: 9 wrong results in 40 for a graph of ten reductions; 0 with packet capture off).  The training
 step contains ~170 such reductions.  Node-by-node replay costs ~1 ms of the 37 ms step.  graph_step.replay_selftest() checks
-the behaviour at run time and refuses graph mode when it is broken."""
+the behaviour at run time and refuses graph mode when it is broken.
+
+TENSILE_STREAMK_DATA_PARALLEL=1: every hipBLASLt GEMM kernel of this stack for gfx950 is a stream-K kernel (..._SK3_SKXCCM8): when the
+tiles of a problem do not divide over the CUs, workgroups of ONE launch wait for each other's partial tiles through flags in memory.
+Two such GEMMs running at the same time on two HIP streams (the generator's Linear layers beside the discriminator's GEMMs: the
+two-stream step of DESIGN.md 4g) can stop the device for good — measured at batch 35 (the step never finishes; rocgdb shows one or two
+Cijk_* dispatches resident and every queue behind them waiting: profiles/r05_streamk_stall.md), not at the batch sizes benchmarked
+before, because whether the stream-K part of a kernel is used depends on the shape.  With this setting the kernels split by output
+tile only (no cross-workgroup wait), which is also what the small GEMMs of this model want: the headline step is 1 % FASTER with it.
+trainer._two_streams() refuses the two-stream layout when the variable is not in force."""
 import os
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")

@@ -23,7 +23,9 @@ Reference behaviours that change numerics and are reproduced on purpose (SURVEY.
 Only the configuration family reachable from configs/*.yaml is built: 4-entry dims,
 norm "LN", patch-embed v2, down/upsample v1, output v3, interact dual/m2p/p2m/single.
 """
+import os
 from collections import OrderedDict
+from contextlib import nullcontext as _nullctx
 from copy import deepcopy
 
 import torch
@@ -257,6 +259,22 @@ class MambaUNet(nn.Module):
         return super().__str__() + f"\nTrainable parameters: {n}"
 
 
+_PHASE_STREAMS = {}
+
+
+class _OnMain:
+    """(dev aid) a phase-chain segment run on the main stream after all: both streams meet before and after it."""
+    def __init__(self, ln):
+        self.ln = ln
+
+    def __enter__(self):
+        self.ln.main.wait_stream(self.ln.side)
+
+    def __exit__(self, *a):
+        self.ln.side.wait_stream(self.ln.main)
+        return False
+
+
 class DualStreamInteractiveMambaUNet(MambaUNet):
     def __init__(self, *args, interact="dual", **kwargs):
         super().__init__(*args, **kwargs)
@@ -285,6 +303,70 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
             phase = phase + mag
         return mag, phase
 
+    # ---- the phase branch on a HIP stream of its own (VMASR_GEN_STREAMS, default "auto": see _lanes) -----------------------------------
+    # Between two interaction points the magnitude and the phase branch are independent (different weights in the patch embeddings, the
+    # encoders and the output layers; the shared decoders run both stacked).  The generator is ~1 400 launches of 5-20 us, so one branch
+    # alone leaves most of the chip idle.  Here the phase branch lives on ONE second stream for the whole forward — two long chains with
+    # cross edges at the interaction points (event waits), not a fork / join per stage: in a captured step the runtime gives every fork a
+    # stream from its pool, and a per-stage fork lands on the discriminator's branch every so often (measured: generator backward 12.6 ->
+    # 17.6 ms beside the D-loss backward).  autograd runs every backward node on its forward's stream, so the backward has the same shape.
+    class _Lanes:
+        def __init__(self, dev, side):
+            self.on = side is not None
+            self.main = torch.cuda.current_stream(dev) if self.on else None
+            self.side = side
+            if self.on:
+                side.wait_stream(self.main)
+
+        def phase(self, tag=None):       # context: the phase chain's stream
+            if not self.on:
+                return _nullctx()
+            only = os.environ.get("VMASR_GEN_LANES")       # dev aid: which segments leave the main stream (pe,e0..e3,d0..d3,out,ia)
+            if only is not None and tag is not None and tag not in only.split(","):
+                return _OnMain(self)
+            return torch.cuda.stream(self.side)
+
+        def to_side(self, *ts):          # tensors produced on main are about to be read on the side stream
+            if self.on:
+                self.side.wait_stream(self.main)
+                for t in ts:     # (also while capturing: the allocator then keeps the block out of reuse until the capture ends)
+                    t.record_stream(self.side)
+
+        def to_main(self, *ts):          # tensors produced on the side stream are about to be read on main
+            if self.on:
+                self.main.wait_stream(self.side)
+                for t in ts:
+                    t.record_stream(self.main)
+
+    def _lanes(self, x):
+        side = None
+        mode = os.environ.get("VMASR_GEN_STREAMS", "auto")
+        # In captured steps only (the dependencies are then edges of the graph; "2eager" forces the eager path, a debugging aid), and
+        # only with data-parallel library GEMMs (vm_asr_amd/hip_env.py: two concurrent stream-K GEMMs can stop the device).
+        # "auto": where the trainer says so (self.phase_lane: generator-only steps, +14 ... +24 % clips/s at batch 35 ... 4) — beside
+        # the discriminator's side stream a third stream LOSES (173 -> 147 clips/s at batch 4: profiles/r05_gen_streams_ab.log), so
+        # the GAN step keeps the generator on one stream.  "2" / "1" force it on / off.
+        want = mode == "2" or (mode == "auto" and getattr(self, "phase_lane", False))
+        if (x.is_cuda and self.interact != "single" and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"
+                and (mode == "2eager" or (want and torch.cuda.is_current_stream_capturing()))):
+            side = _PHASE_STREAMS.get(x.device)          # (not a module attribute: a Stream cannot be deep-copied with the model)
+            if side is None:
+                side = _PHASE_STREAMS[x.device] = torch.cuda.Stream(x.device)
+        return self._Lanes(x.device, side)
+
+    def _interact_lanes(self, ln, mag, phase):
+        """_interact with the magnitude sum on main and the phase sum on the phase chain's stream."""
+        if not ln.on:
+            return self._interact(mag, phase)
+        if self.interact in ("dual", "p2m"):
+            ln.to_main(phase)
+            mag = mag + phase
+        if self.interact in ("dual", "m2p"):
+            ln.to_side(mag)
+            with ln.phase("ia"):
+                phase = phase + mag
+        return mag, phase
+
     def forward(self, x, hf):
         length = x.shape[-1]
         mag_in, phase_in = self._mag_phase(x)          # (B,1,F,M) fp32
@@ -297,14 +379,20 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
         if self.training and self._dp_pool is not None:
             self._dp_pool.refresh(2 * x.shape[0], dev)     # 2B: the shared decoders run both streams stacked
         if not single:
-            mag, phase = self.patch_embed_mag(mag), self.patch_embed_phase(phase)
+            ln = self._lanes(x)
+            ln.to_side(phase)
+            with ln.phase("pe"):
+                phase = self.patch_embed_phase(phase)
+            mag = self.patch_embed_mag(mag)
             skips_m, skips_p = [mag], [phase]
             for i in range(self.num_layers):
-                mag, phase = self.layers_encoder_mag[i](mag), self.layers_encoder_phase[i](phase)
+                with ln.phase(f"e{i}"):
+                    phase = self.layers_encoder_phase[i](phase)
+                mag = self.layers_encoder_mag[i](mag)
                 if i < self.num_layers - 1:
                     skips_m.append(mag)
                     skips_p.append(phase)
-                mag, phase = self._interact(mag, phase)
+                mag, phase = self._interact_lanes(ln, mag, phase)
             for i in range(self.num_layers):
                 dec_m, dec_p = self.layers_decoder_mag[i], self.layers_decoder_phase[i]
                 if i != 0:
@@ -312,20 +400,25 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
                     if self.concat_skip:
                         # sic: the phase stream also runs through the MAGNITUDE decoder (model/model.py:1187).
                         # Same weights for both streams -> one pass over the stacked batch (identical
-                        # arithmetic per sample, half the kernel launches of two separate calls).
+                        # arithmetic per sample, half the kernel launches of two separate calls) — on the main stream.
+                        ln.to_main(phase, ps)
                         both = dec_m(torch.cat((torch.cat((mag, ms), dim=-1), torch.cat((phase, ps), dim=-1)), dim=0))
                         mag, phase = both[: mag.shape[0]], both[mag.shape[0]:]
+                        ln.to_side(phase)
                     else:
-                        mag, phase = dec_m(mag + ms), dec_p(phase + ps)
+                        with ln.phase(f"d{i}"):
+                            phase = dec_p(phase + ps)
+                        mag = dec_m(mag + ms)
                 else:
-                    mag, phase = dec_m(mag), dec_p(phase)
-                mag, phase = self._interact(mag, phase)
+                    with ln.phase("d0"):
+                        phase = dec_p(phase)
+                    mag = dec_m(mag)
+                mag, phase = self._interact_lanes(ln, mag, phase)
             ms, ps = skips_m.pop(), skips_p.pop()
-            if self.concat_skip:
-                mag = self.output_layer_mag(torch.cat((mag, ms), dim=-1))
-                phase = self.output_layer_phase(torch.cat((phase, ps), dim=-1))
-            else:
-                mag, phase = self.output_layer_mag(mag + ms), self.output_layer_phase(phase + ps)
+            with ln.phase("out"):
+                phase = self.output_layer_phase(torch.cat((phase, ps), dim=-1) if self.concat_skip else phase + ps)
+            mag = self.output_layer_mag(torch.cat((mag, ms), dim=-1) if self.concat_skip else mag + ms)
+            ln.to_main(phase)
         else:
             mag = self.patch_embed_mag(mag)
             skips_m = [mag]

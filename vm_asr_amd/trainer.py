@@ -724,7 +724,17 @@ class Trainer(BaseTrainer):
         off in deterministic mode (the ordered-accumulation tickets are per kernel, not per stream)."""
         if os.environ.get("VMASR_TWO_STREAM", "1") != "1" or os.environ.get("VMASR_DETERMINISTIC", "0") == "1":
             return False
-        return self._share_fake_pass()
+        if not self._share_fake_pass():
+            return False
+        if os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") != "1":
+            # hipBLASLt's stream-K GEMMs of two concurrent streams can stop the device for good (vm_asr_amd/hip_env.py)
+            if not getattr(self, "_warned_streamk", False):
+                self._warned_streamk = True
+                import warnings
+                warnings.warn("TENSILE_STREAMK_DATA_PARALLEL=1 is not set: the train step stays on one HIP stream "
+                              "(vm_asr_amd/hip_env.py sets it when the package is imported before the first GEMM)")
+            return False
+        return True
 
     def side_cu_limits(self):
         """(forward, backward) CU limits of the discriminator's convolution kernels while the two streams overlap, DERIVED from the
@@ -1141,6 +1151,8 @@ class Trainer(BaseTrainer):
         multi = self.world > 1 and dist.is_initialized()
         if multi:
             dist.barrier()          # every rank has built its models / communicator before anybody starts capturing
+        # generator-only steps: the phase branch of the generator on a second stream inside the captured step (model._lanes)
+        unwrap(self.models["generator"]).phase_lane = not self.gan
         def attempt():
             try:
                 self._graphed = GraphedTrainStep(self, example_batch, warmup)
