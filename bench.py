@@ -587,6 +587,7 @@ def main():
         for name, wl, bsz, gemm, met in (("mpd_gemm_fp32", "vm_asr_48k_MPD", 0, "fp32", False),
                                          ("with_metrics", "vm_asr_48k_MPD", 0, args.mpd_gemm, True),
                                          ("vm_asr_48k_16k_MPD_VSSM32", "vm_asr_48k_16k_MPD_VSSM32", 0, args.mpd_gemm, False),
+                                         ("vm_asr_48k_generator_only", "vm_asr_48k", 0, args.mpd_gemm, False),
                                          ("vm_asr_48k_16k_nfft2048", "vm_asr_48k_16k_nfft2048", 0, args.mpd_gemm, False),
                                          ("vm_asr_48k_16k_MPD_VSSM32_dstate32_nfft2048", "vm_asr_48k_16k_MPD_VSSM32_dstate32_nfft2048", 0,
                                           args.mpd_gemm, False)):
