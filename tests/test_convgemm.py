@@ -168,3 +168,57 @@ def test_conv_mfma_cu_limit_changes_nothing_but_the_grid():
         assert int(cg._lib.lib().vmasr_conv_get_cu_limit()) == 0 and cg._LIMIT["cus"] == 0
         for a, b in zip(ref, got):
             assert torch.equal(a, b), cus
+
+
+@gpu
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] % 128 == 0])
+def test_conv_mfma_dgrad_with_the_activation_backward_in_its_epilogue(case):
+    """vmasr_conv_mfma_dgrad_gelu == vmasr_conv_mfma_dgrad -> vmasr_masked_l1_bwd_add -> vmasr_gelu_bwd_split / vmasr_gelu_bwd, the three
+    passes it replaces (the reference's autograd: conv backward, + the feature-matching gradient, GELU backward): BIT-EXACT — the same fp32
+    tile, the same fused multiply-add of the sign term, the same GELU' expression, the same split; with and without the sign term, fp32
+    output and pair."""
+    import ctypes
+    from vm_asr_amd import _lib, convgemm as cg
+    from vm_asr_amd.discriminator import split_bf16
+    Cin, Cout, k, stride, pad, geom = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = len(geom)
+    H1 = [cg.out_positions(H, k, stride, pad) for _, H in geom]
+    Ms = [ns * h1 for (ns, _), h1 in zip(geom, H1)]
+    rows_in = -(-max(ns * H for ns, H in geom) // 256) * 256 + 256
+    rows_out = -(-max(Ms) // 256) * 256
+    W = (torch.randn(n, Cout, k * Cin, generator=g) / (k * Cin) ** 0.5).to(dev)
+    Wt = W.view(n, Cout, k, Cin).permute(0, 3, 2, 1).reshape(n, Cin, k * Cout).contiguous()
+    wth, wtl = split_bf16(Wt)
+    gh, gl = split_bf16(_stack([torch.randn(M, Cout, generator=g).to(dev) for M in Ms], rows_out))
+    pre = (2.0 * torch.randn(n, rows_in, Cin, generator=g)).to(dev)
+    sgn = torch.randint(-1, 2, (n, rows_in, Cin), generator=g, dtype=torch.int8).to(dev)
+    gtok = torch.tensor([0.37], device=dev)
+    valid = [max(ns * H - 5 * i, 0) for i, (ns, H) in enumerate(geom)]
+    scale = [0.5 + 0.25 * i for i in range(n)]
+    lib = _lib.lib()
+    dx = cg.conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, rows_in)
+    for with_sgn in (False, True):
+        t = dx
+        if with_sgn:
+            t = torch.empty_like(dx)
+            v = (ctypes.c_int64 * n)(*valid)
+            sc = (ctypes.c_float * n)(*scale)
+            _lib.check(lib.vmasr_masked_l1_bwd_add(sgn.data_ptr(), gtok.data_ptr(), dx.data_ptr(), t.data_ptr(), v, sc, n, rows_in, Cin,
+                                                   _lib.current_stream(dev)), "masked_l1_bwd_add")
+        rh, rl, r32 = torch.empty_like(gh[:, :0]).new_empty((n, rows_in, Cin)), None, torch.empty_like(t)
+        rl = torch.empty_like(rh)
+        _lib.check(lib.vmasr_gelu_bwd_split(pre.data_ptr(), t.data_ptr(), rh.data_ptr(), rl.data_ptr(), None, None, n, rows_in, Cin,
+                                            _lib.current_stream(dev)), "gelu_bwd_split")
+        _lib.check(lib.vmasr_gelu_bwd(pre.data_ptr(), t.data_ptr(), r32.data_ptr(), None, n, rows_in, Cin, _lib.current_stream(dev)), "gelu_bwd")
+        kw = dict(sgn=sgn, gtok=gtok, scale=scale, valid=valid) if with_sgn else {}
+        g32, pair = cg.conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, pre, want_f32=True, want_pair=True, **kw)
+        assert torch.equal(g32, r32), (with_sgn, (g32 - r32).abs().max().item())
+        assert torch.equal(pair[0], rh) and torch.equal(pair[1], rl), with_sgn
+        g32b, pairb = cg.conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, pre, want_f32=False, want_pair=True, **kw)
+        assert g32b is None and torch.equal(pairb[0], rh) and torch.equal(pairb[1], rl)
+        g32c, pairc = cg.conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, pre, want_f32=True, want_pair=False, **kw)
+        assert pairc is None and torch.equal(g32c, r32)
+        for i, (ns, H) in enumerate(geom):
+            assert not g32[i, ns * H:].any() and not pair[0][i, ns * H:].any(), "rows below the slot's data must be zero"

@@ -227,6 +227,49 @@ def test_feature_loss_stacked_matches_per_map_loss():
     assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-6 * grads[1].abs().max().item() + 1e-9)
 
 
+@pytest.mark.gpu
+def test_generator_phase_chain_with_the_activation_backward_in_the_dgrad_epilogue(monkeypatch):
+    """The generator-loss pass through the discriminator (hidden 32: the 128 -> 512 -> 1024 -> 1024 layers on the MFMA kernels): with
+    the stacked feature-matching loss, the input gradient of a layer finishes the layer below's activation backward — GELU', the loss'
+    sign term and the bf16 split — in its epilogue (vmasr_conv_mfma_dgrad_gelu) instead of two more passes over the map.  Same loss,
+    same d(loss)/d(signal) as the unfused chain (the arithmetic per element is identical; the 32-channel layers' atomics differ in
+    order), the fused launch really runs (twice per pass: 1024 -> 1024 over 512 -> 1024, 512 -> 1024 over 128 -> 512), and the
+    per-map loss — whose maps have a second consumer — never takes the fused path."""
+    from vm_asr_amd import convgemm as cg
+    from vm_asr_amd.discriminator import MultiPeriodDiscriminator, StackedFeatures
+    from vm_asr_amd.loss import HiFiGANLoss
+    torch.manual_seed(3)
+    D = MultiPeriodDiscriminator(hidden=32).cuda().eval()
+    y = 0.3 * torch.randn(2, 1, 12000, device="cuda")
+    y_hat0 = 0.3 * torch.randn(2, 1, 12000, device="cuda")
+    L = HiFiGANLoss("lsgan")
+    calls = []
+    orig = cg.conv_dgrad_gelu
+    monkeypatch.setattr(cg, "conv_dgrad_gelu", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+
+    def run(fuse, stacked=True):
+        monkeypatch.setenv("VMASR_MPD_FUSE_GELU_BWD", fuse)
+        y_hat = y_hat0.clone().requires_grad_()
+        with torch.no_grad():
+            _, real = D.forward_single(y)
+        scores, gen = D.forward_single(y_hat, detach_weights=True)
+        assert isinstance(real, StackedFeatures) and isinstance(gen, StackedFeatures)
+        if not stacked:
+            real, gen = [list(f) for f in real], [list(f) for f in gen]
+        loss = 2.0 * L.feature_loss(real, gen) + sum((1.0 - s).pow(2).mean() for s in scores)
+        calls.clear()
+        loss.backward()
+        return loss.item(), y_hat.grad.clone(), len(calls)
+    l0, g0, c0 = run("0")
+    l1, g1, c1 = run("1")
+    assert c0 == 0 and c1 == 2, (c0, c1)
+    assert l0 == l1
+    sc = g0.abs().max().item()
+    assert torch.isfinite(g1).all() and (g1 - g0).abs().max().item() <= 2e-6 * sc, ((g1 - g0).abs().max().item(), sc)
+    l2, g2, c2 = run("1", stacked=False)
+    assert c2 == 0 and torch.isfinite(g2).all() and (g2 - g0).abs().max().item() <= 1e-4 * sc
+
+
 def test_batched_linear_and_unstack_host_logic():
     """Torch-level pieces of the batched discriminator pass, on CPU in fp64: the batched GEMM function (row-split
     weight gradient included) == einsum; the slot-unstacking function routes gradients to the right rows."""

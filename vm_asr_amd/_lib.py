@@ -54,6 +54,11 @@ class CgSlot(ctypes.Structure):
                 + [("nseq", c_i64), ("H", c_i32), ("reserved", c_i32)])
 
 
+class CgGeluBwd(ctypes.Structure):
+    """POD mirror of vmasr_cg_gelu_bwd (the activation backward fused into an input-gradient launch, csrc/convgemm.hip)."""
+    _fields_ = [("pre", c_vp), ("sgn", c_vp), ("valid", c_i64), ("scale", ctypes.c_float), ("reserved", c_i32)]
+
+
 class SS2DDeepParams(ctypes.Structure):
     """POD mirror of vmasr_ss2d_deep_params."""
     _fields_ = ([(n, c_i32) for n in ("B", "D", "H", "W", "R", "dtype")]
@@ -147,6 +152,8 @@ SYMBOLS = {
     "vmasr_conv_mfma_fwd": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_conv_mfma_dgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "vmasr_conv_mfma_wgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vmasr_conv_mfma_dgrad_gelu": (ctypes.c_int, [ctypes.POINTER(CgSlot), ctypes.POINTER(CgGeluBwd), c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                                  c_i32, c_i64, c_vp]),
     "vmasr_wgrad_finish_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "vmasr_linear_f64acc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "vmasr_ss2d_glue_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),

@@ -112,6 +112,41 @@ def conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, rows_in):
     return dx
 
 
+def conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, pre, want_f32=False, want_pair=True, sgn=None, gtok=None,
+                    scale=None, valid=None):
+    """conv_dgrad with the activation backward of the layer BELOW in the epilogue: g = (dx + gtok * scale_i * sgn) * GELU'(pre), where
+    pre (n, rows_in, Cin) fp32 is that layer's pre-activation and sgn (n, rows_in, Cin) int8 (optional) the sign map of its
+    feature-matching term (rows < valid_i of slot i; gtok a device scalar).  -> (g fp32 or None, (gh, gl) bf16 pair or None).
+    Replaces vmasr_masked_l1_bwd_add + vmasr_gelu_bwd_split over the feature map (csrc/convgemm.hip EPI 2)."""
+    _need(gh, gl, wth, wtl, pre, sgn, gtok)
+    n, rows_out, Cout = gh.shape
+    Cin = wth.shape[1]
+    dev = gh.device
+    assert pre.shape == (n, rows_in, Cin) and pre.dtype == torch.float32 and (want_f32 or want_pair)
+    assert sgn is None or (sgn.shape == pre.shape and sgn.dtype == torch.int8 and gtok is not None and gtok.dtype == torch.float32)
+    with torch.cuda.device(dev):
+        g32 = torch.empty((n, rows_in, Cin), dtype=torch.float32, device=dev) if want_f32 else None
+        oh = torch.empty((n, rows_in, Cin), dtype=torch.bfloat16, device=dev) if want_pair else None
+        ol = torch.empty_like(oh) if want_pair else None
+        sl = _slots(n)
+        ep = (_lib.CgGeluBwd * n)()
+        for i, (nseq, H) in enumerate(geom):
+            s = sl[i]
+            s.ah, s.al = _ptr(gh, i, rows_out * Cout * 2), _ptr(gl, i, rows_out * Cout * 2)
+            s.bh, s.bl = _ptr(wth, i, Cin * k * Cout * 2), _ptr(wtl, i, Cin * k * Cout * 2)
+            s.c0 = _ptr(g32, i, rows_in * Cin * 4)
+            s.ch, s.cl = _ptr(oh, i, rows_in * Cin * 2), _ptr(ol, i, rows_in * Cin * 2)
+            s.nseq, s.H = int(nseq), int(H)
+            ep[i].pre = _ptr(pre, i, rows_in * Cin * 4)
+            ep[i].sgn = _ptr(sgn, i, rows_in * Cin)
+            ep[i].valid = int(valid[i]) if (sgn is not None and valid is not None) else 0
+            ep[i].scale = float(scale[i]) if (sgn is not None and scale is not None) else 0.0
+        _apply_limit(Cin, Cout)
+        _lib.check(_lib.lib().vmasr_conv_mfma_dgrad_gelu(sl, ep, ctypes.c_void_p(gtok.data_ptr()) if sgn is not None else None, n, Cin, Cout,
+                                                         k, stride, pad, rows_in, _lib.current_stream(dev)), "conv_mfma_dgrad_gelu")
+    return g32, ((oh, ol) if want_pair else None)
+
+
 def wgrad_splits(n, Cin, Cout, k, M):
     """Split factor of the weight gradient's contraction (the M rows).  256 x 256 tiles (one workgroup per CU) when both channel counts
     allow: no split (200 / 400 tiles on the 512 -> 1024 / 1024 -> 1024 layers: a split would add a sum pass over 50-100 MB per slab for

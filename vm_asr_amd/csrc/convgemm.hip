@@ -60,6 +60,10 @@ struct CgProb {
     int ntaps, tap0, tap_step, dstep;
     int tile_start, mtiles;    // first tile of the problem in the launch's tile list; its number of 128-row tiles
     int zero_rows;             // rows m in [M, zero_rows) are written as zeros (padding rows of the stacked C)
+    // EPI 2 (input gradient with the activation's backward of the layer BELOW in the epilogue): `bias` holds that layer's
+    // pre-activation (rows of C), `c1` its feature-matching sign map (int8, may be null); see conv_mfma_nt_kernel
+    float fscale;              // weight of the sign term for this slot (times *CgParams::gtok)
+    int fvalid;                // C rows below this index carry the sign term
 };
 
 struct CgParams {
@@ -68,6 +72,7 @@ struct CgParams {
     int CA;                    // channels per tap on the A side (K extent per tap)
     int NB;                    // output columns
     int KB;                    // row length of B
+    const float *gtok;         // EPI 2: device scalar, the upstream gradient of the feature-matching loss term (may be null)
 };
 
 // LDS byte offset of 16-byte chunk `chunk` of row `row` (64-byte rows).  The chunk index is XOR-ed with f(row >> 2), f(g) = (-g) & 3:
@@ -77,6 +82,9 @@ __device__ __forceinline__ int cg_swz(const int row) { return (0 - (row >> 2)) &
 __device__ __forceinline__ int cg_off(const int row, const int chunk) { return row * 64 + ((chunk ^ cg_swz(row)) << 4); }
 
 __device__ __forceinline__ float cg_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float cg_gelu_grad(float x) {      // = gelu_grad_f of csrc/split.hip
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 
 __device__ __forceinline__ f32x16 cg_mfma(const bf16x8 a, const bf16x8 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -87,8 +95,14 @@ __device__ __forceinline__ f32x16 cg_mfma(const bf16x8 a, const bf16x8 b, const 
 // workgroup per CU — half the global -> LDS bytes and 3/4 of the LDS fragment reads per MFMA, and a K step lasts twice as long
 // (48 MFMAs per wave), which is what covers the latency of the next tile's DMA; used whenever the output width allows.
 // MF: MFMA shape, 32 = v_mfma_f32_32x32x16_bf16 (two K sub-steps of 16 per stage), 16 = v_mfma_f32_16x16x32_bf16 (one of 32).
-template <int BM, int BN, int WM, int WN, bool ACT, int MF>
+// EPI: what the epilogue does with the fp32 tile.  0: + bias -> c0.  1 (forward): + bias -> c0 (pre-activation), GELU -> c1 and the bf16 pair
+// ch / cl.  2 (input gradient of layer l + 1, finishing layer l's activation backward): t = tile (+ gtok fscale sign[row, col] for rows
+// < fvalid: the feature-matching term that autograd would add to this gradient), g = t GELU'(pre_l[row, col]) -> c0 (fp32, optional) and
+// the bf16 pair ch / cl (optional) — what gelu_bwd_split (csrc/split.hip) and masked_l1_bwd_add (csrc/featloss.hip) do in two more passes
+// over the map (r 4 + 5 + 8, w 4 + 4 + 4 bytes per element -> r 5, w 4).
+template <int BM, int BN, int WM, int WN, int EPI, int MF>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgParams P) {
+    constexpr bool ACT = EPI == 1;
     constexpr int NT = 64 * WM * WN;                   // threads
     constexpr int WTM = BM / WM, WTN = BN / WN;        // per-wave tile
     constexpr int TI = WTM / MF, TJ = WTN / MF;
@@ -260,7 +274,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
     constexpr int RPI = NT / C4;                       // rows per iteration of the store loop
     const int c4 = tid % C4;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pr.bias) bias4 = *reinterpret_cast<const float4 *>(pr.bias + n0 + 4 * c4);
+    float gs = 0.f;
+    if constexpr (EPI == 2) {
+        if (pr.c1 && P.gtok) gs = P.gtok[0] * pr.fscale;
+    } else {
+        if (pr.bias) bias4 = *reinterpret_cast<const float4 *>(pr.bias + n0 + 4 * c4);
+    }
 #pragma unroll 1
     for (int h = 0; h < BM / 128; ++h) {
         if (h > 0) __syncthreads();
@@ -289,6 +308,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
             float4 v = *reinterpret_cast<const float4 *>(ct + row * BN + 4 * c4);
             if (live) { v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w; }
             else v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (EPI == 2) {
+                if (live) {
+                    if (gs != 0.f && cr < pr.fvalid) {
+                        const char4 c = *reinterpret_cast<const char4 *>(reinterpret_cast<const signed char *>(pr.c1) + o);
+                        v.x = fmaf(gs, (float)c.x, v.x); v.y = fmaf(gs, (float)c.y, v.y); v.z = fmaf(gs, (float)c.z, v.z); v.w = fmaf(gs, (float)c.w, v.w);
+                    }
+                    const float4 p = *reinterpret_cast<const float4 *>(pr.bias + o);
+                    v.x *= cg_gelu_grad(p.x); v.y *= cg_gelu_grad(p.y); v.z *= cg_gelu_grad(p.z); v.w *= cg_gelu_grad(p.w);
+                }
+                if (pr.c0) *reinterpret_cast<float4 *>(pr.c0 + o) = v;
+                if (pr.ch) {
+                    union { uint2 raw; bf16_t e[4]; } hh, ll;
+                    const float yy[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hh.e[e] = (bf16_t)yy[e];
+                        ll.e[e] = (bf16_t)(yy[e] - (float)hh.e[e]);
+                    }
+                    *reinterpret_cast<uint2 *>(pr.ch + o) = hh.raw;
+                    *reinterpret_cast<uint2 *>(pr.cl + o) = ll.raw;
+                }
+                continue;
+            }
             *reinterpret_cast<float4 *>(pr.c0 + o) = v;
             if constexpr (ACT) {
                 float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -560,7 +602,7 @@ int cg_grid(int tiles, size_t smem) {
 }
 
 template <int BM, int BN, int WM, int WN, int MF>
-int cg_launch_cfg(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
+int cg_launch_cfg(CgParams &P, int epi, hipStream_t st, int kid, double bytes) {
     int tiles = 0;
     P.ntiles_n = P.NB / BN;
     for (int i = 0; i < P.nprob; ++i) {
@@ -571,34 +613,44 @@ int cg_launch_cfg(CgParams &P, bool act, hipStream_t st, int kid, double bytes) 
     P.total_tiles = tiles;
     if (tiles == 0) return 0;
     constexpr size_t smem = 2 * (2 * BM * 64 + 2 * BN * 64) + BM * sizeof(int);
+    constexpr bool HAS_EPI2 = BN >= 128;   // (the 32-wide tile only serves the 32 -> 128 layer's forward)
     static bool attr_done = false;
     if (!attr_done && smem > 65536) {      // > 64 KB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, true, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, false, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 1, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 0, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if constexpr (HAS_EPI2)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 2, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    if (act) {
-        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, true, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
+    if (epi == 1) {
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 1, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
+    } else if (epi == 2) {
+        if constexpr (HAS_EPI2) {
+            VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 2, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
+        } else {
+            set_error("conv_mfma: no fused activation backward for this tile");
+            return VMASR_EINVAL;
+        }
     } else {
-        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, false, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 0, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
     }
     return check_launch("conv_mfma");
 }
 
 // 256 x 256 tiles when the output width allows and there are enough of them to fill the chip; VMASR_CONV_TILE=128 forces the small tile
-int cg_launch(CgParams &P, bool act, hipStream_t st, int kid, double bytes) {
+int cg_launch(CgParams &P, int epi, hipStream_t st, int kid, double bytes) {
     static const int forced = [] { const char *e = getenv("VMASR_CONV_TILE"); return e ? atoi(e) : 0; }();
     // v_mfma_f32_16x16x32_bf16 by default: same cycles per FLOP as 32x32x16, but the chip holds a higher clock on it under load
     // (MI355X_MICROARCH.md, DVFS give-back item 7): 5-9 % less time on the 512 -> 1024 and 1024 -> 1024 layers, forward and dgrad
     // (profiles/r04_convgemm_microbench_v4.log); VMASR_CONV_MFMA=32 selects the 32x32x16 form
     static const int mf = [] { const char *e = getenv("VMASR_CONV_MFMA"); return e ? atoi(e) : 16; }();
     if (P.NB % 256 == 0 && forced != 128)
-        return mf == 16 ? cg_launch_cfg<256, 256, 2, 4, 16>(P, act, st, kid, bytes) : cg_launch_cfg<256, 256, 2, 4, 32>(P, act, st, kid, bytes);
+        return mf == 16 ? cg_launch_cfg<256, 256, 2, 4, 16>(P, epi, st, kid, bytes) : cg_launch_cfg<256, 256, 2, 4, 32>(P, epi, st, kid, bytes);
     // 256 x 128 (per wave 64 x 64): only for the 32-channel input side (K = 160: five K steps) — on the 128 -> 512 layer's dgrad it measured
     // SLOWER than 128 x 128 with two workgroups per CU (317 vs 279 us, profiles/r04_convgemm_microbench_v6_b4.log)
-    if (P.NB % 128 == 0 && P.CA == 32 && forced != 128) return cg_launch_cfg<256, 128, 4, 2, 16>(P, act, st, kid, bytes);
-    if (P.NB == 32) return cg_launch_cfg<256, 32, 8, 1, 16>(P, act, st, kid, bytes);                            // per wave 32 x 32 (the 32-channel side)
-    return mf == 16 ? cg_launch_cfg<128, 128, 2, 2, 16>(P, act, st, kid, bytes) : cg_launch_cfg<128, 128, 2, 2, 32>(P, act, st, kid, bytes);
+    if (P.NB % 128 == 0 && P.CA == 32 && forced != 128) return cg_launch_cfg<256, 128, 4, 2, 16>(P, epi, st, kid, bytes);
+    if (P.NB == 32) return cg_launch_cfg<256, 32, 8, 1, 16>(P, epi, st, kid, bytes);                            // per wave 32 x 32 (the 32-channel side)
+    return mf == 16 ? cg_launch_cfg<128, 128, 2, 2, 16>(P, epi, st, kid, bytes) : cg_launch_cfg<128, 128, 2, 2, 32>(P, epi, st, kid, bytes);
 }
 
 }  // namespace
@@ -649,31 +701,51 @@ VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int3
         p.zero_rows = (int)rows_out;
         bytes += (double)s.nseq * s.H * Cin * 4 + (double)Cout * k * Cin * 4 + (double)M * Cout * (act ? 12 : 4);
     }
-    return cg_launch(P, act != 0, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_FWD, bytes);
+    return cg_launch(P, act != 0 ? 1 : 0, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_FWD, bytes);
 }
 
-VMASR_EXPORT int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
-                                       int32_t pad, int64_t rows_in, vmasr_stream_t stream) {
-    VMASR_REQUIRE(slots && n >= 1 && n * (stride + 1) <= CG_MAXP, VMASR_EINVAL, "conv_mfma_dgrad: too many slots");
-    VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride), VMASR_EINVAL, "conv_mfma_dgrad: unsupported shape (Cin %d, Cout %d, k %d, stride %d)",
+namespace {
+
+// The input gradient's problems (one per slot and residue class of the stride, plus one zero-fill problem per slot).  epi: the fused
+// activation backward of the layer below (vmasr_conv_mfma_dgrad_gelu), or null.
+int cg_dgrad(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const float *gtok, int32_t n, int32_t Cin, int32_t Cout, int32_t k,
+             int32_t stride, int32_t pad, int64_t rows_in, vmasr_stream_t stream) {
+    const char *what = epi ? "conv_mfma_dgrad_gelu" : "conv_mfma_dgrad";
+    VMASR_REQUIRE(slots && n >= 1 && n * (stride + 1) <= CG_MAXP, VMASR_EINVAL, "%s: too many slots", what);
+    VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride), VMASR_EINVAL, "%s: unsupported shape (Cin %d, Cout %d, k %d, stride %d)", what,
                   Cin, Cout, k, stride);
+    VMASR_REQUIRE(!epi || Cin % 128 == 0, VMASR_EINVAL, "%s: the fused activation backward needs Cin %% 128 == 0", what);
     CgParams P = {};
     P.CA = Cout; P.NB = Cin; P.KB = k * Cout;
+    P.gtok = gtok;
     double bytes = 0;
     int np = 0;
     for (int i = 0; i < n; ++i) {
         const vmasr_cg_slot &s = slots[i];            // here: A = g (nseq * H1, Cout), B = W^T (Cin, k * Cout), c0 = dx (rows_in, Cin), H = H_in
-        VMASR_REQUIRE(s.ah && s.al && s.bh && s.bl && s.c0, VMASR_EINVAL, "conv_mfma_dgrad: null tensor in slot %d", i);
+        VMASR_REQUIRE(s.ah && s.al && s.bh && s.bl && (epi ? (s.c0 || (s.ch && s.cl)) && (!s.ch == !s.cl) : s.c0 != nullptr), VMASR_EINVAL,
+                      "%s: null tensor in slot %d", what, i);
+        VMASR_REQUIRE(!epi || (epi[i].pre && epi[i].valid >= 0 && (!epi[i].sgn || gtok)), VMASR_EINVAL,
+                      "%s: slot %d: pre-activation missing (or a sign map without the loss gradient)", what, i);
         const int64_t H = s.H, H1 = (H + 2 * pad - k) / stride + 1;
         VMASR_REQUIRE(H1 >= 1 && s.nseq * H <= rows_in && rows_in < (1LL << 31) / std::max(Cin, k * Cout), VMASR_EINVAL,
-                      "conv_mfma_dgrad: slot %d: %lld rows do not fit rows_in %lld (or 32-bit offsets)", i, (long long)(s.nseq * H), (long long)rows_in);
+                      "%s: slot %d: %lld rows do not fit rows_in %lld (or 32-bit offsets)", what, i, (long long)(s.nseq * H), (long long)rows_in);
+        auto outputs = [&](CgProb &p) {
+            p.c0 = s.c0; p.c1 = nullptr; p.ch = nullptr; p.cl = nullptr; p.bias = nullptr;
+            if (epi) {
+                p.ch = (bf16_t *)s.ch; p.cl = (bf16_t *)s.cl;
+                p.bias = epi[i].pre;
+                p.c1 = reinterpret_cast<float *>(const_cast<signed char *>(epi[i].sgn));
+                p.fscale = epi[i].scale;
+                p.fvalid = (int)std::min<int64_t>(epi[i].valid, rows_in);
+            }
+        };
         for (int r = 0; r < stride; ++r) {
             const int r0 = ((r - pad) % stride + stride) % stride;          // input positions h = stride q + r0 have (h + pad) % stride == r
             const int64_t Q = H > r0 ? (H - r0 + stride - 1) / stride : 0;
             if (Q == 0) continue;
             CgProb &p = P.prob[np++];
             p.ah = (const bf16_t *)s.ah; p.al = (const bf16_t *)s.al; p.bh = (const bf16_t *)s.bh; p.bl = (const bf16_t *)s.bl;
-            p.c0 = s.c0; p.c1 = nullptr; p.ch = nullptr; p.cl = nullptr; p.bias = nullptr;
+            outputs(p);
             p.M = (int)(s.nseq * Q); p.Q = (int)Q; p.HA = (int)H1; p.HC = (int)H;
             p.hq_mul = 1; p.hq_add = (r0 + pad - r) / stride;               // g position of tap t = r + stride j: q + hq_add - j
             p.crow_mul = stride; p.crow_add = r0;
@@ -684,16 +756,30 @@ VMASR_EXPORT int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, in
         if (s.nseq * H < rows_in) {                                         // zero rows below the slot's data: one pseudo sequence, no taps
             CgProb &p = P.prob[np++];
             p.ah = (const bf16_t *)s.ah; p.al = (const bf16_t *)s.al; p.bh = (const bf16_t *)s.bh; p.bl = (const bf16_t *)s.bl;
-            p.c0 = s.c0; p.c1 = nullptr; p.ch = nullptr; p.cl = nullptr; p.bias = nullptr;
+            outputs(p);
             p.M = (int)(rows_in - s.nseq * H); p.Q = p.M; p.HA = 1; p.HC = 0;
             p.hq_mul = 0; p.hq_add = 0; p.crow_mul = 1; p.crow_add = (int)(s.nseq * H);
             p.ntaps = 0; p.tap0 = 0; p.tap_step = 1; p.dstep = 0;
             p.zero_rows = 0;
         }
         bytes += (double)s.nseq * H1 * Cout * 4 + (double)Cout * k * Cin * 4 + (double)s.nseq * H * Cin * 4;
+        if (epi) bytes += (double)s.nseq * H * Cin * ((s.c0 && s.ch ? 4.0 : 0.0) + 4.0 + (epi[i].sgn ? 1.0 : 0.0));
     }
     P.nprob = np;
-    return cg_launch(P, false, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_DGRAD, bytes);
+    return cg_launch(P, epi ? 2 : 0, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_DGRAD, bytes);
+}
+
+}  // namespace
+
+VMASR_EXPORT int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
+                                       int32_t pad, int64_t rows_in, vmasr_stream_t stream) {
+    return cg_dgrad(slots, nullptr, nullptr, n, Cin, Cout, k, stride, pad, rows_in, stream);
+}
+
+VMASR_EXPORT int vmasr_conv_mfma_dgrad_gelu(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const float *gtok, int32_t n, int32_t Cin,
+                                            int32_t Cout, int32_t k, int32_t stride, int32_t pad, int64_t rows_in, vmasr_stream_t stream) {
+    VMASR_REQUIRE(epi, VMASR_EINVAL, "conv_mfma_dgrad_gelu: epi is required");
+    return cg_dgrad(slots, epi, gtok, n, Cin, Cout, k, stride, pad, rows_in, stream);
 }
 
 VMASR_EXPORT int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,

@@ -797,8 +797,12 @@ class _StackedConvMfmaFn(torch.autograd.Function):
     while the weights are frozen (the split / transposed-split operands of W are built once per step)."""
 
     @staticmethod
-    def forward(ctx, k, stride, pad, rows, geom, wcache, out_pair, weight, bias, x, xh, xl):
+    def forward(ctx, k, stride, pad, rows, geom, wcache, out_pair, weight, bias, x, xh, xl, link=None, below=None):
+        """link / below: plain dicts shared with the layer above / below (None: no fusion across this boundary).  The backward of the
+        layer ABOVE may finish this layer's activation backward in its input-gradient epilogue (csrc/convgemm.hip EPI 2) and leave the
+        result in link["stash"]; this layer's backward then starts from it (see _fuse_below)."""
         from . import convgemm as cg
+        x_req = x.requires_grad
         x = x.float().contiguous()
         if xh is None:
             xh, xl = split_bf16(x)
@@ -813,14 +817,44 @@ class _StackedConvMfmaFn(torch.autograd.Function):
         out_pair.append((yh, yl))
         ctx.save_for_backward(xh, xl, pre, w)
         ctx.meta = (k, stride, pad, tuple(geom), ops, weight.dtype, bias.dtype, x.shape)
+        ctx.link, ctx.below = link, below
+        if link is not None:
+            link.update(pre=pre, C=x.shape[2], x_req=x_req, w_req=weight.requires_grad, b_req=bias.requires_grad)
         return y
+
+    @staticmethod
+    def _fuse_below(ctx, gh, gl, wth, wtl, geom, k, stride, pad, rows_in, skip_w):
+        """Input gradient of this layer + the activation backward of the layer below in one launch, if that layer can start from it:
+        -> True (result left in below["stash"]; the caller returns a poisoned placeholder as dx) or False (nothing done).
+        Only where the layer below wants no bias gradient from this pass (the generator-loss phase: skip_weight_grads) — the column sums
+        are not part of the epilogue — and the feature-matching term of the map between the two layers (its _FeatTapFn) is at hand."""
+        from . import convgemm as cg
+        b = ctx.below
+        if b is None or "pre" not in b or os.environ.get("VMASR_MPD_FUSE_GELU_BWD", "1") != "1" or det_mode():
+            return False
+        if b["b_req"] and not skip_w:
+            return False
+        want_f32 = b["C"] < 128 and b["x_req"]
+        want_pair = (not want_f32 and b["x_req"]) or (b["w_req"] and not skip_w)
+        if not (want_f32 or want_pair):
+            return False
+        # only for a map whose feature-matching term went through the stacked loss (its tap holds the sign map AND the loss' backward
+        # has left the upstream gradient): then the map's only other consumer is the layer above, i.e. this function.  A map read by
+        # anything else as well (per-map losses on the unstacked views) would receive the poisoned placeholder in autograd's sum.
+        h = b.get("tap")
+        if h is None or h.get("sgn") is None or h.get("gtok") is None:
+            return False
+        kw = dict(sgn=h["sgn"], gtok=h["gtok"], scale=h["scale"], valid=h["valid"])
+        h["consumed"] = True
+        b["stash"] = cg.conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, b["pre"], want_f32=want_f32,
+                                        want_pair=want_pair, **kw)
+        return True
 
     @staticmethod
     def backward(ctx, gy):
         from . import convgemm as cg
         xh, xl, pre, w = ctx.saved_tensors
         k, stride, pad, geom, ops, wdt, bdt, xshape = ctx.meta
-        gy = gy.float().contiguous()
         n, M, N = gy.shape
         C = xshape[2]
         lib = _lib.lib()
@@ -832,15 +866,26 @@ class _StackedConvMfmaFn(torch.autograd.Function):
         fp32_dgrad = C < 128 and ctx.needs_input_grad[9]
         need_pair = (not fp32_dgrad and ctx.needs_input_grad[9]) or (ctx.needs_input_grad[7] and not skip_w)
         gh = gl = gx = None
+        stash = ctx.link.pop("stash", None) if ctx.link is not None else None
+        if stash is not None:      # the layer above has already applied GELU' (and the feature-matching term): gy is a placeholder
+            gx, pair_ = stash
+            gh, gl = pair_ if pair_ is not None else (None, None)
+            if want_db or (need_pair and gh is None) or (fp32_dgrad and gx is None):
+                raise RuntimeError("MPD: the fused activation backward left less than this layer's backward needs")
+            db32 = None
         with torch.cuda.device(gy.device):
-            db32, = _lib.zeros_f32(gy.device, (n, N) if want_db else None)
-            if need_pair:
+            if stash is None:
+                gy = gy.float().contiguous()
+                db32, = _lib.zeros_f32(gy.device, (n, N) if want_db else None)
+            if stash is not None:
+                pass
+            elif need_pair:
                 gh = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
                 gl = torch.empty((n, M, N), dtype=torch.bfloat16, device=gy.device)
                 _lib.check(lib.vmasr_gelu_bwd_split(pre.data_ptr(), gy.data_ptr(), gh.data_ptr(), gl.data_ptr(), None,
                                                     db32.data_ptr() if want_db else None, n, M, N, _lib.current_stream(gy.device)),
                            "gelu_bwd_split")
-            if fp32_dgrad:
+            if fp32_dgrad and stash is None:
                 gx = torch.empty_like(gy)
                 _lib.check(lib.vmasr_gelu_bwd(pre.data_ptr(), gy.data_ptr(), gx.data_ptr(),
                                               db32.data_ptr() if (want_db and not need_pair) else None, n, M, N,
@@ -857,13 +902,31 @@ class _StackedConvMfmaFn(torch.autograd.Function):
             if "wt" not in ops:      # (n, Cout, k, C) -> (n, C, k*Cout): the dgrad GEMM's B operand, (tap, output channel) order
                 ops["wt"] = split_bf16(w.view(n, N, k, C).permute(0, 3, 2, 1).reshape(n, C, k * N).contiguous())
             wth, wtl = ops["wt"]
-            dx = cg.conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, xshape[1])
+            if _StackedConvMfmaFn._fuse_below(ctx, gh, gl, wth, wtl, geom, k, stride, pad, xshape[1], skip_w):
+                dx = _poison(gy.device).expand(xshape)      # nobody may read it: the layer below starts from below["stash"]
+            else:
+                dx = cg.conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, xshape[1])
         if not skip_w:
             if ctx.needs_input_grad[7]:
                 dw = cg.conv_wgrad(gh, gl, xh, xl, geom, k, stride, pad).to(wdt)
             if want_db:
                 db = db32.to(bdt)
-        return (None, None, None, None, None, None, None, dw, db, dx, None, None)
+        return (None, None, None, None, None, None, None, dw, db, dx, None, None, None, None)
+
+
+_POISON = {}
+
+
+def _poison(device):
+    """A NaN scalar: expanded to the shape of a gradient that must not be read (its content travelled another way)."""
+    t = _POISON.get(device)
+    if t is None:
+        t = _POISON[device] = torch.full((), float("nan"), dtype=torch.float32, device=device)
+    return t
+
+
+def det_mode():
+    return os.environ.get("VMASR_DETERMINISTIC", "0") == "1"
 
 
 class _StackedConvFirstFn(torch.autograd.Function):
@@ -1021,6 +1084,9 @@ class _FeatTapFn(torch.autograd.Function):
         import ctypes
         h = ctx.holder
         sgn = h.get("sgn")          # (kept: with a shared discriminator pass the graph is walked once per loss phase)
+        h.pop("gtok", None)         # (left by the loss' backward for the layer above: _StackedConvMfmaFn._fuse_below)
+        if h.pop("consumed", False):    # the layer above has formed gy + g_loss * scale * sign (and GELU') in its epilogue
+            return gy, None
         if gtok is None or sgn is None:
             return gy, None
         valid, scale = h["valid"], h["scale"]
@@ -1063,6 +1129,7 @@ class _MaskedL1Fn(torch.autograd.Function):
                                                partials.data_ptr(), v, sc, n, real.shape[1], rows_g, N, _lib.current_stream(dev)), "masked_l1_fwd")
         ctx.meta = (valid, scale, gen.shape)
         ctx.tapped = tapped
+        ctx.holder = holder if tapped else None
         if tapped:
             holder.update(sgn=sgn, valid=valid, scale=scale)
         elif sgn is not None:
@@ -1073,6 +1140,9 @@ class _MaskedL1Fn(torch.autograd.Function):
     def backward(ctx, g):
         import ctypes
         if ctx.tapped:
+            # this node runs before the discriminator's layers (it was created after them); the layer above the tapped map folds
+            # g * scale * sign into its input-gradient epilogue when it finds the upstream gradient here (_fuse_below)
+            ctx.holder["gtok"] = g.detach().reshape(1).float().contiguous()
             return None, None, None, None, g.reshape(1), None
         (sgn,) = ctx.saved_tensors
         valid, scale, (n, rows_g, N) = ctx.meta
@@ -1204,7 +1274,7 @@ class MultiPeriodDiscriminator(nn.Module):
                 xp = F.pad(xp, (0, p - T % p), "reflect")
             cur.append(xp.view(B, 1, -1, p).permute(0, 3, 2, 1).to(cdt))          # (B, p, T/p, 1)
         fmaps, stacks, valid, taps = [[] for _ in discs], [], [], []
-        next_pair = None
+        next_pair = this_link = None
         for li in range(len(discs[0].layers) + 1):
             layers = [d.layers[li] if li < len(d.layers) else d.conv_post for d in discs]
             k, stride, pad = layers[0].kernel_size[0], layers[0].stride[0], layers[0].padding[0]
@@ -1236,6 +1306,7 @@ class MultiPeriodDiscriminator(nn.Module):
             # (slot i = B*p_i sequences of H_i positions) so that its gradient comes back stacked, in one launch
             sgeom, src = None, cur
             pair, next_pair = next_pair, None     # the bf16 (hi, lo) pair of stacks[-1], if the previous layer's epilogue wrote it
+            prev_link, this_link = this_link, None   # set by an MFMA layer: the layer above may finish its activation backward
             if stacks and stacks[-1].dtype == cdt and os.environ.get("VMASR_STACK_INPUT", "1") == "1":
                 sgeom, src = tuple((B * p, c.shape[2]) for c, p in zip(cur, P)), (stacks[-1],)
             if (not act and stacks and cdt == torch.float32 and k == 3 and stride == 1 and pad == 1 and W.shape[1] == 1
@@ -1265,8 +1336,10 @@ class MultiPeriodDiscriminator(nn.Module):
                     wcache = self._frozen.setdefault(("mfma_ops", li), {})
                 out_pair = []
                 xh, xl = pair if pair is not None else (None, None)
-                y = _StackedConvMfmaFn.apply(k, stride, pad, _round_up(max(Ms), 256), sgeom, wcache, out_pair, W, bstack, src[0], xh, xl)
-                next_pair = out_pair[0]
+                link = {}
+                y = _StackedConvMfmaFn.apply(k, stride, pad, _round_up(max(Ms), 256), sgeom, wcache, out_pair, W, bstack, src[0], xh, xl,
+                                             link, prev_link)
+                next_pair, this_link = out_pair[0], link
             elif _split_mode(W.shape[2], W.shape[1], cdt) and cur[0].shape[3] % 4 == 0:
                 y = _StackedConvSplitFn.apply(k, stride, pad, _round_up(max(Ms), 256), act, sgeom, W, bstack, *src)
             else:
@@ -1279,6 +1352,8 @@ class MultiPeriodDiscriminator(nn.Module):
                 holder = {}
                 y, token = _FeatTapFn.apply(y, holder)
                 tap = (token, holder)
+                if this_link is not None:
+                    this_link["tap"] = holder
             outs = _UnstackRowsFn.apply(y, *Ms)
             cur = [o.view(B, p, h, -1) for o, p, h in zip(outs, P, H1)]
             for f, c in zip(fmaps, cur):
