@@ -40,6 +40,8 @@ B=4 python tools/bench_ss2d.py > $O/ss2d_microbench.log 2>&1
 VMASR_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
     bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/bench_2proc_gloo.log 2>&1
 python tools/rccl_single_rank_probe.py 2>&1 | grep -v "amdgpu\|UserWarning\|return func" > $O/rccl_single_rank.log
+bash tools/gen_streams_ab.sh > $O/gen_streams_ab.log 2>&1
+(python tools/host_bound_probe.py; VMASR_GEN_STREAMS=2 python tools/host_bound_probe.py; python tools/host_bound_probe.py vm_asr_48k 4; VMASR_GEN_STREAMS=1 python tools/host_bound_probe.py vm_asr_48k 4) 2>&1 | grep -v "amdgpu\|Warning" > $O/host_bound_probe.log
 python tools/kcat.py $O/trainstep_kernel_stats.csv 49 14
 python tools/kcat.py $O/trainstep_onestream_kernel_stats.csv 49 14
 python tools/kcat.py $O/dstate32_kernel_stats.csv 9 14
