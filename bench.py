@@ -125,6 +125,9 @@ def cpu_baseline(config, budget_s=60.0):
             "spread": "one cold step: 0.037-0.094 clips/s between boxes of the pool (rounds 4-5)"}
 
 
+RUN_INFO = {}       # of the last run_point(): the captured step's generator stream count and, if both variants were captured, their times
+
+
 def run_point(config, args, device, rank, world, steps, warmup, timing, with_metrics=False):
     """Build the trainer for `config`, warm up, capture, time `steps` steps (barrier + synchronize on both sides, max over
     ranks) and — `timing` — run the same steps once more eagerly with the library's HIP-event timer on.
@@ -137,8 +140,12 @@ def run_point(config, args, device, rank, world, steps, warmup, timing, with_met
     batch = synth_batch(config, device, rank)
 
     graphed = False
+    RUN_INFO.clear()
     if not args.no_graphs:
         graphed = trainer.enable_graphs(batch, warmup=max(2, min(3, warmup)))
+        from vm_asr_amd.trainer import unwrap
+        RUN_INFO.update(generator_streams=2 if getattr(unwrap(trainer.models["generator"]), "phase_lane", False) else 1,
+                        graph_variants_ms=getattr(trainer, "graph_variants", None))
         if not graphed:
             # never report the host-bound eager step (2x slower) as if it were the product's number: fail loudly
             print(json.dumps({"error": "HIP graph capture / replay self-test failed; rerun with --no-graphs to measure the eager step",
@@ -317,7 +324,7 @@ def extra_point(name, workload, batch, mpd_gemm, args, device, rank, world, step
     rec = {"workload": f"{workload}.yaml, per-GPU batch {B}, DIMS {cfg.MODEL.VSSM.DIMS}, d_state {cfg.MODEL.VSSM.SSM_D_STATE}, "
                        f"n_fft {cfg.DATA.STFT.N_FFT}, MPD GEMMs {mpd_gemm}" + (", SNR/LSD/LSD-HF/LSD-LF evaluated and read every step" if with_metrics else ""),
            "value": B * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "batch": B,
-           "execution": "HIP graph replay" if graphed else "eager"}
+           "execution": "HIP graph replay" if graphed else "eager", **RUN_INFO}
     if tried:
         rec["out_of_memory_at_batch"] = tried
     shared_prof = prof if "__unshared__" in prof and any(not k.startswith("__") for k in prof) else None
@@ -489,6 +496,7 @@ def main():
     dinfo = distributed_info(device)
     dt, graphed, per_rank, prof = run_point(config, args, device, rank, world, args.steps, args.warmup, not args.no_kernel_timing,
                                             with_metrics=args.with_metrics)
+    main_info = dict(RUN_INFO)
     timing = prof is not None
 
     B = config.DATA.BATCH_SIZE
@@ -522,6 +530,8 @@ def main():
                                       ("HIP graph replay, node by node (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; forward + D-backward graph, G-backward graph, "
                                        "optimiser graph)")) if graphed else ("eager, two streams" if two_stream else "eager")},
     }
+    out["config"]["generator_streams"] = main_info.get("generator_streams")      # (trainer.enable_graphs: the faster of the two captures)
+    out["config"]["graph_variants_ms_note"] = main_info.get("graph_variants_ms")
     out["distributed"] = dinfo     # what the process group actually was: world size, backend, RCCL version, every rank's device
     out["config"]["per_step_metrics"] = bool(args.with_metrics)
     if per_rank is not None:

@@ -782,6 +782,45 @@ def test_generator_only_graph_with_the_phase_lane_matches_eager():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lane", [False, True])
+def test_gan_step_capture_keeps_the_faster_generator_layout(lane, monkeypatch):
+    """GAN step on two streams: enable_graphs() captures the step with the generator on one stream AND with its phase branch on a second
+    one, times both, and keeps the faster — always as the LAST capture (an earlier capture's graphs point into buffers the next capture's
+    warm-up re-creates: replaying it faulted).  Both outcomes forced here: the kept step replays without fault and trains like the eager
+    step from the same state (first new batch tight, then drifting by AdamW's normalised updates as in the tests above)."""
+    import bench
+    from vm_asr_amd.trainer import Trainer, unwrap
+    cfg = bench.make_config("vm_asr_48k_MPD", 2)
+    cfg.defrost()
+    cfg.MODEL.VSSM.DROP_PATH_RATE = 0.0
+    cfg.freeze()
+    dev = torch.device("cuda", 0)
+    batches = [bench.synth_batch(cfg, dev, s) for s in range(3)]
+    monkeypatch.setattr(Trainer, "_prefer_phase_lane", staticmethod(lambda a, b: lane))
+    logs = {}
+    for mode in ("eager", "graph"):
+        tr = bench.build_trainer(cfg, dev, amp=True, capturable=True)
+        for m in tr.models.values():
+            m.train()
+        tr.train_step(*batches[0])
+        if mode == "graph":
+            assert tr.enable_graphs(batches[0], warmup=2)
+            assert set(tr.graph_variants) == {"one_generator_stream_ms", "phase_lane_ms"}
+            assert unwrap(tr.models["generator"]).phase_lane == lane
+        out = []
+        for b in batches[1:]:
+            _, lg = tr.train_step(*b)
+            out.append({k: float(v) for k, v in lg.items()})
+        torch.cuda.synchronize()
+        logs[mode] = out
+        del tr
+        torch.cuda.empty_cache()
+    for i, (a, b) in enumerate(zip(logs["eager"], logs["graph"])):
+        for k in a:
+            assert abs(a[k] - b[k]) <= (5e-3 if i == 0 else 5e-2) * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+
+
+@pytest.mark.gpu
 def test_two_stream_step_at_batch_35_finishes():
     """Regression: with hipBLASLt's stream-K GEMMs (every gfx950 kernel of this stack is one) the two-stream step stopped the device
     for good at batch 35 — two concurrent GEMMs waiting for each other's partial tiles (vm_asr_amd/hip_env.py,

@@ -907,6 +907,13 @@ class Trainer(BaseTrainer):
                 handed = torch.cuda.Event()
                 handed.record(side)
                 self._mark("g_dgrad_end", side)
+                # A dependency on the main stream that costs nothing (everything main has issued so far — the generator's forward, the
+                # waveform losses — ended before the discriminator's forward did) but places the D loss' backward BEHIND the generator's
+                # forward in the captured graph's topology.  The runtime maps the branches of an instantiated graph to its own streams by
+                # that topology: without the edge, the generator's phase branch (model._lanes) shares a hardware queue with this
+                # stream's long kernels in the backward and waits behind them (profiles/r05_lane_trace_gen2.log: 147 clips/s);
+                # with it the discriminator keeps a queue to itself (r05_lane_trace_gen2_edge.log: 186).
+                side.wait_stream(main)
                 if zero:
                     self._zero_grads("mpd", self.optimizer_D)
                 with self._side_cus():                                            # (beside the generator's backward)
@@ -1151,8 +1158,20 @@ class Trainer(BaseTrainer):
         multi = self.world > 1 and dist.is_initialized()
         if multi:
             dist.barrier()          # every rank has built its models / communicator before anybody starts capturing
-        # generator-only steps: the phase branch of the generator on a second stream inside the captured step (model._lanes)
-        unwrap(self.models["generator"]).phase_lane = not self.gan
+        # The generator's phase branch on a second stream inside the captured step (model._lanes; VMASR_GEN_STREAMS=1 / 2 forces it off /
+        # on).  Generator-only steps: always (+14 ... +24 % at batch 35 ... 4).  GAN step on two streams: it depends on how much of the chip
+        # the generator's kernels fill by themselves (batch 2: +17 %, batch 4: +6 %, DIMS 32 / n_fft 2048 at batch 8: +8 %; batch 8: -1 %,
+        # batch 35: -3 %: profiles/r05_gen_streams_ab.log) — so both variants are captured, replayed a few times, and the faster one stays.
+        gen = unwrap(self.models["generator"])
+        mode = os.environ.get("VMASR_GEN_STREAMS", "auto")
+        lanes_possible = (getattr(gen, "interact", "single") != "single" and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"
+                          and mode in ("auto", "2"))
+        if not lanes_possible:
+            candidates = [False]
+        elif not self.gan or mode == "2":
+            candidates = [True]
+        else:
+            candidates = [False, True] if self._two_streams() else [False]
         def attempt():
             try:
                 self._graphed = GraphedTrainStep(self, example_batch, warmup)
@@ -1172,6 +1191,22 @@ class Trainer(BaseTrainer):
                     self._graphed, ok = None, False
                     self.graph_error = "graph capture failed on another rank"
             return ok
+        def timed_replays(n=6):
+            """ms per replayed step of the current capture (real optimiser steps on the example batch: undone below with the warm-up's)"""
+            for _ in range(2):
+                self._graphed(*example_batch)
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                self._graphed(*example_batch)
+            torch.cuda.synchronize(self.device)
+            t = torch.tensor([1e3 * (time.perf_counter() - t0) / n], dtype=torch.float64,
+                             device=torch.device("cpu") if not multi or dist.get_backend() == "gloo" else self.device)
+            if multi:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision: the slowest rank's time
+            return float(t.item())
+
+        gen.phase_lane = candidates[0]
         ok = attempt()
         if (not ok and multi and dist.get_backend() == "nccl" and os.environ.get("VMASR_GRAPH_COLLECTIVES", "1") == "1"):
             # the gradient all-reduces are captured into the step's graph by default (graph_step.py): if that capture fails on any
@@ -1180,12 +1215,36 @@ class Trainer(BaseTrainer):
             os.environ["VMASR_GRAPH_COLLECTIVES"] = "0"
             torch.cuda.synchronize(self.device)
             ok = attempt()
+        self.graph_variants = None
+        if ok and len(candidates) > 1:
+            # second variant: the phase lane on.  Only the LAST capture is replayed afterwards (a capture's warm-up steps re-create
+            # the flat gradient buffers the previous capture's graphs point into), so if the first variant wins it is captured again.
+            t_first = timed_replays()
+            self._graphed = None
+            gen.phase_lane = candidates[1]
+            if attempt():
+                t_second = timed_replays()
+                self.graph_variants = {"one_generator_stream_ms": round(t_first, 3), "phase_lane_ms": round(t_second, 3)}
+                lane_on = self._prefer_phase_lane(t_first, t_second)
+                self.logger.info(f"captured step: {self.graph_variants} -> phase lane {'on' if lane_on else 'off'}")
+                if not lane_on:
+                    self._graphed = None
+                    gen.phase_lane = candidates[0]
+                    ok = attempt()
+            else:                   # the second capture failed: back to the first variant
+                gen.phase_lane, self.graph_error = candidates[0], None
+                ok = attempt()
+            torch.cuda.empty_cache()
         if not ok:
             self.logger.warning("running eagerly")
         if snap is not None:
             torch.cuda.synchronize(self.device)
             self._restore_training_state(snap)
         return ok
+
+    @staticmethod
+    def _prefer_phase_lane(ms_one_stream, ms_phase_lane):
+        return ms_phase_lane < ms_one_stream
 
     def _to_dev(self, batch):
         wave_input, wave_target, highcut = batch[0], batch[1], batch[2]
