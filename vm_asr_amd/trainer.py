@@ -736,26 +736,33 @@ class Trainer(BaseTrainer):
             return False
         return True
 
-    def side_cu_limits(self):
+    def side_cu_limits(self, lanes=False):
         """(forward, backward) CU limits of the discriminator's convolution kernels while the two streams overlap, DERIVED from the
         device and the model instead of fixed numbers: the convolutions are compute-bound (time ~ 1 / CUs), the generator's small
         kernels are not, so the best split gives the side stream the share of the chip that balances the two phases' ends —
         3/8 of the CUs beside the generator's forward (D(real) has slack there: everything waits for the generator's output),
         5/8 beside its backward, 1/2 when the generator is the wide one (DIMS >= 32: its backward is 2x the work).  Measured flat in
         the batch (2, 4, 8) and within 1 % of the best point of every sweep: profiles/r05_side_cus_sweep_*.log (fwd 96 / bwd 160 of
-        256 CUs: 172.1 clips/s at batch 4, 198.5 at batch 8; DIMS 32: fwd 96 / bwd 128: 153.7).  Rounded to 8 CUs (one per XCD)."""
+        256 CUs: 172.1 clips/s at batch 4, 198.5 at batch 8; DIMS 32: fwd 96 / bwd 128: 153.7).  Rounded to 8 CUs (one per XCD).
+        lanes: the generator's phase branch runs on a stream of its own (captured steps, model._lanes): its backward then ends sooner,
+        and at a small per-GPU batch (<= 4) the discriminator's backward is the longer side — 3/4 of the CUs
+        (profiles/r05_side_cus_sweep_lanes.log: batch 4: 185.2 at 160, 193.0 at 192, 193.9 at 208, 184.7 at 240; batch 2: 139.1 / 143.2
+        at 160 / 192; n_fft 2048 at batch 8: 176.9 / 171.1 — stays at 5/8; DIMS 32: 170.5 at 128 and at 160 — stays at 1/2)."""
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         dims = self.config.MODEL.VSSM.DIMS
         dims = dims[0] if isinstance(dims, (list, tuple)) else dims
         r8 = lambda v: max(8, int(round(v / 8.0)) * 8)      # noqa: E731
-        return r8(cus * 3 / 8), r8(cus * (1 / 2 if dims >= 32 else 5 / 8))
+        bwd = 1 / 2 if dims >= 32 else (3 / 4 if lanes and self.config.DATA.BATCH_SIZE <= 4 else 5 / 8)
+        return r8(cus * 3 / 8), r8(cus * bwd)
 
     def _side_cus(self, forward=False):
         """-> context: CUs the discriminator's convolution kernels may take while the generator's kernels run beside them
         (side_cu_limits(); soft by 24: csrc/convgemm.hip cg_grid).  Overrides: VMASR_SIDE_CUS (backward, and forward unless
         VMASR_SIDE_CUS_FWD is given too), 0 = no limit; VMASR_SIDE_CUS_MINC: backward, only layers at least that wide."""
         from . import convgemm
-        fwd_auto, bwd_auto = self.side_cu_limits()
+        lanes = (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+                 and bool(getattr(unwrap(self.models["generator"]), "phase_lane", False)))
+        fwd_auto, bwd_auto = self.side_cu_limits(lanes)
         cus = os.environ.get("VMASR_SIDE_CUS", str(bwd_auto))
         if forward:
             cus = os.environ.get("VMASR_SIDE_CUS_FWD", str(fwd_auto) if "VMASR_SIDE_CUS" not in os.environ else cus)
