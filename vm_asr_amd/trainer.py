@@ -1177,6 +1177,8 @@ class Trainer(BaseTrainer):
             candidates = [False]
         elif not self.gan or mode == "2":
             candidates = [True]
+        elif multi and dist.get_backend() != "nccl":
+            candidates = [False]     # (gloo: the CPU-transport test mode, where ranks may share one GPU and its hardware queues)
         else:
             candidates = [False, True] if self._two_streams() else [False]
         def attempt():
