@@ -330,7 +330,8 @@ int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, in
  * per layer of model/discriminator.py:21-147, conv backward -> (+ the feature-matching term's gradient of model/loss.py) -> GELU backward;
  * vmasr_conv_mfma_dgrad + vmasr_masked_l1_bwd_add + vmasr_gelu_bwd_split are three passes over the feature map, this is one:
  *   t = dx tile (+ gtok[0] * epi[i].scale * sgn[row, col] for rows < epi[i].valid),   g = t * GELU'(pre[row, col])
- *   -> slots[i].c0 (fp32, may be NULL) and the bf16 pair slots[i].ch / cl (may be NULL; one of the two outputs is required).
+ *   -> slots[i].c0 (fp32, may be NULL) and the bf16 pair slots[i].ch / cl (may be NULL; one of the two outputs is required);
+ *   epi[i].db += column sums of g (fp32 atomics, one per column and tile — as vmasr_gelu_bwd_split does per workgroup).
  * slots as for vmasr_conv_mfma_dgrad (c1, bias unused); epi[i].pre (rows_in, Cin) fp32: layer l's pre-activation in slot i's stacked layout;
  * epi[i].sgn (rows_in, Cin) int8 or NULL: sign(generated - real) left by vmasr_masked_l1_fwd; gtok: DEVICE scalar, the loss term's upstream
  * gradient (required with a sign map).  Cin % 128 == 0. */
@@ -340,6 +341,7 @@ typedef struct vmasr_cg_gelu_bwd {
     int64_t valid;
     float scale;
     int32_t reserved;
+    float *db;                  /* (Cin) or NULL: the column sums of g are ADDED here (layer l's bias gradient; zero it first) */
 } vmasr_cg_gelu_bwd;
 int vmasr_conv_mfma_dgrad_gelu(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const float *gtok, int32_t n, int32_t Cin, int32_t Cout,
                                int32_t k, int32_t stride, int32_t pad, int64_t rows_in, vmasr_stream_t stream);

@@ -222,3 +222,13 @@ def test_conv_mfma_dgrad_with_the_activation_backward_in_its_epilogue(case):
         assert pairc is None and torch.equal(g32c, r32)
         for i, (ns, H) in enumerate(geom):
             assert not g32[i, ns * H:].any() and not pair[0][i, ns * H:].any(), "rows below the slot's data must be zero"
+        # the bias gradient's column sums from the same epilogue == gelu_bwd_split's (fp32 atomics in another order: 1e-5 of the scale)
+        db_ref = torch.zeros(n, Cin, device=dev)
+        _lib.check(lib.vmasr_gelu_bwd_split(pre.data_ptr(), t.data_ptr(), rh.data_ptr(), rl.data_ptr(), None, db_ref.data_ptr(), n, rows_in, Cin,
+                                            _lib.current_stream(dev)), "gelu_bwd_split")
+        db = torch.zeros(n, Cin, device=dev)
+        _, paird = cg.conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, pre, want_f32=False, want_pair=True, db=db, **kw)
+        assert torch.equal(paird[0], rh) and torch.equal(paird[1], rl)
+        want = r32.double().sum(1)
+        sc = want.abs().max().item()
+        assert (db.double() - want).abs().max().item() <= 1e-5 * sc and (db_ref.double() - want).abs().max().item() <= 1e-5 * sc

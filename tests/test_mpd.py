@@ -270,6 +270,44 @@ def test_generator_phase_chain_with_the_activation_backward_in_the_dgrad_epilogu
     assert c2 == 0 and torch.isfinite(g2).all() and (g2 - g0).abs().max().item() <= 1e-4 * sc
 
 
+@pytest.mark.gpu
+def test_discriminator_loss_chain_with_the_activation_backward_in_the_dgrad_epilogue(monkeypatch):
+    """The discriminator-loss pass (scores only; every weight and bias wants its gradient): inside `with scores_only():` the input gradient
+    of the 1024 -> 1024 and of the 512 -> 1024 layer finishes the layer below's activation backward in its epilogue, bias-gradient column sums
+    included.  Same gradients of every parameter as the unfused chain (atomics in another order: 2e-5 of each tensor's scale), two fused
+    launches per pass, none without the declaration."""
+    from vm_asr_amd import convgemm as cg
+    from vm_asr_amd.discriminator import MultiPeriodDiscriminator, scores_only
+    torch.manual_seed(4)
+    D = MultiPeriodDiscriminator(hidden=32).cuda().train()
+    x = 0.3 * torch.randn(2, 1, 12000, device="cuda")
+    calls = []
+    orig = cg.conv_dgrad_gelu
+    monkeypatch.setattr(cg, "conv_dgrad_gelu", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+
+    def run(declared):
+        D.zero_grad(set_to_none=True)
+        scores, _ = D.forward_single(x)
+        loss = sum((1.0 - s).pow(2).mean() for s in scores)
+        calls.clear()
+        if declared:
+            with scores_only():
+                loss.backward()
+        else:
+            loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in D.named_parameters() if p.grad is not None}, len(calls)
+    state = {k: v.clone() for k, v in D.state_dict().items()}
+    l0, g0, c0 = run(False)
+    D.load_state_dict(state)          # (the power iteration of the spectral norm advances per training-mode forward)
+    l1, g1, c1 = run(True)
+    assert c0 == 0 and c1 == 2, (c0, c1)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert g0.keys() == g1.keys() and len(g0) > 20
+    for k in g0:
+        sc = max(g0[k].abs().max().item(), 1e-12)
+        assert torch.isfinite(g1[k]).all() and (g1[k] - g0[k]).abs().max().item() <= 2e-5 * sc, (k, (g1[k] - g0[k]).abs().max().item(), sc)
+
+
 def test_batched_linear_and_unstack_host_logic():
     """Torch-level pieces of the batched discriminator pass, on CPU in fp64: the batched GEMM function (row-split
     weight gradient included) == einsum; the slot-unstacking function routes gradients to the right rows."""

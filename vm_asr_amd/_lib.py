@@ -56,7 +56,7 @@ class CgSlot(ctypes.Structure):
 
 class CgGeluBwd(ctypes.Structure):
     """POD mirror of vmasr_cg_gelu_bwd (the activation backward fused into an input-gradient launch, csrc/convgemm.hip)."""
-    _fields_ = [("pre", c_vp), ("sgn", c_vp), ("valid", c_i64), ("scale", ctypes.c_float), ("reserved", c_i32)]
+    _fields_ = [("pre", c_vp), ("sgn", c_vp), ("valid", c_i64), ("scale", ctypes.c_float), ("reserved", c_i32), ("db", c_vp)]
 
 
 class SS2DDeepParams(ctypes.Structure):

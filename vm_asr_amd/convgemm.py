@@ -113,12 +113,14 @@ def conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, rows_in):
 
 
 def conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, pre, want_f32=False, want_pair=True, sgn=None, gtok=None,
-                    scale=None, valid=None):
+                    scale=None, valid=None, db=None):
     """conv_dgrad with the activation backward of the layer BELOW in the epilogue: g = (dx + gtok * scale_i * sgn) * GELU'(pre), where
     pre (n, rows_in, Cin) fp32 is that layer's pre-activation and sgn (n, rows_in, Cin) int8 (optional) the sign map of its
     feature-matching term (rows < valid_i of slot i; gtok a device scalar).  -> (g fp32 or None, (gh, gl) bf16 pair or None).
+    db (n, Cin) fp32, zeroed by the caller: the column sums of g are added to it (the layer below's bias gradient).
     Replaces vmasr_masked_l1_bwd_add + vmasr_gelu_bwd_split over the feature map (csrc/convgemm.hip EPI 2)."""
-    _need(gh, gl, wth, wtl, pre, sgn, gtok)
+    _need(gh, gl, wth, wtl, pre, sgn, gtok, db)
+    assert db is None or (db.shape == (gh.shape[0], wth.shape[1]) and db.dtype == torch.float32)
     n, rows_out, Cout = gh.shape
     Cin = wth.shape[1]
     dev = gh.device
@@ -141,6 +143,7 @@ def conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, pre, want_f
             ep[i].sgn = _ptr(sgn, i, rows_in * Cin)
             ep[i].valid = int(valid[i]) if (sgn is not None and valid is not None) else 0
             ep[i].scale = float(scale[i]) if (sgn is not None and scale is not None) else 0.0
+            ep[i].db = _ptr(db, i, Cin * 4)
         _apply_limit(Cin, Cout)
         _lib.check(_lib.lib().vmasr_conv_mfma_dgrad_gelu(sl, ep, ctypes.c_void_p(gtok.data_ptr()) if sgn is not None else None, n, Cin, Cout,
                                                          k, stride, pad, rows_in, _lib.current_stream(dev)), "conv_mfma_dgrad_gelu")

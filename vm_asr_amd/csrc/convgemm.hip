@@ -44,7 +44,7 @@ __device__ uint4 cg_zero_page[4];   // 64 zero bytes: the DMA source of operand 
 constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32;
 constexpr int CG_TILE = CG_BM * CG_BK * 2;            // bytes of one operand tile (8 KB)
 constexpr int CG_STAGE = 4 * CG_TILE;                 // A_hi, A_lo, B_hi, B_lo
-constexpr int CG_MAXP = 24;                           // (slot, residue class) problems per launch
+constexpr int CG_MAXP = 24;                           // (slot, residue class) problems per launch (CgParams must stay under the 4 KB of kernel arguments)
 
 // One GEMM problem of a launch: C[crow(m), :] (+)= sum_j A[arow(m, j), :] . B[:, tap(j) CA + :]^T for m < M.
 struct CgProb {
@@ -64,6 +64,7 @@ struct CgProb {
     // pre-activation (rows of C), `c1` its feature-matching sign map (int8, may be null); see conv_mfma_nt_kernel
     float fscale;              // weight of the sign term for this slot (times *CgParams::gtok)
     int fvalid;                // C rows below this index carry the sign term
+    float *db;                 // EPI 2: (NB) column sums of g are ADDED here (the layer below's bias gradient), or null
 };
 
 struct CgParams {
@@ -74,6 +75,7 @@ struct CgParams {
     int KB;                    // row length of B
     const float *gtok;         // EPI 2: device scalar, the upstream gradient of the feature-matching loss term (may be null)
 };
+static_assert(sizeof(CgParams) <= 4096, "CgParams is passed by value as the kernel's argument block");
 
 // LDS byte offset of 16-byte chunk `chunk` of row `row` (64-byte rows).  The chunk index is XOR-ed with f(row >> 2), f(g) = (-g) & 3:
 // conflict-free for the ds_read_b128 lane groups of BOTH fragment shapes (32x32x16: 32 rows x one chunk per half wave; 16x16x32:
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
     constexpr int RPI = NT / C4;                       // rows per iteration of the store loop
     const int c4 = tid % C4;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);      // EPI 2: this thread's share of the column sums of g (its 4 columns, its rows)
     float gs = 0.f;
     if constexpr (EPI == 2) {
         if (pr.c1 && P.gtok) gs = P.gtok[0] * pr.fscale;
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
                     }
                     const float4 p = *reinterpret_cast<const float4 *>(pr.bias + o);
                     v.x *= cg_gelu_grad(p.x); v.y *= cg_gelu_grad(p.y); v.z *= cg_gelu_grad(p.z); v.w *= cg_gelu_grad(p.w);
+                    dbs.x += v.x; dbs.y += v.y; dbs.z += v.z; dbs.w += v.w;
                 }
                 if (pr.c0) *reinterpret_cast<float4 *>(pr.c0 + o) = v;
                 if (pr.ch) {
@@ -347,6 +351,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
                     *reinterpret_cast<uint2 *>(pr.ch + o) = hh.raw;
                     *reinterpret_cast<uint2 *>(pr.cl + o) = ll.raw;
                 }
+            }
+        }
+    }
+    if constexpr (EPI == 2) {
+        if (pr.db && pr.ntaps > 0) {                   // fold the RPI row groups in LDS, then ONE atomic per column and tile
+            __syncthreads();                           // (every thread has left the store loop: the fp32 tile can be overwritten)
+            *reinterpret_cast<float4 *>(ct + (tid / C4) * BN + 4 * c4) = dbs;
+            __syncthreads();
+            if (tid < BN) {
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < RPI; ++q) t += ct[q * BN + tid];
+                atomicAdd(pr.db + n0 + tid, t);
             }
         }
     }
@@ -737,6 +754,7 @@ int cg_dgrad(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const flo
                 p.c1 = reinterpret_cast<float *>(const_cast<signed char *>(epi[i].sgn));
                 p.fscale = epi[i].scale;
                 p.fvalid = (int)std::min<int64_t>(epi[i].valid, rows_in);
+                p.db = epi[i].db;
             }
         };
         for (int r = 0; r < stride; ++r) {

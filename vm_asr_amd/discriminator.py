@@ -459,7 +459,7 @@ class _StackedIm2ColFn(torch.autograd.Function):
 # Backward-phase switch of the trainer's shared fake pass: while the GENERATOR loss is back-propagated through
 # the discriminator's graph only the column / input gradients are wanted; the weight gradients belong to the
 # discriminator loss' own backward through the same graph.
-_PHASE = {"skip_weight_grads": False}
+_PHASE = {"skip_weight_grads": False, "scores_only": False}
 
 
 class skip_weight_grads:
@@ -468,6 +468,18 @@ class skip_weight_grads:
 
     def __exit__(self, *exc):
         _PHASE["skip_weight_grads"] = False
+
+
+class scores_only:
+    """with scores_only(): the loss being back-propagated reads the discriminator's SCORES only (the discriminator loss of
+    model/loss.py:190-213), no feature map: a map's only consumer is then the layer above it, which may finish the layer's activation
+    backward — GELU', bf16 split, bias-gradient column sums — in its input-gradient epilogue (_StackedConvMfmaFn._fuse_below)."""
+
+    def __enter__(self):
+        _PHASE["scores_only"] = True
+
+    def __exit__(self, *exc):
+        _PHASE["scores_only"] = False
 
 
 class _BatchedLinearFn(torch.autograd.Function):
@@ -826,26 +838,32 @@ class _StackedConvMfmaFn(torch.autograd.Function):
     def _fuse_below(ctx, gh, gl, wth, wtl, geom, k, stride, pad, rows_in, skip_w):
         """Input gradient of this layer + the activation backward of the layer below in one launch, if that layer can start from it:
         -> True (result left in below["stash"]; the caller returns a poisoned placeholder as dx) or False (nothing done).
-        Only where the layer below wants no bias gradient from this pass (the generator-loss phase: skip_weight_grads) — the column sums
-        are not part of the epilogue — and the feature-matching term of the map between the two layers (its _FeatTapFn) is at hand."""
+        The bias gradient's column sums and the feature-matching term of the map between the two layers are part of the epilogue."""
         from . import convgemm as cg
         b = ctx.below
         if b is None or "pre" not in b or os.environ.get("VMASR_MPD_FUSE_GELU_BWD", "1") != "1" or det_mode():
             return False
-        if b["b_req"] and not skip_w:
-            return False
+        want_db = b["b_req"] and not skip_w
         want_f32 = b["C"] < 128 and b["x_req"]
         want_pair = (not want_f32 and b["x_req"]) or (b["w_req"] and not skip_w)
         if not (want_f32 or want_pair):
             return False
-        # only for a map whose feature-matching term went through the stacked loss (its tap holds the sign map AND the loss' backward
-        # has left the upstream gradient): then the map's only other consumer is the layer above, i.e. this function.  A map read by
-        # anything else as well (per-map losses on the unstacked views) would receive the poisoned placeholder in autograd's sum.
+        # The map between the two layers must have no other consumer (it would receive the poisoned placeholder in autograd's sum):
+        # (a) the generator-loss pass with the stacked feature-matching loss — the map's tap holds the sign map AND the loss' backward has
+        #     left the upstream gradient: the term goes into the epilogue too; or
+        # (b) a pass the caller declared to read scores only (scores_only(): the discriminator loss) — no term, taps pass through.
         h = b.get("tap")
-        if h is None or h.get("sgn") is None or h.get("gtok") is None:
+        kw = {}
+        if h is not None and h.get("sgn") is not None and h.get("gtok") is not None:
+            kw = dict(sgn=h["sgn"], gtok=h["gtok"], scale=h["scale"], valid=h["valid"])
+            h["consumed"] = True
+        elif not _PHASE["scores_only"]:
             return False
-        kw = dict(sgn=h["sgn"], gtok=h["gtok"], scale=h["scale"], valid=h["valid"])
-        h["consumed"] = True
+        db32 = None
+        if want_db:
+            db32, = _lib.zeros_f32(gh.device, (gh.shape[0], wth.shape[1]))
+            kw["db"] = db32
+        b["stash_db"] = db32
         b["stash"] = cg.conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, b["pre"], want_f32=want_f32,
                                         want_pair=want_pair, **kw)
         return True
@@ -870,9 +888,9 @@ class _StackedConvMfmaFn(torch.autograd.Function):
         if stash is not None:      # the layer above has already applied GELU' (and the feature-matching term): gy is a placeholder
             gx, pair_ = stash
             gh, gl = pair_ if pair_ is not None else (None, None)
-            if want_db or (need_pair and gh is None) or (fp32_dgrad and gx is None):
+            db32 = ctx.link.pop("stash_db", None)
+            if (want_db and db32 is None) or (need_pair and gh is None) or (fp32_dgrad and gx is None):
                 raise RuntimeError("MPD: the fused activation backward left less than this layer's backward needs")
-            db32 = None
         with torch.cuda.device(gy.device):
             if stash is None:
                 gy = gy.float().contiguous()

@@ -903,7 +903,7 @@ class Trainer(BaseTrainer):
                          main: d/d(wave) + the waveform losses -> generator, packed        }
         then the main stream joins the side stream."""
         from . import layernorm
-        from .discriminator import skip_weight_grads
+        from .discriminator import scores_only, skip_weight_grads
         tw = st["two"]
         main, side = torch.cuda.current_stream(self.device), self._side_stream()
         try:
@@ -923,7 +923,7 @@ class Trainer(BaseTrainer):
                 side.wait_stream(main)
                 if zero:
                     self._zero_grads("mpd", self.optimizer_D)
-                with self._side_cus():                                            # (beside the generator's backward)
+                with self._side_cus(), scores_only():                             # (beside the generator's backward)
                     st["total_d"].backward(inputs=self._grad_targets("mpd"))
                 self._gather_grads("mpd")
                 self._mark("d_bwd_end", side)
