@@ -944,7 +944,9 @@ def _poison(device):
 
 
 def det_mode():
-    return os.environ.get("VMASR_DETERMINISTIC", "0") == "1"
+    """deterministic-reduction mode of the library (VMASR_DETERMINISTIC=1 / vmasr_set_deterministic): the fused epilogue's bias-gradient
+    atomics have no ordered form, so the unfused chain (gelu_bwd_split with its tickets) runs there"""
+    return os.environ.get("VMASR_DETERMINISTIC", "0") == "1" or bool(_lib.lib().vmasr_get_deterministic())
 
 
 class _StackedConvFirstFn(torch.autograd.Function):
