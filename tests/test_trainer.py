@@ -831,9 +831,12 @@ def test_two_stream_step_at_batch_35_finishes():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"
-    for extra in (["--batch", "35"], ["--workload", "vm_asr_48k", "--batch", "35"]):
+    # (GAN step: discriminator side stream + ONE generator stream — the layout that stalled, and one capture instead of three;
+    #  generator only: its phase lane, the other pair of streams that stalled)
+    for extra, streams in ((["--batch", "35"], "1"), (["--workload", "vm_asr_48k", "--batch", "35"], "auto")):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                            "--no-extra-points", "--no-kernel-timing"] + extra, capture_output=True, text=True, timeout=240, cwd=root)
+                            "--no-extra-points", "--no-kernel-timing"] + extra, capture_output=True, text=True, timeout=240, cwd=root,
+                           env={**os.environ, "VMASR_GEN_STREAMS": streams})
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line.get("value", 0) > 50, line
