@@ -378,6 +378,10 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
         dev = x.device
         if self.training and self._dp_pool is not None:
             self._dp_pool.refresh(2 * x.shape[0], dev)     # 2B: the shared decoders run both streams stacked
+            if x.is_cuda and torch.is_autocast_enabled():
+                # the table's 16-bit copy, made HERE on the main stream: created lazily by whichever branch asks first it would be
+                # written on one stream and read on the other without an edge between them (phase lane, _lanes below)
+                self._dp_pool.get(0, 1, 1, torch.get_autocast_gpu_dtype())
         if not single:
             ln = self._lanes(x)
             ln.to_side(phase)
