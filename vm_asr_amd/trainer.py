@@ -745,7 +745,7 @@ class Trainer(BaseTrainer):
         the batch (2, 4, 8) and within 1 % of the best point of every sweep: profiles/r05_side_cus_sweep_*.log (fwd 96 / bwd 160 of
         256 CUs: 172.1 clips/s at batch 4, 198.5 at batch 8; DIMS 32: fwd 96 / bwd 128: 153.7).  Rounded to 8 CUs (one per XCD).
         lanes: the generator's phase branch runs on a stream of its own (captured steps, model._lanes): its backward then ends sooner,
-        and at a small per-GPU batch (<= 4) the discriminator's backward is the longer side — 3/4 of the CUs
+        and the discriminator's backward can be the longer side — 5/8 or 3/4 of the CUs, whichever capture enable_graphs() times faster
         (profiles/r05_side_cus_sweep_lanes.log: batch 4: 185.2 at 160, 193.0 at 192, 193.9 at 208, 184.7 at 240; batch 2: 139.1 / 143.2
         at 160 / 192; n_fft 2048 at batch 8: 176.9 / 171.1 — stays at 5/8; DIMS 32: 170.5 at 128 and at 160 — stays at 1/2)."""
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
@@ -753,6 +753,9 @@ class Trainer(BaseTrainer):
         dims = dims[0] if isinstance(dims, (list, tuple)) else dims
         r8 = lambda v: max(8, int(round(v / 8.0)) * 8)      # noqa: E731
         bwd = 1 / 2 if dims >= 32 else (3 / 4 if lanes and self.config.DATA.BATCH_SIZE <= 4 else 5 / 8)
+        share = getattr(self, "_lane_bwd_share", None)       # enable_graphs(): the share the timed captures preferred
+        if lanes and share is not None:
+            bwd = share
         return r8(cus * 3 / 8), r8(cus * bwd)
 
     def _side_cus(self, forward=False):
@@ -1173,14 +1176,29 @@ class Trainer(BaseTrainer):
         mode = os.environ.get("VMASR_GEN_STREAMS", "auto")
         lanes_possible = (getattr(gen, "interact", "single") != "single" and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"
                           and mode in ("auto", "2"))
+        # a variant = (phase lane?, share of the CUs for the discriminator's backward beside the generator's; None: side_cu_limits()'s own)
+        dims = self.config.MODEL.VSSM.DIMS
+        dims = dims[0] if isinstance(dims, (list, tuple)) else dims
+        lane_variants = [(True, None)] if dims >= 32 else [(True, 5 / 8), (True, 3 / 4)]
         if not lanes_possible:
-            candidates = [False]
-        elif not self.gan or mode == "2":
-            candidates = [True]
+            candidates = [(False, None)]
+        elif not self.gan:
+            candidates = [(True, None)]
         elif multi and dist.get_backend() != "nccl":
-            candidates = [False]     # (gloo: the CPU-transport test mode, where ranks may share one GPU and its hardware queues)
+            candidates = [(False, None)]     # (gloo: the CPU-transport test mode, where ranks may share one GPU and its hardware queues)
+        elif not self._two_streams():
+            candidates = [(False, None)]
+        elif mode == "2":
+            candidates = lane_variants
         else:
-            candidates = [False, True] if self._two_streams() else [False]
+            candidates = [(False, None)] + lane_variants
+
+        def use(variant):
+            gen.phase_lane, self._lane_bwd_share = variant
+
+        def label(variant):
+            return "one_generator_stream_ms" if not variant[0] else ("phase_lane_ms" if variant[1] is None else f"phase_lane_d_bwd_{variant[1]:.3f}_ms")
+
         def attempt():
             try:
                 self._graphed = GraphedTrainStep(self, example_batch, warmup)
@@ -1215,7 +1233,7 @@ class Trainer(BaseTrainer):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision: the slowest rank's time
             return float(t.item())
 
-        gen.phase_lane = candidates[0]
+        use(candidates[0])
         ok = attempt()
         if (not ok and multi and dist.get_backend() == "nccl" and os.environ.get("VMASR_GRAPH_COLLECTIVES", "1") == "1"):
             # the gradient all-reduces are captured into the step's graph by default (graph_step.py): if that capture fails on any
@@ -1226,22 +1244,23 @@ class Trainer(BaseTrainer):
             ok = attempt()
         self.graph_variants = None
         if ok and len(candidates) > 1:
-            # second variant: the phase lane on.  Only the LAST capture is replayed afterwards (a capture's warm-up steps re-create
-            # the flat gradient buffers the previous capture's graphs point into), so if the first variant wins it is captured again.
-            t_first = timed_replays()
-            self._graphed = None
-            gen.phase_lane = candidates[1]
-            if attempt():
-                t_second = timed_replays()
-                self.graph_variants = {"one_generator_stream_ms": round(t_first, 3), "phase_lane_ms": round(t_second, 3)}
-                lane_on = self._prefer_phase_lane(t_first, t_second)
-                self.logger.info(f"captured step: {self.graph_variants} -> phase lane {'on' if lane_on else 'off'}")
-                if not lane_on:
-                    self._graphed = None
-                    gen.phase_lane = candidates[0]
-                    ok = attempt()
-            else:                   # the second capture failed: back to the first variant
-                gen.phase_lane, self.graph_error = candidates[0], None
+            # Every variant is captured and replayed a few times; the fastest stays.  Only the LAST capture is replayed afterwards (a
+            # capture's warm-up steps re-create the flat gradient buffers the previous capture's graphs point into), so unless the
+            # winner was captured last it is captured again.
+            times, last = {0: timed_replays()}, 0
+            for i in range(1, len(candidates)):
+                self._graphed = None
+                use(candidates[i])
+                if attempt():
+                    times[i], last = timed_replays(), i
+                else:
+                    self.graph_error = None
+            self.graph_variants = {label(candidates[i]): round(t, 3) for i, t in times.items()}
+            best = self._pick_variant([candidates[i] for i in times], [times[i] for i in times])
+            self.logger.info(f"captured step: {self.graph_variants} -> {label(best)[:-3]}")
+            use(best)
+            if best != candidates[last] or self._graphed is None:
+                self._graphed = None
                 ok = attempt()
             torch.cuda.empty_cache()
         if not ok:
@@ -1252,8 +1271,9 @@ class Trainer(BaseTrainer):
         return ok
 
     @staticmethod
-    def _prefer_phase_lane(ms_one_stream, ms_phase_lane):
-        return ms_phase_lane < ms_one_stream
+    def _pick_variant(variants, ms):
+        """the fastest of the captured step layouts (tests override it to force one)"""
+        return variants[min(range(len(ms)), key=lambda i: ms[i])]
 
     def _to_dev(self, batch):
         wave_input, wave_target, highcut = batch[0], batch[1], batch[2]
