@@ -1168,10 +1168,12 @@ class Trainer(BaseTrainer):
         multi = self.world > 1 and dist.is_initialized()
         if multi:
             dist.barrier()          # every rank has built its models / communicator before anybody starts capturing
-        # The generator's phase branch on a second stream inside the captured step (model._lanes; VMASR_GEN_STREAMS=1 / 2 forces it off /
-        # on).  Generator-only steps: always (+14 ... +24 % at batch 35 ... 4).  GAN step on two streams: it depends on how much of the chip
-        # the generator's kernels fill by themselves (batch 2: +17 %, batch 4: +6 %, DIMS 32 / n_fft 2048 at batch 8: +8 %; batch 8: -1 %,
-        # batch 35: -3 %: profiles/r05_gen_streams_ab.log) — so both variants are captured, replayed a few times, and the faster one stays.
+        # The generator's phase branch on a second stream inside the captured step (model._lanes; VMASR_GEN_STREAMS=1 / 2 restricts the
+        # choice).  Generator-only steps: always (+14 ... +24 % at batch 35 ... 4).  GAN step on two streams: whether it pays, and how many
+        # CUs the discriminator's backward should then keep, depends on the configuration (batch 4: 174 / 185 / 193 clips/s for one
+        # generator stream / lane with 5/8 / lane with 3/4 of the CUs; batch 8: 201 / 200 / 213; n_fft 2048 at batch 8: 161 / 177 / 171:
+        # profiles/r05_gen_streams_ab.log, r05_side_cus_sweep_lanes.log) — so the variants are captured, replayed a few times, and the
+        # fastest stays.
         gen = unwrap(self.models["generator"])
         mode = os.environ.get("VMASR_GEN_STREAMS", "auto")
         lanes_possible = (getattr(gen, "interact", "single") != "single" and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"
