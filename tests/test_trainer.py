@@ -1102,3 +1102,13 @@ def test_graph_warmup_leaves_the_training_state_untouched():
         _, le = ref.train_step(*batch)
         for k in le:
             assert abs(float(lg[k]) - float(le[k])) <= 2e-3 * max(1.0, abs(float(le[k]))), (presteps, k, float(lg[k]), float(le[k]))
+
+
+def test_pick_variant_takes_the_fastest_capture():
+    """host logic of Trainer.enable_graphs(): of the captured step layouts (generator on one stream; phase lane with 5/8 or 3/4 of the CUs
+    for the discriminator's backward) the one with the smallest replay time stays."""
+    from vm_asr_amd.trainer import Trainer
+    vs = [(False, None), (True, 5 / 8), (True, 3 / 4)]
+    assert Trainer._pick_variant(vs, [23.0, 21.7, 20.9]) == (True, 3 / 4)
+    assert Trainer._pick_variant(vs, [39.6, 40.2, 39.9]) == (False, None)
+    assert Trainer._pick_variant(vs[:1], [5.0]) == (False, None)
