@@ -501,7 +501,7 @@ def main():
 
     B = config.DATA.BATCH_SIZE
     two_stream = (config.TRAIN.ADVERSARIAL.ENABLE and os.environ.get("VMASR_TWO_STREAM", "1") == "1"
-                  and os.environ.get("VMASR_DETERMINISTIC", "0") != "1" and os.environ.get("VMASR_SHARE_FAKE_PASS", "1") == "1")
+                  and not _lib.det_mode() and os.environ.get("VMASR_SHARE_FAKE_PASS", "1") == "1")
     out = {
         "metric": "audio clips/sec (train step) 48kHz n_fft=1024", "value": world * B * args.steps / dt,
         "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -237,6 +237,19 @@ def torch_dtype_code(dt):
         raise RuntimeError(f"unsupported dtype {dt}: expected float32 / float16 / bfloat16")
 
 
+def det_mode():
+    """Deterministic-reduction mode is in force: VMASR_DETERMINISTIC=1 in the environment OR switched on through the library
+    (vmasr_set_deterministic: what the tests and embedding programs use).  Every stream-layout decision (trainer._two_streams,
+    model._lanes, enable_graphs' variants, bench.py's labels) asks HERE — the ordered-accumulation tickets are per kernel id, not
+    per stream (csrc/common.h), so the mode keeps the one-stream layout however it was switched on."""
+    if os.environ.get("VMASR_DETERMINISTIC", "0") == "1":
+        return True
+    try:
+        return bool(lib().vmasr_get_deterministic())
+    except (OSError, RuntimeError, AttributeError):
+        return False
+
+
 def current_stream(device):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

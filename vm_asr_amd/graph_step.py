@@ -11,9 +11,9 @@ Two-stream layout (default on the GPU: trainer._two_streams) — TWO graphs:
               captured graph run concurrently on replay (a graph launch as a whole serialises with every other stream: measured,
               tools/overlap_probe*.py), and nodes are enqueued in capture order — which is why _backward_two() issues the D loss'
               backward before the generator's.
-              world_size > 1 (RCCL): the MPD gradient's all-reduce (82 MB as bf16) is a THIRD branch, issued on the side stream right
-              behind the D loss' backward; the generator's (9 MB) follows its pack; both join at the end of the graph.
-              (VMASR_GRAPH_COLLECTIVES=0 or another backend: both all-reduces between graph A and graph B, fully exposed.)
+              world_size > 1: both all-reduces run between graph A and graph B on torch.distributed's communicator (default).
+              VMASR_GRAPH_COLLECTIVES=1 (RCCL, opt-in): the MPD gradient's all-reduce is a THIRD branch of graph A, issued on the side
+              stream right behind the D loss' backward; the generator's (9 MB) follows its pack; both join at the end of the graph.
     graph B   AdamW step for G and for D (capturable optimisers) + refresh of the bf16 shadow weights
 
 One-stream layout (VMASR_TWO_STREAM=0, deterministic mode, no shared fake pass) — three graphs:
@@ -115,13 +115,13 @@ class GraphedTrainStep:
             from .trainer import lr_to_device
             if any(torch.is_tensor(g["lr"]) and not g["lr"].is_cuda for g in opt.param_groups):
                 lr_to_device(opt, tr.device)      # a host lr would be frozen into graph B at capture
-        # world_size > 1 on RCCL: the gradient all-reduces are captured INTO graph A (branches of the same graph run concurrently on
-        # replay; a graph launch as a whole serialises with every other stream, so a collective issued between two replays is fully
-        # exposed: tools/overlap_probe*.py).  VMASR_GRAPH_COLLECTIVES=0 (or another backend): collectives between the graphs.
+        # world_size > 1 on RCCL with VMASR_GRAPH_COLLECTIVES=1: the gradient all-reduces are captured INTO graph A (branches of the same
+        # graph run concurrently on replay; a graph launch as a whole serialises with every other stream, so a collective issued between
+        # two replays is fully exposed: tools/overlap_probe*.py).  Default (or another backend): collectives between the graphs.
         import os
         import torch.distributed as dist
         self.collectives_in_graph = (tr.world > 1 and tr.dp_mode == "flat" and dist.is_initialized() and dist.get_backend() == "nccl"
-                                     and os.environ.get("VMASR_GRAPH_COLLECTIVES", "1") == "1"
+                                     and tr.graph_collectives()
                                      # (two-stream layout only: a collective forked in one capture cannot be joined in another,
                                      #  so the one-stream layout's A1 | all-reduce | A2 overlap stays between its graphs)
                                      and tr._two_streams())

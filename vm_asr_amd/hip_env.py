@@ -18,6 +18,29 @@ before, because whether the stream-K part of a kernel is used depends on the sha
 tile only (no cross-workgroup wait), which is also what the small GEMMs of this model want: the headline step is 1 % FASTER with it.
 trainer._two_streams() refuses the two-stream layout when the variable is not in force."""
 import os
+import sys
+
+
+def _gpu_untouched():
+    """No GEMM can have run yet: torch is not imported, or its GPU side is not initialised (hipBLASLt / Tensile read the variable when
+    they are first used — a value set after that is not known to be in force)."""
+    t = sys.modules.get("torch")
+    try:
+        return t is None or not t.cuda.is_initialized()
+    except Exception:      # noqa: BLE001  (a half-imported torch: be conservative)
+        return False
+
+
+# data-parallel (non stream-K) library GEMMs are known to be in force: the variable was already "1" when this module was imported, or
+# it is set HERE before the GPU was touched.  trainer._two_streams() / model._lanes() test THIS flag, not the raw variable: a
+# program that ran a GEMM first and imported vm_asr_amd later keeps the one-stream layout (two concurrent stream-K GEMMs can stop
+# the device for good: a hang is the failure mode, so the guard is conservative).
+STREAMK_DP_IN_FORCE = os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1" or (
+    "TENSILE_STREAMK_DATA_PARALLEL" not in os.environ and _gpu_untouched())
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")
+
+
+def streamk_dp_in_force():
+    return STREAMK_DP_IN_FORCE and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"

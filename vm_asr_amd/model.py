@@ -347,7 +347,9 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
         # the discriminator's side stream a third stream LOSES (173 -> 147 clips/s at batch 4: profiles/r05_gen_streams_ab.log), so
         # the GAN step keeps the generator on one stream.  "2" / "1" force it on / off.
         want = mode == "2" or (mode == "auto" and getattr(self, "phase_lane", False))
-        if (x.is_cuda and self.interact != "single" and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"
+        from . import _lib, hip_env
+        # (never in deterministic mode: both branches launch the same ticketed kernels — the tickets are per kernel id, one stream only)
+        if (x.is_cuda and self.interact != "single" and hip_env.streamk_dp_in_force() and not _lib.det_mode()
                 and (mode == "2eager" or (want and torch.cuda.is_current_stream_capturing()))):
             side = _PHASE_STREAMS.get(x.device)          # (not a module attribute: a Stream cannot be deep-copied with the model)
             if side is None:
@@ -378,10 +380,10 @@ class DualStreamInteractiveMambaUNet(MambaUNet):
         dev = x.device
         if self.training and self._dp_pool is not None:
             self._dp_pool.refresh(2 * x.shape[0], dev)     # 2B: the shared decoders run both streams stacked
-            if x.is_cuda and torch.is_autocast_enabled():
+            if x.is_cuda and torch.is_autocast_enabled("cuda"):
                 # the table's 16-bit copy, made HERE on the main stream: created lazily by whichever branch asks first it would be
                 # written on one stream and read on the other without an edge between them (phase lane, _lanes below)
-                self._dp_pool.get(0, 1, 1, torch.get_autocast_gpu_dtype())
+                self._dp_pool.get(0, 1, 1, torch.get_autocast_dtype("cuda"))
         if not single:
             ln = self._lanes(x)
             ln.to_side(phase)

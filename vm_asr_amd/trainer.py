@@ -624,12 +624,14 @@ class Trainer(BaseTrainer):
         torch._foreach_copy_(dst, src)
 
     def _comm_dtype(self, key):
-        """Wire dtype of `key`'s gradient all-reduce.  VMASR_GRAD_COMM: "fp32" | "bf16" | "auto" (default): the period
-        discriminator's 164 MB buffer travels as bf16 (82 MB; the fp32 flat buffer stays the optimiser's input, AdamW's moments and
-        the weights stay fp32 — DDP's bf16 compression hook), the generator's 9 MB as fp32.  RCCL only: gloo is the
-        CPU test backend."""
-        mode = os.environ.get("VMASR_GRAD_COMM", "auto")
-        if mode == "fp32" or self.device.type != "cuda" or dist.get_backend() != "nccl":
+        """Wire dtype of `key`'s gradient all-reduce.  VMASR_GRAD_COMM: "fp32" (default: what the reference's DDP sends, so N-rank and
+        1-rank training agree to fp32 rounding) | "mpd-bf16": the period discriminator's 164 MB buffer travels as bf16 (82 MB; the
+        fp32 flat buffer stays the optimiser's input, AdamW's moments and the weights stay fp32 — DDP's bf16 compression hook,
+        SURVEY.md 8(e)), the generator's 9 MB as fp32 | "bf16": both.  The 16-bit wire is a NUMERICS CHANGE (3e-4 ... 9e-4 on the
+        losses of one step) and is opt-in until a multi-GPU run has shown loss parity with the fp32 wire.  RCCL only: gloo is
+        the CPU test backend."""
+        mode = os.environ.get("VMASR_GRAD_COMM", "fp32")
+        if mode not in ("bf16", "mpd-bf16") or self.device.type != "cuda" or dist.get_backend() != "nccl":
             return torch.float32
         return torch.bfloat16 if (mode == "bf16" or key != "generator") else torch.float32
 
@@ -722,17 +724,21 @@ class Trainer(BaseTrainer):
         """The step on two HIP streams: the period discriminator's chip-filling MFMA kernels on a side stream,
         the generator's ~1400 small launches on the main one.  Needs the shared fake pass (GPU, flat gradient buffers);
         off in deterministic mode (the ordered-accumulation tickets are per kernel, not per stream)."""
-        if os.environ.get("VMASR_TWO_STREAM", "1") != "1" or os.environ.get("VMASR_DETERMINISTIC", "0") == "1":
+        from . import _lib, hip_env
+        mode = os.environ.get("VMASR_TWO_STREAM", "1")
+        # ("force": test hook — the EAGER two-stream step in deterministic mode: generator and discriminator share no ticketed kernel id,
+        #  so their ordered tails cannot meet; tests/test_determinism.py uses it to pin the stream layout's arithmetic bit for bit)
+        if mode not in ("1", "force") or (_lib.det_mode() and mode != "force"):     # (the mode switched on by env var OR through the library)
             return False
         if not self._share_fake_pass():
             return False
-        if os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") != "1":
+        if not hip_env.streamk_dp_in_force():
             # hipBLASLt's stream-K GEMMs of two concurrent streams can stop the device for good (vm_asr_amd/hip_env.py)
             if not getattr(self, "_warned_streamk", False):
                 self._warned_streamk = True
                 import warnings
-                warnings.warn("TENSILE_STREAMK_DATA_PARALLEL=1 is not set: the train step stays on one HIP stream "
-                              "(vm_asr_amd/hip_env.py sets it when the package is imported before the first GEMM)")
+                warnings.warn("TENSILE_STREAMK_DATA_PARALLEL=1 is not known to be in force: the train step stays on one HIP stream "
+                              "(vm_asr_amd/hip_env.py sets it when the package is imported before the GPU is initialised)")
             return False
         return True
 
@@ -752,7 +758,8 @@ class Trainer(BaseTrainer):
         dims = self.config.MODEL.VSSM.DIMS
         dims = dims[0] if isinstance(dims, (list, tuple)) else dims
         r8 = lambda v: max(8, int(round(v / 8.0)) * 8)      # noqa: E731
-        bwd = 1 / 2 if dims >= 32 else (3 / 4 if lanes and self.config.DATA.BATCH_SIZE <= 4 else 5 / 8)
+        batch = getattr(self, "_step_batch", None) or self.config.DATA.BATCH_SIZE    # (the batch actually built: enable_graphs() notes it)
+        bwd = 1 / 2 if dims >= 32 else (3 / 4 if lanes and batch <= 4 else 5 / 8)
         share = getattr(self, "_lane_bwd_share", None)       # enable_graphs(): the share the timed captures preferred
         if lanes and share is not None:
             bwd = share
@@ -1174,9 +1181,13 @@ class Trainer(BaseTrainer):
         # generator stream / lane with 5/8 / lane with 3/4 of the CUs; batch 8: 201 / 200 / 213; n_fft 2048 at batch 8: 161 / 177 / 171:
         # profiles/r05_gen_streams_ab.log, r05_side_cus_sweep_lanes.log) — so the variants are captured, replayed a few times, and the
         # fastest stays.
+        from . import _lib, hip_env
         gen = unwrap(self.models["generator"])
         mode = os.environ.get("VMASR_GEN_STREAMS", "auto")
-        lanes_possible = (getattr(gen, "interact", "single") != "single" and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"
+        self._step_batch = int(example_batch[0].shape[0])      # (not config.DATA.BATCH_SIZE: after a resume that is the checkpoint's)
+        # never in deterministic mode: both branches launch the same ticketed kernels (sscan, xproj, dwconv, mlp, ss2d_glue) and the
+        # ordered-accumulation tickets are per kernel id, ONE STREAM ONLY (csrc/common.h)
+        lanes_possible = (getattr(gen, "interact", "single") != "single" and hip_env.streamk_dp_in_force() and not _lib.det_mode()
                           and mode in ("auto", "2"))
         # a variant = (phase lane?, share of the CUs for the discriminator's backward beside the generator's; None: side_cu_limits()'s own)
         dims = self.config.MODEL.VSSM.DIMS
@@ -1194,6 +1205,15 @@ class Trainer(BaseTrainer):
             candidates = lane_variants
         else:
             candidates = [(False, None)] + lane_variants
+        # VMASR_STEP_VARIANT pins the layout (reproducible runs: the timed choice below rests on differences of 1-5 % and changes the
+        # order of the atomic additions): "one" | "lane" | "lane:<share of the CUs for the discriminator's backward>", e.g. lane:0.75
+        pin = os.environ.get("VMASR_STEP_VARIANT")
+        if pin and len(candidates) > 1:
+            want = (False, None) if pin == "one" else (True, float(pin.split(":", 1)[1]) if ":" in pin else None)
+            if want[0] and want[1] is None:
+                want = next((c for c in candidates if c[0]), want)
+            if want in candidates or (want[0] and lanes_possible):
+                candidates = [want]
 
         def use(variant):
             gen.phase_lane, self._lane_bwd_share = variant
@@ -1237,11 +1257,11 @@ class Trainer(BaseTrainer):
 
         use(candidates[0])
         ok = attempt()
-        if (not ok and multi and dist.get_backend() == "nccl" and os.environ.get("VMASR_GRAPH_COLLECTIVES", "1") == "1"):
-            # the gradient all-reduces are captured into the step's graph by default (graph_step.py): if that capture fails on any
-            # rank, every rank tries once more with the collectives BETWEEN the graphs (the round-4 layout) before giving graphs up
-            self.logger.warning("retrying the capture with the collectives between the graphs (VMASR_GRAPH_COLLECTIVES=0)")
-            os.environ["VMASR_GRAPH_COLLECTIVES"] = "0"
+        if (not ok and multi and dist.get_backend() == "nccl" and self.graph_collectives()):
+            # the gradient all-reduces were to be captured into the step's graph (VMASR_GRAPH_COLLECTIVES=1, graph_step.py): if that
+            # capture fails on any rank, every rank tries once more with the collectives BETWEEN the graphs before giving graphs up
+            self.logger.warning("retrying the capture with the collectives between the graphs")
+            self._graph_collectives = False          # (this trainer's choice: the process environment is left alone)
             torch.cuda.synchronize(self.device)
             ok = attempt()
         self.graph_variants = None
@@ -1271,6 +1291,13 @@ class Trainer(BaseTrainer):
             torch.cuda.synchronize(self.device)
             self._restore_training_state(snap)
         return ok
+
+    def graph_collectives(self):
+        """Capture the gradient all-reduces INTO the step's graph (RCCL's C API on a communicator of this trainer, vm_asr_amd/rccl.py)?
+        Opt-in (VMASR_GRAPH_COLLECTIVES=1): that path has no process-group watchdog behind it and has not run with more than one
+        real rank yet; the default keeps the collectives between the graphs on torch.distributed's communicator."""
+        own = getattr(self, "_graph_collectives", None)
+        return os.environ.get("VMASR_GRAPH_COLLECTIVES", "0") == "1" if own is None else bool(own)
 
     @staticmethod
     def _pick_variant(variants, ms):
