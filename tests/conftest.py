@@ -36,3 +36,10 @@ def pytest_collection_modifyitems(session, config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("VMASR_PARITY_TABLE")
+    if path:
+        import errtable
+        errtable.write(path)

@@ -30,6 +30,10 @@ def _close(got, want, rtol, atol, what=""):
     assert got.shape == want.shape, (what, got.shape, want.shape)
     assert np.isfinite(got).all(), f"{what}: non-finite values"
     excess = np.abs(got - want) - (atol + rtol * np.abs(want))
+    if got.size:
+        import errtable
+        w = int(np.argmax(np.abs(got - want)))
+        errtable.record(what, got, want, atol + rtol * float(np.abs(want).flat[w]))
     assert excess.max() <= 0, f"{what}: max|diff|={np.abs(got - want).max():.3e} (tol rtol={rtol}, atol={atol})"
 
 

@@ -26,6 +26,10 @@ def _close(got, want, tol=1e-4, what=""):
     assert got.shape == want.shape, (what, got.shape, want.shape)
     lim = tol * max(1.0, float(np.abs(want).max()))
     err = np.abs(got - want) - tol * np.abs(want)
+    if got.size:
+        import errtable
+        w = int(np.argmax(np.abs(got - want)))
+        errtable.record(what, got, want, lim + tol * float(np.abs(want).flat[w]))
     assert err.max() <= lim, f"{what}: max|diff| {np.abs(got - want).max():.3e} > {lim:.3e}"
 
 

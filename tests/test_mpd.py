@@ -26,6 +26,8 @@ def _close(got, want, tol, what):
     scale = max(np.abs(want).max(), 1e-6)
     assert got.shape == want.shape, (what, got.shape, want.shape)
     err = np.abs(got - want).max()
+    import errtable
+    errtable.record(what, got, want, tol * scale)
     assert err <= tol * scale, (what, err, scale)
 
 
