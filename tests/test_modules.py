@@ -193,6 +193,15 @@ def test_tiny_generator_hip():
     _run_tiny("cuda:0")
 
 
+@pytest.mark.gpu
+def test_tiny_generator_hip_default_training_gemms(monkeypatch):
+    """tests/conftest.py forces the float64-accumulating Linear for the whole suite, so the fp32 parity tests never ran the
+    product's DEFAULT training GEMMs (VMASR_LINEAR_F64ACC=auto: library GEMMs wherever a gradient is recorded).  Same golden, same
+    gates (forward 1e-4, gradients 1e-3 of each tensor's scale), default mode."""
+    monkeypatch.setenv("VMASR_LINEAR_F64ACC", "auto")
+    _run_tiny("cuda:0")
+
+
 def test_reference_parameter_count_and_keys():
     """dims=16 generator: 3,010,352 parameters in 714 tensors (README.md:8)."""
     from vm_asr_amd.model import DualStreamInteractiveMambaUNet

@@ -5,6 +5,7 @@ the concatenated batch."""
 import numpy as np
 import os
 import sys
+import time
 
 import pytest
 import torch
@@ -1112,3 +1113,113 @@ def test_pick_variant_takes_the_fastest_capture():
     assert Trainer._pick_variant(vs, [23.0, 21.7, 20.9]) == (True, 3 / 4)
     assert Trainer._pick_variant(vs, [39.6, 40.2, 39.9]) == (False, None)
     assert Trainer._pick_variant(vs[:1], [5.0]) == (False, None)
+
+
+# ---- multi-GPU hardening without hardware: the failure paths of the in-graph RCCL route, on one rank ----------
+
+def _one_rank_group():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        return True
+    return False
+
+
+def test_rccl_comm_setup_failure_is_a_clean_error_on_every_rank(monkeypatch):
+    """ncclCommInitRank failing (bad unique id, no fabric) must not leave one rank with a communicator and the others without: the ranks
+    agree by all-reduce(MIN) and ALL raise RuntimeError — which GraphedTrainStep turns into 'collectives between the graphs'."""
+    import ctypes
+    import torch.distributed as dist
+    from vm_asr_amd import rccl
+
+    class FakeRccl:
+        def __init__(self, init_rc):
+            self.init_rc, self.destroyed = init_rc, 0
+
+        def ncclGetUniqueId(self, p):
+            return 0
+
+        def ncclCommInitRank(self, comm_p, world, uid, rank):
+            if self.init_rc == 0:
+                ctypes.cast(comm_p, ctypes.POINTER(ctypes.c_void_p))[0] = 0x1234
+            return self.init_rc
+
+        def ncclCommDestroy(self, comm):
+            self.destroyed += 1
+            return 0
+
+        def ncclGetErrorString(self, code):
+            return b"unhandled system error"
+
+    made = _one_rank_group()
+    try:
+        bad = FakeRccl(2)
+        monkeypatch.setattr(rccl, "_rccl", lambda: bad)
+        with pytest.raises(RuntimeError, match="communicator setup failed on this rank.*RCCL error 2"):
+            rccl.RcclComm(torch.device("cpu"))
+        good = FakeRccl(0)
+        monkeypatch.setattr(rccl, "_rccl", lambda: good)
+        comm = rccl.RcclComm(torch.device("cpu"))
+        assert comm._comm.value == 0x1234
+        comm.close()
+        assert good.destroyed == 1 and comm._comm is None
+        comm.close()                                   # idempotent
+        assert good.destroyed == 1
+    finally:
+        if made:
+            dist.destroy_process_group()
+
+
+def test_collective_watchdog_fires_on_a_hung_event_and_not_on_a_finished_one():
+    """rccl.CollectiveWatchdog: an armed event that never completes -> the timeout action (default: exit code 3); completed events -> nothing."""
+    import threading
+    from vm_asr_amd.rccl import CollectiveWatchdog
+
+    class Ev:
+        def __init__(self, done_after):
+            self.n, self.done_after = 0, done_after
+
+        def query(self):
+            self.n += 1
+            return self.n > self.done_after
+
+    fired = []
+    hit = threading.Event()
+
+    def on_timeout(what, waited):
+        fired.append((what, waited))
+        hit.set()
+    wd = CollectiveWatchdog(timeout_s=0.3, poll_s=0.01, on_timeout=on_timeout)
+    wd.arm(Ev(3), "finishes")
+    time.sleep(0.6)
+    assert not fired
+    wd.arm(Ev(10 ** 9), "hangs")
+    assert hit.wait(5.0) and fired[0][0] == "hangs" and fired[0][1] >= 0.3
+
+
+def test_collective_watchdog_default_action_exits_the_process_non_zero():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import time\nfrom vm_asr_amd.rccl import CollectiveWatchdog\n"
+            "class Ev:\n    def query(self):\n        return False\n"
+            "wd = CollectiveWatchdog(timeout_s=0.2, poll_s=0.01)\nwd.arm(Ev())\ntime.sleep(30)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert "exiting with code 3" in r.stderr
+
+
+def test_grad_wire_and_graph_collectives_defaults_are_the_conservative_ones(monkeypatch):
+    """ADVICE r05: until a multi-GPU run has shown parity, gradients travel as fp32 on torch.distributed's communicator between the graphs;
+    the bf16 wire and the in-graph RCCL route are opt-in."""
+    from vm_asr_amd.trainer import Trainer
+    for k in ("VMASR_GRAD_COMM", "VMASR_GRAPH_COLLECTIVES"):
+        monkeypatch.delenv(k, raising=False)
+    t = Trainer.__new__(Trainer)
+    assert t.graph_collectives() is False
+    monkeypatch.setenv("VMASR_GRAPH_COLLECTIVES", "1")
+    assert t.graph_collectives() is True
+    t._graph_collectives = False                       # a failed capture's retry: this trainer only, the environment untouched
+    assert t.graph_collectives() is False and os.environ["VMASR_GRAPH_COLLECTIVES"] == "1"

@@ -129,10 +129,19 @@ class GraphedTrainStep:
             # the captured collectives go through RCCL's C API on a communicator of this trainer (vm_asr_amd/rccl.py); one eager
             # round first: RCCL sets up its channels / buffers on the first collective of a communicator, which must not happen
             # inside a capture
-            comm = tr.enable_direct_rccl()
+            try:
+                comm = tr.enable_direct_rccl()      # (raises on EVERY rank if it failed on any: rccl.RcclComm agrees by all-reduce(MIN))
+            except RuntimeError as e:
+                tr.logger.warning(f"{e}: the gradient all-reduces stay between the graphs")
+                tr._graph_collectives = False
+                self.collectives_in_graph = False
+        self.watchdog = None
+        if self.collectives_in_graph:
             for key in (["mpd"] if tr.gan else []) + ["generator"]:
                 comm.all_reduce_(torch.zeros_like(tr._flat[key], dtype=tr._comm_dtype(key)), avg=True, stream=tr._comm_stream())
             torch.cuda.synchronize()
+            from .rccl import CollectiveWatchdog
+            self.watchdog = CollectiveWatchdog()     # nothing else watches a captured collective: the rank exits non-zero if one hangs
         # No cyclic garbage collection while a capture is open: an old CUDAGraph (a trainer <-> GraphedTrainStep cycle left by an earlier
         # trainer of this process) whose destructor runs inside a capture frees device memory there, which the runtime refuses — the
         # process aborts.  torch.cuda.graph() only collects first when torch.compiler.config.force_cudagraph_gc is set (2.9+).
@@ -175,6 +184,10 @@ class GraphedTrainStep:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph_fb.replay()
+        if self.watchdog is not None:
+            done = torch.cuda.Event()
+            done.record()                       # behind graph A (outside any capture: queryable)
+            self.watchdog.arm(done, "the gradient all-reduce captured into the step's graph")
         if not self.collectives_in_graph:
             if self.tr.gan:
                 self.tr._reduce_grads("mpd", async_op=True)   # (between the graphs: exposed — a graph launch does not overlap another stream)

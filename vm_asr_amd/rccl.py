@@ -16,7 +16,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["RcclComm", "available"]
+__all__ = ["RcclComm", "CollectiveWatchdog", "available"]
 
 _DTYPES = {torch.float32: 7, torch.float16: 6, torch.bfloat16: 9, torch.float64: 8, torch.int32: 2, torch.int64: 4, torch.uint8: 1}
 _SUM, _AVG = 0, 4
@@ -75,8 +75,19 @@ class RcclComm:
         raw = bytes(t.cpu().numpy().tobytes())
         ctypes.memmove(ctypes.addressof(uid), raw, 128)
         self._comm = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+        err = None
+        try:
+            import contextlib
+            with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
+                _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+        except RuntimeError as e:
+            err, self._comm = e, None
+        # all ranks have a communicator or none keeps one: a rank that went on alone would sit in its first collective for good
+        flag = torch.tensor([0.0 if err is not None else 1.0], device=on)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 0.0:
+            self.close()
+            raise RuntimeError(f"RcclComm: communicator setup failed on {'this rank: ' + str(err) if err is not None else 'another rank'}")
 
     def all_reduce_(self, t, avg=True, stream=None):
         """In-place sum / mean of `t` over the ranks, enqueued on `stream` (default: the current stream).  Capturable."""
@@ -89,7 +100,7 @@ class RcclComm:
         return t
 
     def close(self):
-        if getattr(self, "_comm", None):
+        if getattr(self, "_comm", None) is not None and self._comm:
             _rccl().ncclCommDestroy(self._comm)
             self._comm = None
 
@@ -98,3 +109,52 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+class CollectiveWatchdog:
+    """Nothing watches a collective that was captured into a HIP graph (the process group's watchdog never saw it): if a peer dies, the
+    survivors sit in the replayed all-reduce for good.  This thread does the watching: after every replay the trainer records an event
+    behind the graph (`arm`, outside any capture) and the thread polls it; an event that has not completed after `timeout_s` makes
+    the rank EXIT NON-ZERO (`os._exit`, no cleanup: the GPU side is wedged) — starting a fresh process is the launcher's job
+    (torchrun --max-restarts), never a re-exec of a process that has touched the GPU.  VMASR_RCCL_TIMEOUT_S (default 300)."""
+
+    EXIT_CODE = 3
+
+    def __init__(self, timeout_s=None, poll_s=0.05, on_timeout=None):
+        import queue
+        import threading
+        self.timeout_s = float(os.environ.get("VMASR_RCCL_TIMEOUT_S", "300")) if timeout_s is None else float(timeout_s)
+        self.poll_s = poll_s
+        self.on_timeout = on_timeout or self._die
+        self._q = queue.Queue()
+        self._thread = threading.Thread(target=self._run, name="vmasr-rccl-watchdog", daemon=True)
+        self._thread.start()
+
+    def arm(self, event, what="captured all-reduce"):
+        """`event`: anything with .query() -> bool (a torch.cuda.Event recorded behind the replayed graph)."""
+        import time
+        self._q.put((event, time.monotonic(), what))
+
+    def _die(self, what, waited):
+        import sys
+        sys.stderr.write(f"[vm_asr_amd] {what} has not completed after {waited:.0f} s (a peer rank is gone or the fabric is wedged): "
+                         f"exiting with code {self.EXIT_CODE}; restart the job from the last checkpoint\n")
+        sys.stderr.flush()
+        os._exit(self.EXIT_CODE)
+
+    def _run(self):
+        import time
+        while True:
+            event, t0, what = self._q.get()
+            while True:
+                try:
+                    done = bool(event.query())
+                except Exception:      # noqa: BLE001  (a query that throws — device lost — is a timeout too)
+                    done = False
+                if done:
+                    break
+                waited = time.monotonic() - t0
+                if waited > self.timeout_s:
+                    self.on_timeout(what, waited)
+                    break
+                time.sleep(self.poll_s)
