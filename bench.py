@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PMC_FILE = "r05_pmc_traffic.json"
+PMC_FILE = "r06_pmc_traffic.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 
@@ -279,14 +279,18 @@ def csrc_digest():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "vm_asr_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vm_asr_amd", "csrc", "*.h"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "vm_asr_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vm_asr_amd", "csrc", "*.h"))
+                    + [os.path.join(ROOT, "vm_asr_amd", "csrc", "Makefile")]):       # (the build flags are part of what was measured)
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
-VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9     # lane-instructions per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (157 TFLOP/s of packed fp32 FMA)
-VALU_SLOTS_FWD, VALU_SLOTS_BWD = 14.0, 35.0  # packed instructions per state-step of csrc/sscan_n.hip's forward / backward (ISA count)
+VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9     # lane-instructions per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+# VALU issue slots per state-step of csrc/sscan_n.hip's forward / backward, counted on the round-5 ISA (two fp32 operations per packed
+# instruction).  Since round 6 the library is built WITHOUT packed-fp32 instructions (csrc/Makefile) and the stress point runs at the
+# same speed (41.2 vs 40.5 clips/s, tools/hunt13.sh): a packed instruction takes two passes, so the slot count stands as a count of passes.
+VALU_SLOTS_FWD, VALU_SLOTS_BWD = 14.0, 35.0
 
 
 def scan_state_steps_per_clip(cfg):

@@ -640,6 +640,13 @@ class Trainer(BaseTrainer):
         async_op: the call returns at once and the collective runs on RCCL's own stream, ordered after the CURRENT stream's work so
         far — the caller overlaps it with further work and joins it with _wait_reduces() before the optimiser reads the gradients.
         Capturable (RCCL): inside a stream capture the collective becomes a branch of the graph."""
+        emu = os.environ.get("VMASR_GRAD_COMM_EMULATE") if self.world == 1 else None
+        if emu and key in self._flat and (emu == "bf16" or (emu == "mpd-bf16" and key != "generator")):
+            # one rank, no wire: the 16-bit wire's ROUNDING applied to this rank's own gradient (tools/wire_dtype_run.py compares the
+            # loss curves of 200 steps with and without it — the numerics question of the bf16 wire, answerable without a second GPU)
+            flat = self._flat[key]
+            flat.copy_(flat.to(torch.bfloat16))
+            return
         if self.world > 1 and self.dp_mode == "flat":
             if key not in self._flat:
                 self._setup_flat(key, None)
