@@ -71,10 +71,13 @@ class _SmallLinearFn(torch.autograd.Function):
         return (dx.view(shape) if need_dx else None, dw.to(wdt), db.to(bdt) if bdt is not None else None, None)
 
 
+_SPLITK_CHUNK = int(os.environ.get("VMASR_SPLITK_CHUNK", "2048"))   # fewest rows of one K-split
+
+
 def splitk_plan(rows, out_f, in_f):
     """Number of K-splits for dW (out_f, in_f) = gy^T (out_f, rows) @ x (rows, in_f); 1 = plain GEMM."""
     tiles = -(-out_f // 64) * -(-in_f // 64)          # output tiles one GEMM would spread over the CUs
-    return min(rows // 2048, max(1, 512 // tiles))
+    return min(rows // _SPLITK_CHUNK, max(1, 512 // tiles))
 
 
 _F32_OUT = None   # does this torch build take out_dtype=float32 on 16-bit mm / bmm (hipBLASLt fp32 output)?
