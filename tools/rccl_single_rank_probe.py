@@ -1,6 +1,7 @@
 """The N > 1 training-step path on ONE GPU with the real RCCL backend (dev tool): a 1-rank "nccl" process group, the trainer
 told that world = 2 so that it takes the flat-buffer all-reduce path (async RCCL all-reduce with ReduceOp.AVG between the
-replayed graphs, or — the default — captured INTO the step's graph as a third branch; RCCL's watchdog thread alive during graph capture).  With one rank the collective is the identity, so the
+replayed graphs — the default —, or, VMASR_GRAPH_COLLECTIVES=1, captured INTO the step's graph as a third branch through RCCL's C API, with rccl.CollectiveWatchdog
+armed behind every replay; RCCL's own watchdog thread alive during graph capture).  With one rank the collective is the identity, so the
 losses must match a plain single-process run; what this shows is that RCCL + HIP-graph capture + replay coexist on this stack.
     python tools/rccl_single_rank_probe.py"""
 import os
