@@ -1176,7 +1176,10 @@ class Trainer(BaseTrainer):
         flat gradient buffers and the optimiser states have to exist before anything is captured).  With
         `preserve_state` (default) weights, buffers, Adam moments and step counters are copied back in place afterwards,
         so that training — fresh or resumed — starts from exactly the state it was given and `global_step` / the LR
-        schedule count only real training steps."""
+        schedule count only real training steps.
+        With preserve_state=False all of it STAYS: up to three captures x (warm-up + 8 timed replays) = ~30 extra optimisation steps on
+        `example_batch`, and the layout is chosen by timings that differ by 1-5 % (it can differ between runs, which changes the order of
+        the atomic additions): pin it with VMASR_STEP_VARIANT (one | lane | lane:<share>) for reproducible runs."""
         from .graph_step import GraphedTrainStep
         snap = self._snapshot_training_state() if preserve_state else None
         multi = self.world > 1 and dist.is_initialized()
