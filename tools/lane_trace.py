@@ -50,6 +50,20 @@ for q, ks in sorted(byq.items()):
     mpd = sum(1 for _, _, n in ks if any(t in n for t in ("conv_mfma", "conv_first", "conv_post", "gelu_bwd", "masked_l1", "im2col", "col2im")))
     print(f"queue {q}: {len(ks):5d} kernels ({mpd} discriminator-side), busy {busy / 1e6:6.2f} ms, first {ks[0][0] / 1e6:6.2f} last {ks[-1][1] / 1e6:6.2f} ms, "
           f"sum of kernel durations {sum(e - s for s, e, _ in ks) / 1e6:6.2f} ms")
+# idle structure of each queue: gaps between consecutive kernels (launch gaps are a few us each; a wait for another stream is one long gap)
+for q, ks in sorted(byq.items()):
+    ks = sorted(ks)
+    gaps = [max(0, ks[i + 1][0] - ks[i][1]) for i in range(len(ks) - 1)]
+    if not gaps:
+        continue
+    g = sorted(gaps)
+    small = [x for x in gaps if x <= 10e3]
+    big = [x for x in gaps if x > 50e3]
+    top = sorted(((ks[i + 1][0] - ks[i][1], ks[i][2][:40], ks[i + 1][2][:40], ks[i][1] / 1e6) for i in range(len(ks) - 1)), reverse=True)[:5]
+    print(f"queue {q}: gaps total {sum(gaps) / 1e6:6.2f} ms; <= 10 us: {len(small)} gaps, {sum(small) / 1e6:5.2f} ms (median {g[len(g) // 2] / 1e3:.1f} us); "
+          f"> 50 us: {len(big)} gaps, {sum(big) / 1e6:5.2f} ms")
+    for d, a_, b_, at in top:
+        print(f"      {d / 1e3:8.1f} us at {at:6.2f} ms  after {a_}  before {b_}")
 qs = sorted(U)
 for i, a in enumerate(qs):
     for b in qs[i + 1:]:
