@@ -237,3 +237,40 @@ def test_captured_generator_only_step_in_deterministic_mode():
         assert lib.vmasr_det_timeouts() == 0
     finally:
         lib.vmasr_set_deterministic(was)
+
+
+def test_general_state_projection_gradients_are_ordered_in_deterministic_mode():
+    """Round 6: the d_state > 1 projections' weight gradients (csrc/xproj_n.hip: 32 x 32 tiles over chunks of positions, float atomics) had no
+    ordered form — with the mode on, 54 tensors of the d_state-32 train step still differed between two evaluations (x_proj_weight,
+    dt_projs_weight of every block).  Now workgroups add in workgroup order and their four waves in wave order: bit-equal, equal to the
+    default mode to rounding, no ordered wait timed out."""
+    from vm_asr_amd import _lib
+    from vm_asr_amd.xproj import x_proj_dt
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    B, K, D, N, R, L = 2, 4, 64, 32, 4, 4096
+    xs = torch.randn(B, K, D, L, generator=g).cuda().requires_grad_(True)
+    wx = (0.1 * torch.randn(K, R + 2 * N, D, generator=g)).cuda().requires_grad_(True)
+    wdt = (0.1 * torch.randn(K, D, R, generator=g)).cuda().requires_grad_(True)
+    gd, gb, gc = (torch.randn(s, generator=g).cuda() for s in ((B, K * D, L), (B, K, N, L), (B, K, N, L)))
+
+    def run():
+        for t in (xs, wx, wdt):
+            t.grad = None
+        dts, Bs, Cs = x_proj_dt(xs, wx, wdt, N)
+        (dts.reshape(B, K * D, L) * gd).sum().add((Bs * gb).sum()).add((Cs * gc).sum()).backward()
+        torch.cuda.synchronize()
+        return [t.grad.clone() for t in (xs, wx, wdt)]
+    was = lib.vmasr_get_deterministic()
+    try:
+        lib.vmasr_set_deterministic(0)
+        ref = run()
+        lib.vmasr_set_deterministic(1)
+        runs = [run() for _ in range(4)]
+        assert lib.vmasr_det_timeouts() == 0
+    finally:
+        lib.vmasr_set_deterministic(was)
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+    for a, b in zip(ref, runs[0]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * a.abs().max().item())

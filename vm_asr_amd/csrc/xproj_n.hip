@@ -219,7 +219,7 @@ template <typename TB>
 __global__ __launch_bounds__(256) void xproj_nbwd_b_kernel(const Seg3 A, const long a_bk_stride0, const long a_bk_stride1, const long a_bk_stride2,
                                                            const TB *__restrict__ Bp, const long b_bk_stride, const int M, const int Nc,
                                                            float *__restrict__ out, const long out_k_stride, const int ldo, const int K,
-                                                           const int L, const int chunk, const bool vec) {
+                                                           const int L, const int chunk, const bool vec, unsigned *det) {
     const int lane = threadIdx.x & 63, j = lane & 31, kq = lane >> 5, wave = threadIdx.x >> 6;
     const int ntn = (Nc + 31) / 32;
     const int mb = blockIdx.y / ntn, nb = blockIdx.y % ntn;
@@ -250,11 +250,19 @@ __global__ __launch_bounds__(256) void xproj_nbwd_b_kernel(const Seg3 A, const l
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4[3], acc1, 0, 0, 0);
     }
     float *o = out + (long)k * out_k_stride;
+    // (deterministic mode, common.h: the workgroups' atomics in workgroup order, the four waves of a workgroup in wave order — each
+    //  wave's atomics performed, `s_waitcnt vmcnt(0)`, before the next wave issues its own)
+    auto add_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int mm = mb * 32 + acc_row(i, kq);
-        if (mm < M && n < Nc) atomicAdd(o + (long)mm * ldo + n, acc[i] + acc1[i]);
-    }
+        for (int i = 0; i < 16; ++i) {
+            const int mm = mb * 32 + acc_row(i, kq);
+            if (mm < M && n < Nc) atomicAdd(o + (long)mm * ldo + n, acc[i] + acc1[i]);
+        }
+        if (det) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    det_enter(det);
+    VMASR_DET_WAVE_ORDER(det, 4, add_tile());
+    det_leave(det);
 }
 
 int check(const XnGeom &g, int dtype, const char *what) {
@@ -315,17 +323,18 @@ VMASR_EXPORT int vmasr_xproj_n_bwd(const void *xs, const float *Wx, const float 
     const int tiles_x = ((g.C + 31) / 32) * ((D + 31) / 32), tiles_t = ((D + 31) / 32) * ((R + 31) / 32);
     int chunk = 4096;
     while (chunk > 512 && (long)((L + chunk - 1) / chunk) * tiles_x * B * K < 2048) chunk >>= 1;
+    unsigned *det = det_ticket(VMASR_K_XPROJ_BWD_B);       // deterministic mode: ordered accumulation (null otherwise)
     const Seg3 ax{{ws, dBs, dCs}, {R, N, N}};
     const dim3 gx((L + chunk - 1) / chunk, tiles_x, B * K), gt((L + chunk - 1) / chunk, tiles_t, B * K);
 #define VMASR_XNB(TT)                                                                                                                \
     VMASR_LAUNCH(VMASR_K_XPROJ_BWD_B, bytes_b, (xproj_nbwd_b_kernel<TT>), gx, dim3(256), 0, st, ax, (long)R * L, (long)N * L, (long)N * L, \
-                 (const TT *)xs, (long)D * L, g.C, D, dWx, (long)g.C * D, D, K, L, chunk, vec)
+                 (const TT *)xs, (long)D * L, g.C, D, dWx, (long)g.C * D, D, K, L, chunk, vec, det)
     if (dtype == VMASR_F32) VMASR_XNB(float);
     else if (dtype == VMASR_F16) VMASR_XNB(f16_t);
     else VMASR_XNB(bf16_t);
 #undef VMASR_XNB
     const Seg3 at{{ddts, nullptr, nullptr}, {D, 0, 0}};
     VMASR_LAUNCH(VMASR_K_XPROJ_BWD_B, 0.0, (xproj_nbwd_b_kernel<float>), gt, dim3(256), 0, st, at, (long)D * L, 0L, 0L, dtr, (long)R * L, D, R,
-                 dWdt, (long)D * R, R, K, L, chunk, vec);
+                 dWdt, (long)D * R, R, K, L, chunk, vec, det);
     return check_launch("xproj_n_bwd");
 }
