@@ -101,9 +101,11 @@ def synth_batch(config, device, rank):
     return inp.to(device), tgt.to(device), hc.to(device)
 
 
-def cpu_baseline(config, budget_s=60.0):
+def cpu_baseline(config, budget_s=40.0):
     """Same train step on the host: torch-CPU modules with the oracle's C kernels in the operator
-    hooks (kind 'port').  Sample: 1 clip, 1 step (plus one untimed warm-up forward of STFT)."""
+    hooks (kind 'port').  Sample: 1 clip, two full steps back to back — the first is cold (thread pools spin up, pages fault in:
+    it varied 0.037-0.094 clips/s between boxes in rounds 4-5), the second is what is reported; a second step that would not fit the
+    budget is skipped and the cold one reported, saying so."""
     import oracle
     from oracle.torch_backend import oracle_stft_patch, use_oracle
     from vm_asr_amd.config import update_config
@@ -115,14 +117,20 @@ def cpu_baseline(config, budget_s=60.0):
     tr = build_trainer(cfg, torch.device("cpu"), amp=False)
     use_oracle(tr.models["generator"])
     inp, tgt, hc = synth_batch(cfg, torch.device("cpu"), 0)
+    dts = []
     with oracle_stft_patch():
-        t0 = time.time()
-        tr.train_step(inp, tgt, hc)
-        dt = time.time() - t0
+        for _ in range(2):
+            t0 = time.time()
+            tr.train_step(inp, tgt, hc)
+            dts.append(time.time() - t0)
+            if dts[0] * 2 > budget_s:
+                break
+    dt = dts[-1]
+    what = "G+MPD" if cfg.TRAIN.ADVERSARIAL.ENABLE else "G"
     return {"value": 1.0 / dt, "unit": "clips/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"1 clip x 1 full train step ({'G+MPD' if cfg.TRAIN.ADVERSARIAL.ENABLE else 'G'}, fp32) "
-                      f"in {dt:.1f} s: torch-CPU modules + oracle C kernels (OpenMP)",
-            "spread": "one cold step: 0.037-0.094 clips/s between boxes of the pool (rounds 4-5)"}
+            "sample": (f"1 clip x 2 full train steps ({what}, fp32), the second timed: {dt:.1f} s (the cold first: {dts[0]:.1f} s)" if len(dts) == 2 else
+                       f"1 clip x 1 full train step ({what}, fp32), cold: {dt:.1f} s (a second would not fit the {budget_s:.0f} s budget)")
+                      + ": torch-CPU modules + oracle C kernels (OpenMP)"}
 
 
 RUN_INFO = {}       # of the last run_point(): the captured step's generator stream count and, if both variants were captured, their times
