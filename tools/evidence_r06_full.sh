@@ -11,7 +11,7 @@ unset VMASR_TWO_STREAM
 cd $R
 python tools/pmc_bench_report.py $(find /tmp/pmc_f -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_w -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json 2>&1 | tail -n 8
 cp $O/pmc_traffic.json profiles/r06_pmc_traffic.json          # (on the box: the bench below quotes it after checking the digest)
-bash tools/evidence_r06.sh c
+bash tools/evidence_r06.sh ${LEASE:-c}
 timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cat $O/bench.json | cut -c1-600; cp bench_detail.json $O/bench_detail.json
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o e -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-points --timing-pass shared > $O/bench_prof.json 2> /tmp/prof.err
