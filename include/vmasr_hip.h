@@ -324,6 +324,15 @@ int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int3
                         int64_t rows_out, int32_t act, vmasr_stream_t stream);
 int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
                           int64_t rows_in, vmasr_stream_t stream);
+/* The same stacked convolution with FP32 OPERANDS and exact-f32 products (v_mfma_f32_32x32x2_f32) for Cin = 32 — the 32 -> 128 layer of
+ * model/discriminator.py:40-60, whose forward at the bf16 pair's 16-17 bits moved d(loss)/d(wave) out of its gate.  slots: ah = x fp32
+ * (rows of Cin), bh = W fp32 (Cout, k Cin) in (tap, channel) order [dgrad: ah = g fp32 (rows of Cout), bh = W^T fp32 (Cin, k Cout) in
+ * (tap, output channel) order, c0 = dx fp32]; al / bl are ignored; outputs, geometry and epilogue as the pair form.  Replace the fp32
+ * GEMM over a materialised im2col operand + bias / GELU pass (forward) and the GEMM + col2im (input gradient). */
+int vmasr_conv_f32_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                       int64_t rows_out, int32_t act, vmasr_stream_t stream);
+int vmasr_conv_f32_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                         int64_t rows_in, vmasr_stream_t stream);
 int vmasr_conv_mfma_wgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
                           int32_t splits, vmasr_stream_t stream);
 /* The input gradient of layer l + 1 with the activation backward of layer l in its epilogue (round 5).  The reference's autograd runs,

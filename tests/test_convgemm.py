@@ -232,3 +232,62 @@ def test_conv_mfma_dgrad_with_the_activation_backward_in_its_epilogue(case):
         want = r32.double().sum(1)
         sc = want.abs().max().item()
         assert (db.double() - want).abs().max().item() <= 1e-5 * sc and (db_ref.double() - want).abs().max().item() <= 1e-5 * sc
+
+
+F32_CASES = [
+    # (Cin, Cout, k, stride, pad, geom): the 32 -> 128 layer's geometry (ragged sequences, several tiles, sequences shorter than the kernel)
+    (32, 128, 5, 3, 2, [(5, 61), (3, 100)]),
+    (32, 128, 5, 3, 2, [(9, 333), (4, 517), (2, 1031)]),
+    (32, 128, 5, 3, 2, [(7, 3)]),
+    (32, 256, 5, 3, 2, [(6, 200)]),
+]
+
+
+@gpu
+@pytest.mark.parametrize("case", F32_CASES)
+def test_conv_f32_fwd_dgrad_match_float64_at_fp32_accuracy(case):
+    """The exact-f32 form (csrc/convgemm.hip OPS 1: fp32 operands, v_mfma_f32_32x32x2_f32) of the 32 -> 128 layer's forward and input
+    gradient against float64 — held to what an fp32 evaluation of the same lines achieves (torch's own fp32 convolution x 4), two orders
+    tighter than the bf16x3 form's 16-17 bits; epilogue (bias, GELU, bf16 pair, zero padding rows) as the pair form."""
+    from vm_asr_amd import convgemm as cg
+    Cin, Cout, k, stride, pad, geom = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = len(geom)
+    xs = [torch.randn(ns, H, Cin, generator=g).to(dev) for ns, H in geom]
+    W = (torch.randn(n, Cout, k * Cin, generator=g) / (k * Cin) ** 0.5).to(dev)
+    bias = torch.randn(n, Cout, generator=g).to(dev)
+    H1 = [cg.out_positions(H, k, stride, pad) for _, H in geom]
+    Ms = [ns * h1 for (ns, _), h1 in zip(geom, H1)]
+    rows_in = -(-max(ns * H for ns, H in geom) // 256) * 256 + 256
+    rows_out = -(-max(Ms) // 256) * 256
+    x = _stack([t.reshape(-1, Cin) for t in xs], rows_in)
+    pre, y, yh, yl = cg.conv_fwd_f32(x, W, bias, geom, k, stride, pad, rows_out, act=True)
+    xs64 = [t.double().requires_grad_(True) for t in xs]
+    W64 = W.double().requires_grad_(True)
+    pres64, ys64 = _ref(xs64, W64, bias.double(), k, stride, pad, True)
+    pres32, _ = _ref(xs, W, bias, k, stride, pad, True)
+    for i, M in enumerate(Ms):
+        sc = pres64[i].abs().max().item()
+        e = (pre[i, :M].double() - pres64[i]).abs().max().item()
+        e32 = (pres32[i].double() - pres64[i]).abs().max().item()
+        assert e <= 4 * e32 + 1e-7 * sc, (i, e, e32, sc)          # fp32 accuracy (measured: at or below torch's fp32 convolution)
+        assert (y[i, :M].double() - ys64[i]).abs().max().item() <= 4 * e32 + 1e-6 * max(1.0, ys64[i].abs().max().item())
+        pair = yh[i, :M].float() + yl[i, :M].float()
+        assert (pair - y[i, :M]).abs().max().item() <= 2 ** -16 * y[i, :M].abs().max().item()
+        for t in (pre, y, yh, yl):
+            assert not t[i, M:].any(), "padding rows must be zero"
+    gy = [torch.randn(M, Cout, generator=g).to(dev) for M in Ms]
+    gst = _stack(gy, rows_out)
+    sum((p * gg.double()).sum() for p, gg in zip(pres64, gy)).backward()
+    xs32 = [t.clone().requires_grad_(True) for t in xs]
+    p32, _ = _ref(xs32, W, bias, k, stride, pad, True)
+    sum((p * gg).sum() for p, gg in zip(p32, gy)).backward()
+    Wt = W.view(n, Cout, k, Cin).permute(0, 3, 2, 1).reshape(n, Cin, k * Cout).contiguous()
+    dx = cg.conv_dgrad_f32(gst, Wt, geom, k, stride, pad, rows_in)
+    for i, (ns, H) in enumerate(geom):
+        want = xs64[i].grad.reshape(-1, Cin)
+        sc = max(want.abs().max().item(), 1e-30)
+        e32 = (xs32[i].grad.reshape(-1, Cin).double() - want).abs().max().item()
+        assert (dx[i, :ns * H].double() - want).abs().max().item() <= 4 * e32 + 1e-7 * sc, (i, e32, sc)
+        assert not dx[i, ns * H:].any(), "rows below the slot's data must be zero"

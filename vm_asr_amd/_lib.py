@@ -151,6 +151,8 @@ SYMBOLS = {
     "vmasr_conv_get_cu_limit": (c_i32, []),
     "vmasr_conv_mfma_fwd": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
     "vmasr_conv_mfma_dgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "vmasr_conv_f32_fwd": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
+    "vmasr_conv_f32_dgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "vmasr_conv_mfma_wgrad": (ctypes.c_int, [ctypes.POINTER(CgSlot), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vmasr_conv_mfma_dgrad_gelu": (ctypes.c_int, [ctypes.POINTER(CgSlot), ctypes.POINTER(CgGeluBwd), c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                   c_i32, c_i64, c_vp]),

@@ -112,6 +112,54 @@ def conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, rows_in):
     return dx
 
 
+def conv_fwd_f32(x, w, bias, geom, k, stride, pad, rows_out, act=True, want_pair=True):
+    """conv_fwd with FP32 operands and exact-f32 products (csrc/convgemm.hip OPS 1; Cin = 32): x (n, rows_in, Cin) fp32, w (n, Cout, k*Cin)
+    fp32 in (tap, channel) order.  Same outputs as conv_fwd."""
+    _need(x, w, bias)
+    n, rows_in, Cin = x.shape
+    Cout = w.shape[1]
+    dev = x.device
+    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    with torch.cuda.device(dev):
+        pre = torch.empty((n, rows_out, Cout), dtype=torch.float32, device=dev)
+        y = torch.empty_like(pre) if act else None
+        yh = torch.empty((n, rows_out, Cout), dtype=torch.bfloat16, device=dev) if act and want_pair else None
+        yl = torch.empty_like(yh) if yh is not None else None
+        sl = _slots(n)
+        for i, (nseq, H) in enumerate(geom):
+            s = sl[i]
+            s.ah, s.bh = _ptr(x, i, rows_in * Cin * 4), _ptr(w, i, Cout * k * Cin * 4)
+            s.c0, s.c1 = _ptr(pre, i, rows_out * Cout * 4), _ptr(y, i, rows_out * Cout * 4)
+            s.ch, s.cl = _ptr(yh, i, rows_out * Cout * 2), _ptr(yl, i, rows_out * Cout * 2)
+            s.bias = _ptr(bias, i, Cout * 4)
+            s.nseq, s.H = int(nseq), int(H)
+        _apply_limit(Cin, Cout)
+        _lib.check(_lib.lib().vmasr_conv_f32_fwd(sl, n, Cin, Cout, k, stride, pad, rows_out, int(bool(act)), _lib.current_stream(dev)),
+                   "conv_f32_fwd")
+    return pre, y, yh, yl
+
+
+def conv_dgrad_f32(g, wt, geom, k, stride, pad, rows_in):
+    """conv_dgrad with FP32 operands and exact-f32 products (Cin = 32): g (n, rows_out, Cout) fp32, wt (n, Cin, k*Cout) fp32 in
+    (tap, output channel) order.  -> dx (n, rows_in, Cin) fp32."""
+    _need(g, wt)
+    n, rows_out, Cout = g.shape
+    Cin = wt.shape[1]
+    dev = g.device
+    assert g.dtype == torch.float32 and wt.dtype == torch.float32
+    with torch.cuda.device(dev):
+        dx = torch.empty((n, rows_in, Cin), dtype=torch.float32, device=dev)
+        sl = _slots(n)
+        for i, (nseq, H) in enumerate(geom):
+            s = sl[i]
+            s.ah, s.bh = _ptr(g, i, rows_out * Cout * 4), _ptr(wt, i, Cin * k * Cout * 4)
+            s.c0 = _ptr(dx, i, rows_in * Cin * 4)
+            s.nseq, s.H = int(nseq), int(H)
+        _apply_limit(Cin, Cout)
+        _lib.check(_lib.lib().vmasr_conv_f32_dgrad(sl, n, Cin, Cout, k, stride, pad, rows_in, _lib.current_stream(dev)), "conv_f32_dgrad")
+    return dx
+
+
 def conv_dgrad_gelu(gh, gl, wth, wtl, geom, k, stride, pad, rows_in, pre, want_f32=False, want_pair=True, sgn=None, gtok=None,
                     scale=None, valid=None, db=None):
     """conv_dgrad with the activation backward of the layer BELOW in the epilogue: g = (dx + gtok * scale_i * sgn) * GELU'(pre), where

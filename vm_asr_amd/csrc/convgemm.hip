@@ -102,8 +102,15 @@ __device__ __forceinline__ f32x16 cg_mfma(const bf16x8 a, const bf16x8 b, const 
 // < fvalid: the feature-matching term that autograd would add to this gradient), g = t GELU'(pre_l[row, col]) -> c0 (fp32, optional) and
 // the bf16 pair ch / cl (optional) — what gelu_bwd_split (csrc/split.hip) and masked_l1_bwd_add (csrc/featloss.hip) do in two more passes
 // over the map (r 4 + 5 + 8, w 4 + 4 + 4 bytes per element -> r 5, w 4).
-template <int BM, int BN, int WM, int WN, int EPI, int MF>
+// OPS: 0 = operands are bf16 (hi, lo) pairs, three bf16 MFMAs per fragment pair (above); 1 = operands are FP32 rows, exact-f32 products on
+// v_mfma_f32_32x32x2_f32 (MF must be 32) — the 32 -> 128 layer, whose forward at the pair's 16-17 bits moved d(loss)/d(wave) out of its
+// gate (vm_asr_amd/discriminator.py).  Same LDS image and the same fragment addresses: a K step consumes 32 FLOATS of a row = 128 B,
+// floats 0..15 in the tile the pair form calls A_hi / B_hi, floats 16..31 in A_lo / B_lo (pointers: lo = hi + 32 bf16-units); the
+// 16-byte chunk a lane reads holds 4 consecutive k of its row, lane half lh takes chunk 2 ks + lh, and four 32x32x2 MFMAs contract
+// (k, k + 4) pairs — the pairing is the same on the A and on the B side, so the sum over the K step is complete.  CA, KB count FLOATS here.
+template <int BM, int BN, int WM, int WN, int EPI, int MF, int OPS = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgParams P) {
+    static_assert(OPS == 0 || MF == 32, "the f32 form uses the 32-row fragment layout");
     constexpr bool ACT = EPI == 1;
     constexpr int NT = 64 * WM * WN;                   // threads
     constexpr int WTM = BM / WM, WTN = BN / WN;        // per-wave tile
@@ -133,7 +140,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
     const int local = t - pr.tile_start;
     const int nt = local % P.ntiles_n, mt = local / P.ntiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int M = pr.M, Q = pr.Q, HA = pr.HA, CA = P.CA, NB = P.NB, KB = P.KB;
+    const int M = pr.M, Q = pr.Q, HA = pr.HA, CA = P.CA, NB = P.NB;
+    constexpr int UPK = OPS ? 64 : 32;                 // bf16-units of a row that one K step consumes (f32 form: 32 floats = 64 units)
+    const int LDA = OPS ? 2 * CA : CA;                 // row stride of A / per-tap stride inside a B row, in bf16-units
+    const int KB = OPS ? 2 * P.KB : P.KB;
 
     if (tid < BM) {
         const int m = m0 + tid;
@@ -170,29 +180,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
         bsrc_h[i] = pr.bh + o;
         bsrc_l[i] = pr.bl + o;
     }
-    const int cpk = CA / CG_BK;                                        // K steps per tap
+    const int cpk = CA / CG_BK;                                        // K steps per tap (32 elements of either form)
     const int nk = (m0 < M) ? pr.ntaps * cpk : 0;                      // all-padding tiles only write zeros
     const int wbase = wave * 16 * 64;                                  // this wave's 1 KB of each pass
     const bf16_t *zp = reinterpret_cast<const bf16_t *>(cg_zero_page);
 
 #define CG_DMA(src, dst) __builtin_amdgcn_global_load_lds((cg_gptr)(src), (cg_lptr)(dst), 16, 0, 0)
     auto stage_tile = [&](const int kt, const int buf) {
-        const int j = kt / cpk, c0 = (kt - j * cpk) * CG_BK;
-        const int koff = (pr.tap0 + j * pr.tap_step) * CA + c0;
+        const int j = kt / cpk, c0 = (kt - j * cpk) * UPK;
+        const int koff = (pr.tap0 + j * pr.tap_step) * LDA + c0;
         unsigned char *d = smem + buf * STAGE + wbase;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int pos = a_hq[i] + j * pr.dstep;
             const bool ok = a_ok[i] && pos >= 0 && pos < HA;
-            const size_t o = (size_t)(a_base[i] + pos) * CA + c0 + chunk * 8;
+            const size_t o = (size_t)(a_base[i] + pos) * LDA + c0 + chunk * 8;
             CG_DMA(ok ? pr.ah + o : zp, d + i * RPP * 64);
-            CG_DMA(ok ? pr.al + o : zp, d + TILE_A + i * RPP * 64);
+            CG_DMA(ok ? (OPS ? pr.ah + o + 32 : pr.al + o) : zp, d + TILE_A + i * RPP * 64);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             if (B_PART && srow >= BN) break;           // (wave-uniform: a wave stages 16 whole rows)
             CG_DMA(bsrc_h[i] + koff, d + 2 * TILE_A + i * RPP * 64);
-            CG_DMA(bsrc_l[i] + koff, d + 2 * TILE_A + TILE_B + i * RPP * 64);
+            CG_DMA((OPS ? bsrc_h[i] + 32 : bsrc_l[i]) + koff, d + 2 * TILE_A + TILE_B + i * RPP * 64);
         }
     };
 
@@ -214,7 +224,33 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_nt_kernel(const CgP
         const int buf = kt & 1;
         if (kt + 1 < nk) stage_tile(kt + 1, buf ^ 1);                  // lands during this tile's MFMAs (every wave left buf ^ 1 at the last barrier)
         const unsigned char *s = smem + buf * STAGE;
-        if constexpr (MF == 32) {
+        if constexpr (OPS == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x4 a0[TI], a1[TI], b0[TJ], b1[TJ];          // floats 0..15 / 16..31 of the K step: this lane's 4 consecutive k of each
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int oa = cg_off(wm * WTM + i * 32 + lr, ks * 2 + lh);
+                    a0[i] = *reinterpret_cast<const f32x4 *>(s + oa);
+                    a1[i] = *reinterpret_cast<const f32x4 *>(s + TILE_A + oa);
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int ob = cg_off(wn * WTN + j * 32 + lr, ks * 2 + lh);
+                    b0[j] = *reinterpret_cast<const f32x4 *>(s + 2 * TILE_A + ob);
+                    b1[j] = *reinterpret_cast<const f32x4 *>(s + 2 * TILE_A + TILE_B + ob);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][e], b0[j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][e], b1[j][e], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else if constexpr (MF == 32) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
@@ -618,7 +654,7 @@ int cg_grid(int tiles, size_t smem) {
     return std::min(tiles, std::min(g, cap));
 }
 
-template <int BM, int BN, int WM, int WN, int MF>
+template <int BM, int BN, int WM, int WN, int MF, int OPS = 0>
 int cg_launch_cfg(CgParams &P, int epi, hipStream_t st, int kid, double bytes) {
     int tiles = 0;
     P.ntiles_n = P.NB / BN;
@@ -630,26 +666,26 @@ int cg_launch_cfg(CgParams &P, int epi, hipStream_t st, int kid, double bytes) {
     P.total_tiles = tiles;
     if (tiles == 0) return 0;
     constexpr size_t smem = 2 * (2 * BM * 64 + 2 * BN * 64) + BM * sizeof(int);
-    constexpr bool HAS_EPI2 = BN >= 128;   // (the 32-wide tile only serves the 32 -> 128 layer's forward)
+    constexpr bool HAS_EPI2 = BN >= 128 && OPS == 0;   // (the 32-wide tile and the f32 form only serve the 32 -> 128 layer)
     static bool attr_done = false;
     if (!attr_done && smem > 65536) {      // > 64 KB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 1, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 0, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 1, MF, OPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 0, MF, OPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if constexpr (HAS_EPI2)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 2, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_nt_kernel<BM, BN, WM, WN, 2, MF, OPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     if (epi == 1) {
-        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 1, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 1, MF, OPS>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
     } else if (epi == 2) {
         if constexpr (HAS_EPI2) {
-            VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 2, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
+            VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 2, MF, OPS>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
         } else {
             set_error("conv_mfma: no fused activation backward for this tile");
             return VMASR_EINVAL;
         }
     } else {
-        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 0, MF>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
+        VMASR_LAUNCH(kid, bytes, (conv_mfma_nt_kernel<BM, BN, WM, WN, 0, MF, OPS>), dim3(cg_grid(tiles, smem)), dim3(64 * WM * WN), smem, st, P);
     }
     return check_launch("conv_mfma");
 }
@@ -692,23 +728,27 @@ VMASR_EXPORT int vmasr_conv_mfma_supported_launch(int32_t Cin, int32_t Cout, int
     return rows >= 1 && rows < (1LL << 31) / widest ? 1 : 0;
 }
 
-VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
-                                     int32_t pad, int64_t rows_out, int32_t act, vmasr_stream_t stream) {
-    VMASR_REQUIRE(slots && n >= 1 && n <= CG_MAXP, VMASR_EINVAL, "conv_mfma_fwd: 1..%d slots", CG_MAXP);
-    VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride), VMASR_EINVAL, "conv_mfma_fwd: unsupported shape (Cin %d, Cout %d, k %d, stride %d)",
-                  Cin, Cout, k, stride);
-    VMASR_REQUIRE(rows_out % 256 == 0, VMASR_EINVAL, "conv_mfma_fwd: rows_out must be a multiple of 256");
+namespace {
+// ops: 0 = bf16 (hi, lo) pairs (slots' ah / al, bh / bl), 1 = fp32 operands (ah = x fp32, bh = W fp32; al / bl unused): conv_mfma_nt_kernel OPS
+int cg_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int64_t rows_out,
+           int32_t act, vmasr_stream_t stream, int ops) {
+    const char *what = ops ? "conv_f32_fwd" : "conv_mfma_fwd";
+    VMASR_REQUIRE(slots && n >= 1 && n <= CG_MAXP, VMASR_EINVAL, "%s: 1..%d slots", what, CG_MAXP);
+    VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride) && (!ops || Cin == 32), VMASR_EINVAL,
+                  "%s: unsupported shape (Cin %d, Cout %d, k %d, stride %d)", what, Cin, Cout, k, stride);
+    VMASR_REQUIRE(rows_out % 256 == 0, VMASR_EINVAL, "%s: rows_out must be a multiple of 256", what);
     CgParams P = {};
     P.nprob = n;
     P.CA = Cin; P.NB = Cout; P.KB = k * Cin;
     double bytes = 0;
     for (int i = 0; i < n; ++i) {
         const vmasr_cg_slot &s = slots[i];
-        VMASR_REQUIRE(s.ah && s.al && s.bh && s.bl && s.c0, VMASR_EINVAL, "conv_mfma_fwd: null tensor in slot %d", i);
+        VMASR_REQUIRE(s.ah && s.bh && s.c0 && (ops || (s.al && s.bl)), VMASR_EINVAL, "%s: null tensor in slot %d", what, i);
+        VMASR_REQUIRE(!ops || (aligned_to(s.ah, 16) && aligned_to(s.bh, 16)), VMASR_EALIGN, "%s: slot %d: operands must be 16-byte aligned", what, i);
         const int64_t H1 = ((int64_t)s.H + 2 * pad - k) / stride + 1;
         const int64_t M = s.nseq * H1;
-        VMASR_REQUIRE(H1 >= 1 && M <= rows_out && rows_out < (1LL << 31) / std::max(Cout, k * Cin), VMASR_EINVAL,
-                      "conv_mfma_fwd: slot %d: %lld rows do not fit rows_out %lld (or 32-bit offsets)", i, (long long)M, (long long)rows_out);
+        VMASR_REQUIRE(H1 >= 1 && M <= rows_out && rows_out < (1LL << 30) / std::max(Cout, k * Cin), VMASR_EINVAL,
+                      "%s: slot %d: %lld rows do not fit rows_out %lld (or 32-bit offsets)", what, i, (long long)M, (long long)rows_out);
         CgProb &p = P.prob[i];
         p.ah = (const bf16_t *)s.ah; p.al = (const bf16_t *)s.al; p.bh = (const bf16_t *)s.bh; p.bl = (const bf16_t *)s.bl;
         p.c0 = s.c0; p.c1 = s.c1; p.ch = (bf16_t *)s.ch; p.cl = (bf16_t *)s.cl; p.bias = s.bias;
@@ -718,7 +758,25 @@ VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int3
         p.zero_rows = (int)rows_out;
         bytes += (double)s.nseq * s.H * Cin * 4 + (double)Cout * k * Cin * 4 + (double)M * Cout * (act ? 12 : 4);
     }
-    return cg_launch(P, act != 0 ? 1 : 0, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_FWD, bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ops) {      // 128 x 128 / 4 waves, two workgroups per CU: the layer is as much output-write- as MFMA-bound
+        VMASR_REQUIRE(Cout % 128 == 0, VMASR_EINVAL, "%s: Cout %% 128", what);
+        return cg_launch_cfg<128, 128, 2, 2, 32, 1>(P, act != 0 ? 1 : 0, st, VMASR_K_CONV_MFMA_FWD, bytes);
+    }
+    return cg_launch(P, act != 0 ? 1 : 0, st, VMASR_K_CONV_MFMA_FWD, bytes);
+}
+}  // namespace
+
+VMASR_EXPORT int vmasr_conv_mfma_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
+                                     int32_t pad, int64_t rows_out, int32_t act, vmasr_stream_t stream) {
+    return cg_fwd(slots, n, Cin, Cout, k, stride, pad, rows_out, act, stream, 0);
+}
+
+// The same stacked convolution with FP32 operands and exact-f32 products (v_mfma_f32_32x32x2_f32): slots' ah = x (fp32 rows of Cin),
+// bh = W (Cout, k Cin) fp32 in (tap, channel) order; al / bl are ignored.  Cin = 32 (the 32 -> 128 layer of model/discriminator.py:40-60).
+VMASR_EXPORT int vmasr_conv_f32_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
+                                    int32_t pad, int64_t rows_out, int32_t act, vmasr_stream_t stream) {
+    return cg_fwd(slots, n, Cin, Cout, k, stride, pad, rows_out, act, stream, 1);
 }
 
 namespace {
@@ -726,8 +784,9 @@ namespace {
 // The input gradient's problems (one per slot and residue class of the stride, plus one zero-fill problem per slot).  epi: the fused
 // activation backward of the layer below (vmasr_conv_mfma_dgrad_gelu), or null.
 int cg_dgrad(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const float *gtok, int32_t n, int32_t Cin, int32_t Cout, int32_t k,
-             int32_t stride, int32_t pad, int64_t rows_in, vmasr_stream_t stream) {
-    const char *what = epi ? "conv_mfma_dgrad_gelu" : "conv_mfma_dgrad";
+             int32_t stride, int32_t pad, int64_t rows_in, vmasr_stream_t stream, int ops = 0) {
+    const char *what = ops ? "conv_f32_dgrad" : epi ? "conv_mfma_dgrad_gelu" : "conv_mfma_dgrad";
+    VMASR_REQUIRE(!ops || (!epi && Cin == 32), VMASR_EINVAL, "%s: the f32 form serves Cin = 32 without a fused activation backward", what);
     VMASR_REQUIRE(slots && n >= 1 && n * (stride + 1) <= CG_MAXP, VMASR_EINVAL, "%s: too many slots", what);
     VMASR_REQUIRE(vmasr_conv_mfma_supported(Cin, Cout, k, stride), VMASR_EINVAL, "%s: unsupported shape (Cin %d, Cout %d, k %d, stride %d)", what,
                   Cin, Cout, k, stride);
@@ -739,8 +798,9 @@ int cg_dgrad(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const flo
     int np = 0;
     for (int i = 0; i < n; ++i) {
         const vmasr_cg_slot &s = slots[i];            // here: A = g (nseq * H1, Cout), B = W^T (Cin, k * Cout), c0 = dx (rows_in, Cin), H = H_in
-        VMASR_REQUIRE(s.ah && s.al && s.bh && s.bl && (epi ? (s.c0 || (s.ch && s.cl)) && (!s.ch == !s.cl) : s.c0 != nullptr), VMASR_EINVAL,
+        VMASR_REQUIRE(s.ah && s.bh && (ops || (s.al && s.bl)) && (epi ? (s.c0 || (s.ch && s.cl)) && (!s.ch == !s.cl) : s.c0 != nullptr), VMASR_EINVAL,
                       "%s: null tensor in slot %d", what, i);
+        VMASR_REQUIRE(!ops || (aligned_to(s.ah, 16) && aligned_to(s.bh, 16)), VMASR_EALIGN, "%s: slot %d: operands must be 16-byte aligned", what, i);
         VMASR_REQUIRE(!epi || (epi[i].pre && epi[i].valid >= 0 && (!epi[i].sgn || gtok)), VMASR_EINVAL,
                       "%s: slot %d: pre-activation missing (or a sign map without the loss gradient)", what, i);
         const int64_t H = s.H, H1 = (H + 2 * pad - k) / stride + 1;
@@ -784,6 +844,7 @@ int cg_dgrad(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const flo
         if (epi) bytes += (double)s.nseq * H * Cin * ((s.c0 && s.ch ? 4.0 : 0.0) + 4.0 + (epi[i].sgn ? 1.0 : 0.0));
     }
     P.nprob = np;
+    if (ops) return cg_launch_cfg<256, 32, 8, 1, 32, 1>(P, 0, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_DGRAD, bytes);
     return cg_launch(P, epi ? 2 : 0, static_cast<hipStream_t>(stream), VMASR_K_CONV_MFMA_DGRAD, bytes);
 }
 
@@ -792,6 +853,13 @@ int cg_dgrad(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const flo
 VMASR_EXPORT int vmasr_conv_mfma_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
                                        int32_t pad, int64_t rows_in, vmasr_stream_t stream) {
     return cg_dgrad(slots, nullptr, nullptr, n, Cin, Cout, k, stride, pad, rows_in, stream);
+}
+
+// Input gradient with FP32 operands and exact-f32 products: slots' ah = g (fp32 rows of Cout), bh = W^T (Cin, k Cout) fp32 in (tap, output
+// channel) order, c0 = dx (rows_in, Cin) fp32.  Cin = 32: no GEMM over a materialised column operand, no col2im.
+VMASR_EXPORT int vmasr_conv_f32_dgrad(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int32_t k, int32_t stride,
+                                      int32_t pad, int64_t rows_in, vmasr_stream_t stream) {
+    return cg_dgrad(slots, nullptr, nullptr, n, Cin, Cout, k, stride, pad, rows_in, stream, 1);
 }
 
 VMASR_EXPORT int vmasr_conv_mfma_dgrad_gelu(const vmasr_cg_slot *slots, const vmasr_cg_gelu_bwd *epi, const float *gtok, int32_t n, int32_t Cin,

@@ -816,18 +816,24 @@ class _StackedConvMfmaFn(torch.autograd.Function):
         from . import convgemm as cg
         x_req = x.requires_grad
         x = x.float().contiguous()
-        if xh is None:
-            xh, xl = split_bf16(x)
         w = weight.detach().float().contiguous()
+        f32 = x.shape[2] < 128 and _l1_mode() == "f32"       # the 32 -> 128 layer: exact-f32 products, forward and input gradient
         ops = wcache.get("ops") if wcache is not None else None
         if ops is None:
-            ops = {"w": split_bf16(w)}
+            ops = {} if f32 else {"w": split_bf16(w)}
             if wcache is not None:
                 wcache["ops"] = ops
-        wh, wl = ops["w"]
-        pre, y, yh, yl = cg.conv_fwd(xh, xl, wh, wl, bias.detach().float().contiguous(), geom, k, stride, pad, rows, act=True)
+        if f32:
+            pre, y, yh, yl = cg.conv_fwd_f32(x, w, bias.detach().float().contiguous(), geom, k, stride, pad, rows, act=True)
+            xh = xl = x                                       # (the bf16 pair of x is made in the backward, where the weight gradient wants it)
+        else:
+            if xh is None:
+                xh, xl = split_bf16(x)
+            wh, wl = ops["w"]
+            pre, y, yh, yl = cg.conv_fwd(xh, xl, wh, wl, bias.detach().float().contiguous(), geom, k, stride, pad, rows, act=True)
         out_pair.append((yh, yl))
         ctx.save_for_backward(xh, xl, pre, w)
+        ctx.f32 = f32
         ctx.meta = (k, stride, pad, tuple(geom), ops, weight.dtype, bias.dtype, x.shape)
         ctx.link, ctx.below = link, below
         if link is not None:
@@ -878,9 +884,10 @@ class _StackedConvMfmaFn(torch.autograd.Function):
         lib = _lib.lib()
         skip_w = _PHASE["skip_weight_grads"]
         want_db = ctx.needs_input_grad[8] and not skip_w
-        # The input gradient of the 32 -> 128 layer stays an fp32 GEMM + col2im: it is the last GEMM in front of d(loss)/d(wave), a sum
-        # with heavy cancellation, where the pair's 16-17 bits per product showed (2.5e-3 of the gradient's scale from float64 against
-        # 4e-4 for fp32 — tests/test_mpd.py holds 5e-4); its forward and weight gradient take the MFMA kernels like the other layers
+        # The input gradient of the 32 -> 128 layer stays FP32 arithmetic: it is the last GEMM in front of d(loss)/d(wave), a sum with heavy
+        # cancellation, where the pair's 16-17 bits per product showed (2.5e-3 of the gradient's scale from float64 against 4e-4 for fp32 —
+        # tests/test_mpd.py holds 5e-4).  Default (ctx.f32): the exact-f32 MFMA implicit GEMM; VMASR_MPD_CONV_L1=1: fp32 library GEMM + col2im.
+        # The weight gradient takes the bf16x3 kernel like the other layers
         fp32_dgrad = C < 128 and ctx.needs_input_grad[9]
         need_pair = (not fp32_dgrad and ctx.needs_input_grad[9]) or (ctx.needs_input_grad[7] and not skip_w)
         gh = gl = gx = None
@@ -909,7 +916,11 @@ class _StackedConvMfmaFn(torch.autograd.Function):
                                               db32.data_ptr() if (want_db and not need_pair) else None, n, M, N,
                                               _lib.current_stream(gy.device)), "gelu_bwd")
         dx = dw = db = None
-        if fp32_dgrad:
+        if fp32_dgrad and ctx.f32:
+            if "wt32" not in ops:      # (n, Cout, k, C) -> (n, C, k*Cout) fp32: the input gradient's B operand, (tap, output channel) order
+                ops["wt32"] = w.view(n, N, k, C).permute(0, 3, 2, 1).reshape(n, C, k * N).contiguous()
+            dx = cg.conv_dgrad_f32(gx, ops["wt32"], geom, k, stride, pad, xshape[1])      # exact-f32 implicit GEMM: no column operand, no col2im
+        elif fp32_dgrad:
             dcols = torch.bmm(gx, w)                                      # (n, M, k*C) fp32
             with torch.cuda.device(gy.device):
                 dx = torch.empty(xshape, dtype=torch.float32, device=gy.device)
@@ -926,6 +937,8 @@ class _StackedConvMfmaFn(torch.autograd.Function):
                 dx = cg.conv_dgrad(gh, gl, wth, wtl, geom, k, stride, pad, xshape[1])
         if not skip_w:
             if ctx.needs_input_grad[7]:
+                if ctx.f32:
+                    xh, xl = split_bf16(xh)                                # (saved as the fp32 input)
                 dw = cg.conv_wgrad(gh, gl, xh, xl, geom, k, stride, pad).to(wdt)
             if want_db:
                 db = db32.to(bdt)
@@ -941,6 +954,11 @@ def _poison(device):
     if t is None:
         t = _POISON[device] = torch.full((), float("nan"), dtype=torch.float32, device=device)
     return t
+
+
+def _l1_mode():
+    """how the 32 -> 128 layer runs: "f32" (default) exact-f32 MFMA implicit GEMM, "1" bf16x3 pairs (forward below the accuracy gate), "0" library GEMMs"""
+    return os.environ.get("VMASR_MPD_CONV_L1", "f32")
 
 
 def det_mode():
@@ -1340,17 +1358,18 @@ class MultiPeriodDiscriminator(nn.Module):
                 y = _StackedConvFirstFn.apply(_round_up(max(Ms), 256), W, bstack, *cur)
             elif (cdt == torch.float32 and os.environ.get("VMASR_MPD_GEMM", "bf16x3") == "bf16x3" and act and sgeom is not None
                   and os.environ.get("VMASR_MPD_CONV", "mfma") == "mfma"
-                  and (cur[0].shape[3] >= 128 or os.environ.get("VMASR_MPD_CONV_L1", "0") == "1")
+                  and (cur[0].shape[3] >= 128 or _l1_mode() != "0")
                   # (shape, slot count and row count of the whole stacked launch: an MPD with more periods or a longer segment than
                   #  the launchers address falls through to the split-GEMM path below)
                   and _lib.lib().vmasr_conv_mfma_supported_launch(cur[0].shape[3], W.shape[1], k, stride, n,
                                                                   max(_round_up(max(Ms), 256), max(g[0] * g[1] for g in sgeom)))):
                 # the three compute-bound layers (128 -> 512 -> 1024 -> 1024): one implicit-GEMM launch each way (csrc/convgemm.hip); the
-                # layer's epilogue leaves the bf16 pair of its activation for the next layer.  The 32 -> 128 layer CAN take the same
-                # kernels (256 x 128 / 256 x 32 / 128 x 32 tile configurations, VMASR_MPD_CONV_L1=1: 28.7 -> 28.0 ms per step) but stays on
-                # fp32 GEMMs by default: it is the first GEMM behind the signal, and with its forward at the pair's 16-17 bits the input
-                # gradient d(loss)/d(wave) of an |f|-type loss moved to 2.5e-3 of its scale from float64 (fp32: 4e-4; gate 5e-4,
-                # tests/test_mpd.py) — near-zero GELU outputs change sign
+                # layer's epilogue leaves the bf16 pair of its activation for the next layer.  The 32 -> 128 layer takes the same kernels
+                # in their EXACT-F32 form (round 6, VMASR_MPD_CONV_L1=f32, the default: fp32 operands, v_mfma_f32_32x32x2_f32, forward and
+                # input gradient; the weight gradient as a bf16x3 triple): it is the first GEMM behind the signal, and with its forward at
+                # the pair's 16-17 bits (VMASR_MPD_CONV_L1=1) the input gradient d(loss)/d(wave) of an |f|-type loss moved to 2.5e-3 of its
+                # scale from float64 (fp32: 4e-4; gate 5e-4, tests/test_mpd.py) — near-zero GELU outputs change sign.  =0: the round-5
+                # path (im2col + fp32 library GEMM + bias / GELU pass; GEMM + col2im)
                 wcache = None
                 if self._frozen is not None:
                     wcache = self._frozen.setdefault(("mfma_ops", li), {})

@@ -1265,6 +1265,17 @@ class Trainer(BaseTrainer):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision: the slowest rank's time
             return float(t.item())
 
+        # No cyclic garbage collection from here until the chosen capture has been replayed: a collection that runs between a capture and
+        # its first replays — it destroys whatever cycles the capture left behind: autograd contexts with their closures, an earlier
+        # trainer's graphs — crashed the process inside hipGraphLaunch in 3 of 16 runs of tests/test_trainer.py's layout test (host-side
+        # segmentation fault, both with and without this round's changes); with the collector off across captures AND timed replays:
+        # 0 of 12 (tools/hunt22.sh, hunt23.sh; a device synchronisation after the collection alone did not help: 2 of 12).  One
+        # collection at the end, behind a device synchronisation.
+        import gc as _gc
+        _gc_on = _gc.isenabled() and os.environ.get("VMASR_GRAPH_GC_GUARD", "1") == "1"
+        if _gc_on:
+            _gc.collect()
+            _gc.disable()
         use(candidates[0])
         ok = attempt()
         if (not ok and multi and dist.get_backend() == "nccl" and self.graph_collectives()):
@@ -1297,9 +1308,17 @@ class Trainer(BaseTrainer):
             torch.cuda.empty_cache()
         if not ok:
             self.logger.warning("running eagerly")
+        elif _gc_on:
+            self._graphed(*example_batch)          # the kept capture's first replay happens HERE, before the collector runs again (see above)
+            torch.cuda.synchronize(self.device)
         if snap is not None:
             torch.cuda.synchronize(self.device)
             self._restore_training_state(snap)
+        if _gc_on:
+            torch.cuda.synchronize(self.device)
+            _gc.collect()
+            torch.cuda.synchronize(self.device)
+            _gc.enable()
         return ok
 
     def graph_collectives(self):
