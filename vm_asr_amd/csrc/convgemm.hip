@@ -761,6 +761,8 @@ int cg_fwd(const vmasr_cg_slot *slots, int32_t n, int32_t Cin, int32_t Cout, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ops) {      // 128 x 128 / 4 waves, two workgroups per CU: the layer is as much output-write- as MFMA-bound
         VMASR_REQUIRE(Cout % 128 == 0, VMASR_EINVAL, "%s: Cout %% 128", what);
+        static const int tile = [] { const char *e = getenv("VMASR_CONV_F32_TILE"); return e ? atoi(e) : 128; }();
+        if (tile == 256) return cg_launch_cfg<256, 128, 4, 2, 32, 1>(P, act != 0 ? 1 : 0, st, VMASR_K_CONV_MFMA_FWD, bytes);
         return cg_launch_cfg<128, 128, 2, 2, 32, 1>(P, act != 0 ? 1 : 0, st, VMASR_K_CONV_MFMA_FWD, bytes);
     }
     return cg_launch(P, act != 0 ? 1 : 0, st, VMASR_K_CONV_MFMA_FWD, bytes);
