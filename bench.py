@@ -600,6 +600,7 @@ def main():
                             "(what rocprofv3 of the two-stream step sees): durations of kernels that have a share of the chip, not a statement about the kernels",
                     "kernel": dom, "achieved": d2["gbs"], "frac": d2["gbs"] / HBM_PEAK_GBS, "avg_launch_us": d2["avg_us"],
                     "selective_scan_op": op2,
+                    "shapes": shape_table(shared_prof, dom),      # per call shape, beside `roofline.shapes` (alone on the chip)
                     "kernels": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbs"], 1),
                                     "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in sorted(kern2.items())}}
     if rank == 0 and world == 1 and not args.no_extra_points and args.workload == "vm_asr_48k_MPD" and not args.batch and not args.no_graphs:
