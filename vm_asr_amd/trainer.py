@@ -1180,6 +1180,29 @@ class Trainer(BaseTrainer):
         With preserve_state=False all of it STAYS: up to three captures x (warm-up + 8 timed replays) = ~30 extra optimisation steps on
         `example_batch`, and the layout is chosen by timings that differ by 1-5 % (it can differ between runs, which changes the order of
         the atomic additions): pin it with VMASR_STEP_VARIANT (one | lane | lane:<share>) for reproducible runs."""
+        # No cyclic garbage collection from here until the kept capture has been replayed: a collection that runs between a capture and
+        # its first replays — it destroys whatever cycles the capture left behind: autograd contexts with their closures, an earlier
+        # trainer's graphs — crashed the process inside hipGraphLaunch in 5 of 28 runs of tests/test_trainer.py's layout test (host-side
+        # segmentation fault, with and without round 6's changes); with the collector off across captures AND timed replays: 0 of 38
+        # (profiles/r06_replay_segfault.md; a device synchronisation after the collection alone did not help: 2 of 12).  One
+        # collection at the end, behind a device synchronisation.  VMASR_GRAPH_GC_GUARD=0: off.
+        import gc as _gc
+        guard = _gc.isenabled() and os.environ.get("VMASR_GRAPH_GC_GUARD", "1") == "1"
+        if guard:
+            _gc.collect()
+            _gc.disable()
+        try:
+            return self._enable_graphs(example_batch, warmup, preserve_state, first_replay=True)      # (every rank alike: the replay holds collectives)
+        finally:
+            if guard:
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                _gc.collect()
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                _gc.enable()
+
+    def _enable_graphs(self, example_batch, warmup, preserve_state, first_replay):
         from .graph_step import GraphedTrainStep
         snap = self._snapshot_training_state() if preserve_state else None
         multi = self.world > 1 and dist.is_initialized()
@@ -1265,17 +1288,6 @@ class Trainer(BaseTrainer):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision: the slowest rank's time
             return float(t.item())
 
-        # No cyclic garbage collection from here until the chosen capture has been replayed: a collection that runs between a capture and
-        # its first replays — it destroys whatever cycles the capture left behind: autograd contexts with their closures, an earlier
-        # trainer's graphs — crashed the process inside hipGraphLaunch in 3 of 16 runs of tests/test_trainer.py's layout test (host-side
-        # segmentation fault, both with and without this round's changes); with the collector off across captures AND timed replays:
-        # 0 of 12 (tools/hunt22.sh, hunt23.sh; a device synchronisation after the collection alone did not help: 2 of 12).  One
-        # collection at the end, behind a device synchronisation.
-        import gc as _gc
-        _gc_on = _gc.isenabled() and os.environ.get("VMASR_GRAPH_GC_GUARD", "1") == "1"
-        if _gc_on:
-            _gc.collect()
-            _gc.disable()
         use(candidates[0])
         ok = attempt()
         if (not ok and multi and dist.get_backend() == "nccl" and self.graph_collectives()):
@@ -1308,17 +1320,12 @@ class Trainer(BaseTrainer):
             torch.cuda.empty_cache()
         if not ok:
             self.logger.warning("running eagerly")
-        elif _gc_on:
-            self._graphed(*example_batch)          # the kept capture's first replay happens HERE, before the collector runs again (see above)
+        elif first_replay:
+            self._graphed(*example_batch)          # the kept capture's first replay happens HERE, before the collector runs again (enable_graphs)
             torch.cuda.synchronize(self.device)
         if snap is not None:
             torch.cuda.synchronize(self.device)
             self._restore_training_state(snap)
-        if _gc_on:
-            torch.cuda.synchronize(self.device)
-            _gc.collect()
-            torch.cuda.synchronize(self.device)
-            _gc.enable()
         return ok
 
     def graph_collectives(self):
